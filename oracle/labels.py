@@ -1,0 +1,116 @@
+"""Oracle: uncertainty estimator, label merge, losses and metrics of the pseudo-label pass.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  numpy for the integer work, torch-CPU fp32
+for the floating point.  Citations are relative to /root/reference.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# data_loader/segmentation/greenhouse.py:15-58 (source-dataset class id -> 5 greenhouse classes).
+ID_CAMVID_TO_GREENHOUSE = np.array([4, 2, 2, 3, 3, 1, 2, 2, 2, 4, 4, 2, 4])
+ID_CITYSCAPES_TO_GREENHOUSE = np.array([3, 3, 2, 2, 2, 2, 2, 2, 1, 3, 4, 4, 4, 2, 2, 2, 2, 2, 2, 4])
+ID_FOREST_TO_GREENHOUSE = np.array([3, 1, 1, 2, 2])
+LUTS = {'camvid': ID_CAMVID_TO_GREENHOUSE, 'cityscapes': ID_CITYSCAPES_TO_GREENHOUSE,
+        'forest': ID_FOREST_TO_GREENHOUSE}
+GREENHOUSE_CLASSES = 5
+NO_AGREEMENT_CLASS = 4  # the literal 4 written at uest_seg_multi_os.py:716
+
+
+def pixelwise_kld(d1, d2):
+    """PixelwiseKLD.forward, loss_fns/segmentation_loss.py:181-189: sum_c p1*(logp1 - logp2)."""
+    p1 = F.softmax(d1, dim=1)
+    lp1 = F.log_softmax(d1, dim=1)
+    lp2 = F.log_softmax(d2, dim=1)
+    return torch.sum(p1 * lp1 - p1 * lp2, dim=1)
+
+
+def get_output(pred, pred_aux):
+    """get_output, uest_seg_multi_os.py:685-693, applied to every batch element.
+
+    The reference keeps batch element 0 only (bs=1 loop); the batched restatement returns the same
+    thing for each element.  Returns (softmax(pred + 0.5 aux) as (N,C,H,W), kld as (N,H,W)).
+    """
+    prob = F.softmax(pred + 0.5 * pred_aux, dim=1)
+    return prob, pixelwise_kld(pred, pred_aux)
+
+
+def argmax_labels(prob):
+    """uest_seg_multi_os.py:903-904: np.argmax over the class axis (first max wins) -> uint8."""
+    out = prob.numpy() if isinstance(prob, torch.Tensor) else prob
+    return np.asarray(np.argmax(out.transpose(0, 2, 3, 1), axis=3), dtype=np.uint8)
+
+
+def to_greenhouse(amax, os_data):
+    """uest_seg_multi_os.py:907-912: LUT for the three outsource datasets, identity otherwise."""
+    lut = LUTS.get(os_data)
+    return amax if lut is None else lut[amax]
+
+
+def merge_outputs(amax_outputs, seg_classes=GREENHOUSE_CLASSES, thresh=None):
+    """merge_outputs, uest_seg_multi_os.py:695-718.  amax_outputs: (S, ...) integer class maps."""
+    num_data = amax_outputs.shape[0]
+    if thresh is None or thresh == 'half':
+        thresh = num_data // 2 + 1
+    elif thresh == 'all':
+        thresh = num_data
+    elif isinstance(thresh, int) and not isinstance(thresh, bool) and thresh <= num_data:
+        pass
+    else:
+        thresh = num_data // 2 + 1
+    counts = np.array([(amax_outputs == c).sum(axis=0) for c in range(seg_classes)])
+    amax = counts.argmax(axis=0)
+    amax[counts.max(axis=0) < thresh] = NO_AGREEMENT_CLASS
+    return amax
+
+
+def class_histogram(merged, classes=GREENHOUSE_CLASSES):
+    """uest_seg_multi_os.py:919-921."""
+    return np.array([(merged == i).sum() for i in range(classes)], dtype=np.float64)
+
+
+def class_weights_from_histogram(class_array, policy='normal'):
+    """uest_seg_multi_os.py:942-947."""
+    class_array = np.asarray(class_array, dtype=np.float64)
+    if policy == 'normal':
+        freq = class_array / class_array.sum()
+        w = 1.0 / (freq + 1e-10)
+        w[0] = 0.0
+        return w
+    return np.ones(len(class_array))
+
+
+def uw_seg_loss(pred, target, u_weight, class_weights, ignore_idx=None):
+    """UncertaintyWeightedSegmentationLoss.forward, loss_fns/segmentation_loss.py:155-175.
+
+    class_weights[ignore_idx] is zeroed (:152-153, on a copy here); the mean runs over ALL pixels.
+    """
+    cw = class_weights.clone()
+    if ignore_idx is not None:
+        cw[ignore_idx] = 0.0
+    n, c, h, w = pred.shape
+    logp = -F.log_softmax(pred, dim=1)
+    logp = logp * cw.reshape(1, c, 1, 1)
+    logp = logp.gather(1, target.view(n, 1, h, w))
+    logp = logp * torch.exp(-u_weight.reshape(n, 1, h, w))
+    return logp.mean()
+
+
+def uest_train_loss(pred, pred_aux, labels, class_weights, ignore_idx=None):
+    """uest_seg_multi_os.py:1020-1023: criterion(pred+0.5aux, labels, kld)*20 + kld.mean() (kld not detached)."""
+    kld = pixelwise_kld(pred, pred_aux)
+    return uw_seg_loss(pred + 0.5 * pred_aux, labels, kld, class_weights, ignore_idx) * 20 + kld.mean()
+
+
+def miou_areas(output, target, num_classes):
+    """MIOU.get_iou, utilities/metrics/segmentation_miou.py:13-44 (uint8 arithmetic, 255 wraps to 0)."""
+    pred = output.argmax(1) if output.dim() == 4 else output
+    pred = pred.to(torch.uint8) + 1
+    target = target.to(torch.uint8) + 1
+    pred = pred * (target > 0)
+    inter = pred * (pred == target)
+    k = num_classes
+    a_i = torch.histc(inter.float(), bins=k, min=1, max=k)
+    a_p = torch.histc(pred.float(), bins=k, min=1, max=k)
+    a_m = torch.histc(target.float(), bins=k, min=1, max=k)
+    return a_i.numpy(), (a_p + a_m - a_i + 1e-6).numpy()

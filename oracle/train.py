@@ -1,0 +1,36 @@
+"""Oracle: one uest self-training step (forward, UW-loss*20 + KLD, backward, Adam) on CPU.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows uest_seg_multi_os.py:1012-1041 with
+torch.optim.Adam semantics (L2 weight decay folded into the gradient; parameters whose gradient
+is None are skipped entirely).  BatchNorm is frozen (eval mode, Appendix B-3).
+"""
+import torch
+
+from . import labels as olab
+from . import net as onet
+
+
+def train_step(sd, param_names, x, labels, class_weights, ignore_idx, lr=5e-4, weight_decay=5e-4,
+               betas=(0.9, 0.999), eps=1e-8):
+    """Returns (loss, {name: grad or None}, {name: updated tensor}) for the first Adam step."""
+    work = dict(sd)
+    params = {}
+    for n in param_names:
+        params[n] = sd[n].clone().requires_grad_(True)
+        work[n] = params[n]
+    main, aux = onet.espdnet_ue_forward(work, x)
+    loss = olab.uest_train_loss(main, aux, labels, class_weights, ignore_idx)
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    gmap, new = {}, {}
+    b1, b2 = betas
+    for (n, p), g in zip(params.items(), grads):
+        gmap[n] = g
+        if g is None:
+            new[n] = p.detach()
+            continue
+        g = g + weight_decay * p.detach()
+        m = (1 - b1) * g
+        v = (1 - b2) * g * g
+        denom = (v.sqrt() / (1 - b2) ** 0.5) + eps
+        new[n] = p.detach() - (lr / (1 - b1)) * (m / denom)
+    return loss.detach(), gmap, new

@@ -1,0 +1,36 @@
+"""Case tables shared by tests/golden/make_golden.py (reference side) and the tests (oracle / HIP side)."""
+
+# name -> (kind, constructor kwargs, input shape, optional second-input shape)
+LAYER_CASES = {
+    # EESP stride 1, d = [1,2,3,4] (r_lim 9) and d = [1,1,2,3] (r_lim 7); residual path active
+    'eesp_s1_r9': ('eesp', dict(nIn=32, nOut=32, stride=1, k=4, r_lim=9), (2, 32, 20, 28), None),
+    'eesp_s1_r7': ('eesp', dict(nIn=64, nOut=64, stride=1, k=4, r_lim=7), (2, 64, 12, 15), None),
+    # EESP with nIn != nOut: no residual
+    'eesp_s1_nores': ('eesp', dict(nIn=16, nOut=32, stride=1, k=4, r_lim=13), (1, 16, 9, 14), None),
+    # DownSampler with image reinforcement (image is 2x the feature resolution, pooled twice)
+    'down_r13_reinf': ('down', dict(nin=16, nout=48, k=4, r_lim=13, reinf=True), (2, 16, 24, 40), (2, 3, 48, 80)),
+    # DownSampler called without the image (ESPNetv2 level2_0, model/segmentation/espnetv2.py:127)
+    'down_r9_noimg': ('down', dict(nin=32, nout=64, k=4, r_lim=9, reinf=True), (1, 32, 16, 20), None),
+    # odd input size: 3x3/s2/p1 pooling and strided depthwise on 15x21
+    'down_r11_odd': ('down', dict(nin=16, nout=32, k=4, r_lim=11, reinf=True), (1, 16, 15, 21), (1, 3, 60, 84)),
+    # EfficientPyrPool, with and without the trailing BR (biased 1x1 in the latter)
+    'pyr_br': ('pyr', dict(in_planes=24, proj_planes=8, out_planes=12, last_layer_br=True), (2, 24, 14, 22), None),
+    'pyr_nobr': ('pyr', dict(in_planes=12, proj_planes=16, out_planes=5, last_layer_br=False), (1, 12, 16, 30), None),
+    # tiny map: every scale < 1 hits the clamp-to-5 branch (efficient_pyramid_pool.py:43-44)
+    'pyr_tiny': ('pyr', dict(in_planes=8, proj_planes=4, out_planes=6, last_layer_br=True), (1, 8, 6, 9), None),
+    # EfficientPWConv: grouped (gcd 8) and depthwise (gcd 16) expansion
+    'pw_g8': ('pw', dict(nin=32, nout=24), (2, 32, 10, 14), None),
+    'pw_dw': ('pw', dict(nin=16, nout=16), (1, 16, 12, 9), None),
+}
+
+# whole-model cases: name -> (model kind, s, classes, dataset, input shape, sd seed, input seed)
+MODEL_CASES = {
+    'ue_c13_small': ('espdnetue', 2.0, 13, 'camvid', (1, 3, 48, 64), 11, 0),
+    'ue_c5_small': ('espdnetue', 2.0, 5, 'greenhouse', (2, 3, 32, 48), 12, 1),
+    'ue_c20_small': ('espdnetue', 2.0, 20, 'city', (1, 3, 32, 32), 13, 2),
+    'v2_s05_c13_small': ('espnetv2', 0.5, 13, 'camvid', (2, 3, 32, 64), 14, 3),
+    'ue_c13_256x480': ('espdnetue', 2.0, 13, 'camvid', (1, 3, 256, 480), 11, 4),
+}
+
+TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), sd_seed=21, in_seed=5,
+                  lr=5e-4, weight_decay=5e-4, ignore_idx=4)

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules on CPU.
+
+Run once in the build container (the reference never travels to the GPU box):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo \
+        python3 tests/golden/make_golden.py
+
+Only data is written (inputs are regenerated from seeds by tests/synth.py; outputs are stored by
+value).  The one reference data file taken along is the smallest zoo checkpoint
+(model/segmentation/model_zoo/espnetv2/espnetv2_s_0.5_city_512x256.pth, weights only), stored as
+an .npz so the real-weights case can run without /root/reference.
+"""
+import argparse
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests.cases import LAYER_CASES, MODEL_CASES, TRAIN_CASE  # noqa: E402
+from tests.synth import synth_input, synth_labels, synth_state_dict  # noqa: E402
+
+# reference imports (torch-only modules)
+from nn_layers.eesp import EESP, DownSampler  # noqa: E402
+from nn_layers.efficient_pyramid_pool import EfficientPyrPool  # noqa: E402
+from nn_layers.efficient_pt import EfficientPWConv  # noqa: E402
+from model.segmentation.espdnet_ue import ESPDNetwithUncertaintyEstimation  # noqa: E402
+from model.segmentation.espnetv2 import ESPNetv2Segmentation  # noqa: E402
+from loss_fns.segmentation_loss import PixelwiseKLD, UncertaintyWeightedSegmentationLoss  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print('wrote %s (%.1f KiB)' % (path, os.path.getsize(path) / 1024))
+
+
+def build_layer(kind, kw):
+    if kind == 'eesp':
+        return EESP(**kw)
+    if kind == 'down':
+        return DownSampler(**kw)
+    if kind == 'pyr':
+        return EfficientPyrPool(scales=[2.0, 1.5, 1.0, 0.5, 0.1], **kw)
+    if kind == 'pw':
+        return EfficientPWConv(**kw)
+    raise KeyError(kind)
+
+
+def build_model(kind, s, classes, dataset):
+    a = argparse.Namespace(s=s, channels=3, num_classes=1000)
+    if kind == 'espdnetue':
+        return ESPDNetwithUncertaintyEstimation(a, classes=classes, dataset=dataset, fix_pyr_plane_proj=True)
+    return ESPNetv2Segmentation(a, classes=classes, dataset=dataset)
+
+
+def gen_layers():
+    out = {}
+    keys = {}
+    for i, (name, (kind, kw, shp, shp2)) in enumerate(sorted(LAYER_CASES.items())):
+        m = build_layer(kind, kw).eval()
+        keys[name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synth_state_dict(m.state_dict(), 100 + i))
+        x = synth_input(shp, 200 + i)
+        with torch.no_grad():
+            y = m(x, synth_input(shp2, 300 + i)) if shp2 is not None else m(x)
+        out[name] = y
+    save('layers', **out)
+    with open(os.path.join(HERE, 'layer_keys.json'), 'w') as f:
+        json.dump(keys, f, sort_keys=True)
+
+
+def gen_models():
+    keysets = {}
+    for name, (kind, s, classes, dataset, shp, sd_seed, in_seed) in sorted(MODEL_CASES.items()):
+        m = build_model(kind, s, classes, dataset).eval()
+        sd = m.state_dict()
+        keysets['%s_s%s_c%d' % (kind, s, classes)] = {k: list(v.shape) for k, v in sd.items()}
+        m.load_state_dict(synth_state_dict(sd, sd_seed))
+        x = synth_input(shp, in_seed)
+        with torch.no_grad():
+            y = m(x)
+        if kind == 'espdnetue':
+            main, aux = y
+            kld = PixelwiseKLD()(main, aux)
+            prob = torch.softmax(main + 0.5 * aux, 1)
+            amax = np.argmax(prob.numpy().transpose(0, 2, 3, 1), axis=3).astype(np.uint8)
+            srt = torch.sort(prob, dim=1, descending=True)[0]
+            margin = (srt[:, 0] - srt[:, 1])
+            if shp[2] * shp[3] > 64 * 64:
+                st = 8
+                save('model_' + name, main=main[:, :, ::st, ::st], aux=aux[:, :, ::st, ::st],
+                     kld=kld[:, ::st, ::st], amax=amax, margin=margin.half(), stride=st)
+            else:
+                save('model_' + name, main=main, aux=aux, kld=kld, amax=amax, margin=margin.half(), stride=1)
+        else:
+            save('model_' + name, main=y, stride=1)
+    with open(os.path.join(HERE, 'state_dict_keys.json'), 'w') as f:
+        json.dump(keysets, f, sort_keys=True)
+    print('param counts:', {k: sum(int(np.prod(s)) for kk, s in v.items()
+                                   if not kk.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+                            for k, v in keysets.items()})
+
+
+def gen_zoo():
+    """Real weights: ESPNetv2 s=0.5, Cityscapes 512x256 checkpoint (strict load), BASELINE config 1 shape."""
+    src = os.path.join(REF, 'model/segmentation/model_zoo/espnetv2/espnetv2_s_0.5_city_512x256.pth')
+    sd = torch.load(src, map_location='cpu')
+    m = build_model('espnetv2', 0.5, 20, 'city').eval()
+    m.load_state_dict(sd, strict=True)
+    np.savez_compressed(os.path.join(HERE, 'zoo_espnetv2_s0.5_city_512x256.npz'),
+                        **{k: v.numpy() for k, v in sd.items()})
+    x = synth_input((2, 3, 288, 480), 40)
+    with torch.no_grad():
+        y = m(x)
+    amax = y.argmax(1).to(torch.uint8)
+    srt = torch.sort(y, dim=1, descending=True)[0]
+    save('model_v2_zoo_288x480', main=y[:, :, ::8, ::8], amax=amax, margin=(srt[:, 0] - srt[:, 1]).half(),
+         class_sum=y.double().sum((0, 2, 3)), abs_sum=y.double().abs().sum(), stride=8)
+
+
+def extract_functions(path, names, ns):
+    """AST-extract pure functions from a script that cannot be imported (argparse at import time)."""
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, 'exec'), ns)
+    return ns
+
+
+def gen_labels():
+    ns = {'np': np, 'args': argparse.Namespace(classes=5)}
+    extract_functions(os.path.join(REF, 'uest_seg_multi_os.py'), {'merge_outputs'}, ns)
+    merge = ns['merge_outputs']
+    out = {}
+    # exhaustive truth tables: S sources x 5 classes, every policy the CLI can produce (strings) + None
+    for S in (1, 2, 3, 4):
+        grids = np.stack(np.meshgrid(*[np.arange(5)] * S, indexing='ij')).reshape(S, -1)
+        out['tt_in_S%d' % S] = grids.astype(np.uint8)
+        for pol in ('all', 'half', 'none'):
+            out['tt_S%d_%s' % (S, pol)] = merge(grids, 5, None if pol == 'none' else pol).astype(np.uint8)
+    rng = np.random.RandomState(7)
+    rnd = rng.randint(0, 5, size=(3, 64, 96)).astype(np.uint8)
+    out['rnd_in'] = rnd
+    out['rnd_all'] = merge(rnd, 5, 'all').astype(np.uint8)
+    out['rnd_half'] = merge(rnd, 5, 'half').astype(np.uint8)
+    # LUTs as data (data_loader/segmentation/greenhouse.py:15-58 are literal arrays; file not importable)
+    tree = ast.parse(open(os.path.join(REF, 'data_loader/segmentation/greenhouse.py')).read())
+    lns = {'np': np}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], 'id', '').startswith('id_'):
+            exec(compile(ast.Module([node], []), 'greenhouse', 'exec'), lns)
+    for k in ('id_camvid_to_greenhouse', 'id_cityscapes_to_greenhouse', 'id_forest_to_greenhouse'):
+        out['lut_' + k] = lns[k].astype(np.int64)
+    # uncertainty estimator on small logits
+    for C in (5, 13, 20):
+        d1 = synth_input((2, C, 12, 20), 50 + C) * 3
+        d2 = synth_input((2, C, 12, 20), 70 + C) * 3
+        out['kld_C%d' % C] = PixelwiseKLD()(d1, d2)
+        out['prob_C%d' % C] = torch.nn.Softmax2d()(d1 + 0.5 * d2)
+    save('labels', **out)
+
+
+def gen_loss():
+    pred = (synth_input((2, 5, 32, 48), 90) * 2).requires_grad_(True)
+    aux = (synth_input((2, 5, 32, 48), 91) * 2).requires_grad_(True)
+    tgt = synth_labels((2, 32, 48), 5, 92)
+    cw = torch.tensor([0.0, 6.31, 3.78, 3.18, 7.64])
+    crit = UncertaintyWeightedSegmentationLoss(5, class_weights=cw.clone(), ignore_idx=4, device='cpu')
+    kld = PixelwiseKLD()(pred, aux)
+    loss = crit(pred + 0.5 * aux, tgt, kld) * 20 + kld.mean()
+    loss.backward()
+    torch.autograd.set_detect_anomaly(False)
+    save('loss', loss=loss.detach(), dpred=pred.grad, daux=aux.grad, cw=cw)
+
+
+def gen_train():
+    c = TRAIN_CASE
+    m = build_model('espdnetue', c['s'], c['classes'], c['dataset']).eval()  # eval: uest default (Appendix B-3)
+    m.load_state_dict(synth_state_dict(m.state_dict(), c['sd_seed']))
+    x = synth_input(c['shape'], c['in_seed'])
+    labels = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed'])
+    opt = torch.optim.Adam(m.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
+    crit = UncertaintyWeightedSegmentationLoss(c['classes'], class_weights=torch.ones(c['classes']),
+                                               ignore_idx=c['ignore_idx'], device='cpu')
+    opt.zero_grad()
+    pred, aux = m(x)
+    kld = PixelwiseKLD()(pred, aux)
+    loss = crit(pred + 0.5 * aux, labels, kld) * 20 + kld.mean()
+    loss.backward()
+    torch.autograd.set_detect_anomaly(False)
+    names = [n for n, _ in m.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in m.named_parameters()])
+    gsum = np.array([float(p.grad.double().sum()) if p.grad is not None else 0.0 for _, p in m.named_parameters()])
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt.step()
+    delta = np.array([float((p.detach() - before[n]).double().norm()) for n, p in m.named_parameters()])
+    keep = ['base_net.level1.conv.weight', 'base_net.level4.6.spp_dw.3.conv.weight', 'bu_dec_l4.merge_layer.3.bias',
+            'depth_base_net.level3.1.proj_1x1.act.weight', 'aux_decoder.stages.0.weight',
+            'merge_enc_dec_l3.wt_layer.1.weight', 'bu_br_l3.0.weight', 'base_net.level2_0.inp_reinf.1.bn.bias']
+    pd = dict(m.named_parameters())
+    save('train_step', loss=loss.detach(), names=np.array(names), gnorm=gnorm, gsum=gsum, delta=delta,
+         keep=np.array(keep), **{'after_%d' % i: pd[k].detach() for i, k in enumerate(keep)})
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train']
+    for w in which:
+        globals()['gen_' + w]()

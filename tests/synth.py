@@ -1,0 +1,62 @@
+"""Deterministic synthetic state dicts and inputs shared by the golden generator and the tests.
+
+Every tensor is a pure function of (key name, shape, seed), so the reference-side generator
+(tests/golden/make_golden.py, run once in the build container) and the tests (run anywhere) see
+bit-identical weights without committing megabytes of parameters.  BatchNorm statistics, affine
+terms and PReLU slopes are randomised on purpose: the reference's own init (gamma=1, beta=0,
+mean=0, var=1, slope=0.25) would make a folded-BN bug invisible.
+"""
+import zlib
+
+import torch
+
+
+def _gen(key, seed):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
+    return g
+
+
+def synth_tensor(key, shape, seed, template_keys):
+    shape = tuple(shape)
+    g = _gen(key, seed)
+    stem, _, leaf = key.rpartition('.')
+    if leaf == 'num_batches_tracked':
+        return torch.zeros(shape, dtype=torch.int64)
+    if leaf == 'running_mean':
+        return torch.randn(shape, generator=g) * 0.1
+    if leaf == 'running_var':
+        return torch.rand(shape, generator=g) + 0.5
+    is_bn = (stem + '.running_mean') in template_keys
+    if len(shape) == 4:  # conv weight, unit-gain so activations stay O(1) through the net
+        fan_in = shape[1] * shape[2] * shape[3]
+        return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+    if leaf == 'weight' and is_bn:
+        return torch.rand(shape, generator=g) + 0.5
+    if leaf == 'bias':
+        return torch.randn(shape, generator=g) * 0.1
+    if leaf == 'weight' and len(shape) == 1:  # PReLU slope
+        return torch.rand(shape, generator=g) * 0.4 + 0.05
+    raise ValueError('unclassified state-dict entry %s %s' % (key, shape))
+
+
+def synth_state_dict(template, seed):
+    """template: mapping key -> tensor or shape (only keys and shapes are used)."""
+    keys = set(template.keys())
+    out = {}
+    for k, v in template.items():
+        shape = tuple(v.shape) if hasattr(v, 'shape') else tuple(v)
+        out[k] = synth_tensor(k, shape, seed, keys)
+    return out
+
+
+def synth_input(shape, seed):
+    g = torch.Generator()
+    g.manual_seed(1000003 + seed)
+    return torch.randn(tuple(shape), generator=g)
+
+
+def synth_labels(shape, num_classes, seed):
+    g = torch.Generator()
+    g.manual_seed(2000003 + seed)
+    return torch.randint(0, num_classes, tuple(shape), generator=g)

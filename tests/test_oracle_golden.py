@@ -1,0 +1,161 @@
+"""Pin the CPU oracle (oracle/) against vectors produced by the reference's own modules.
+
+The golden files were written by tests/golden/make_golden.py, which imports /root/reference on CPU.
+These tests run anywhere (no reference, no GPU).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels as olab
+from oracle import net as onet
+from tests.cases import LAYER_CASES, MODEL_CASES, TRAIN_CASE
+from tests.conftest import GOLDEN
+from tests.synth import synth_input, synth_labels, synth_state_dict
+
+KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+
+
+LAYER_KEYS = json.load(open(os.path.join(GOLDEN, 'layer_keys.json')))
+
+
+@pytest.mark.parametrize('name', sorted(LAYER_CASES))
+def test_layer(name, golden):
+    kind, kw, shp, shp2 = LAYER_CASES[name]
+    i = sorted(LAYER_CASES).index(name)
+    sd = synth_state_dict(LAYER_KEYS[name], 100 + i)
+    sd = {'m.' + k: v for k, v in sd.items()}
+    x = synth_input(shp, 200 + i)
+    with torch.no_grad():
+        if kind == 'eesp':
+            y = onet.eesp(x, sd, 'm', kw['stride'], kw['r_lim'], k=kw['k'])
+        elif kind == 'down':
+            img = synth_input(shp2, 300 + i) if shp2 is not None else None
+            y = onet.downsampler(x, sd, 'm', kw['r_lim'], img, k=kw['k'])
+        elif kind == 'pyr':
+            y = onet.pyr_pool(x, sd, 'm', kw['last_layer_br'])
+        else:
+            y = onet.pw_conv(x, sd, 'm')
+    ref = torch.from_numpy(golden('layers')[name])
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', sorted(MODEL_CASES))
+def test_model(name, golden):
+    kind, s, classes, dataset, shp, sd_seed, in_seed = MODEL_CASES[name]
+    sd = synth_state_dict(KEYS['%s_s%s_c%d' % (kind, s, classes)], sd_seed)
+    x = synth_input(shp, in_seed)
+    g = golden('model_' + name)
+    st = int(g['stride'])
+    with torch.no_grad():
+        if kind == 'espdnetue':
+            main, aux = onet.espdnet_ue_forward(sd, x)
+            torch.testing.assert_close(main[:, :, ::st, ::st], torch.from_numpy(g['main']), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(aux[:, :, ::st, ::st], torch.from_numpy(g['aux']), rtol=1e-4, atol=1e-4)
+            prob, kld = olab.get_output(main, aux)
+            torch.testing.assert_close(kld[:, ::st, ::st], torch.from_numpy(g['kld']), rtol=1e-3, atol=1e-4)
+            amax = olab.argmax_labels(prob)
+            # two independent fp32 forwards may flip argmax where the top-2 margin is at rounding level
+            diff = amax != g['amax']
+            assert not np.any(diff & (g['margin'].astype(np.float32) > 1e-4))
+            assert diff.mean() < 1e-3
+        else:
+            main = onet.espnetv2_forward(sd, x)
+            torch.testing.assert_close(main[:, :, ::st, ::st], torch.from_numpy(g['main']), rtol=1e-4, atol=1e-4)
+
+
+def test_param_counts_match_published_tables():
+    """model/segmentation/model_zoo/README.md:51-87: 0.79 M (s=2.0) / 0.08 M (s=0.5) parameters."""
+    def count(keys):
+        return sum(int(np.prod(v)) for k, v in keys.items()
+                   if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    zoo = np.load(os.path.join(GOLDEN, 'zoo_espnetv2_s0.5_city_512x256.npz'))
+    n = sum(int(np.prod(zoo[k].shape)) for k in zoo.files
+            if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    assert round(n / 1e6, 2) == 0.08
+    assert count(KEYS['espdnetue_s2.0_c5']) == 2234230
+    assert count(KEYS['espdnetue_s2.0_c13']) == 2234502
+    assert count(KEYS['espdnetue_s2.0_c20']) == 2234740
+    assert len(KEYS['espdnetue_s2.0_c20']) == 918
+
+
+def test_zoo_real_weights(golden):
+    """BASELINE config 1 shape with the real Cityscapes checkpoint (strict key match)."""
+    zoo = np.load(os.path.join(GOLDEN, 'zoo_espnetv2_s0.5_city_512x256.npz'))
+    sd = {k: torch.from_numpy(zoo[k]) for k in zoo.files}
+    x = synth_input((2, 3, 288, 480), 40)
+    g = golden('model_v2_zoo_288x480')
+    with torch.no_grad():
+        y = onet.espnetv2_forward(sd, x)
+    torch.testing.assert_close(y[:, :, ::8, ::8], torch.from_numpy(g['main']), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(y.double().sum((0, 2, 3)).numpy(), g['class_sum'], rtol=1e-4)
+    amax = y.argmax(1).to(torch.uint8).numpy()
+    diff = amax != g['amax']
+    assert not np.any(diff & (g['margin'].astype(np.float32) > 1e-3))
+    assert diff.mean() < 1e-3
+
+
+@pytest.mark.parametrize('S', [1, 2, 3, 4])
+@pytest.mark.parametrize('pol', ['all', 'half', 'none'])
+def test_merge_truth_table(S, pol, golden):
+    g = golden('labels')
+    got = olab.merge_outputs(g['tt_in_S%d' % S], 5, None if pol == 'none' else pol)
+    np.testing.assert_array_equal(got.astype(np.uint8), g['tt_S%d_%s' % (S, pol)])
+
+
+def test_merge_random_and_luts(golden):
+    g = golden('labels')
+    np.testing.assert_array_equal(olab.merge_outputs(g['rnd_in'], 5, 'all'), g['rnd_all'])
+    np.testing.assert_array_equal(olab.merge_outputs(g['rnd_in'], 5, 'half'), g['rnd_half'])
+    np.testing.assert_array_equal(olab.ID_CAMVID_TO_GREENHOUSE, g['lut_id_camvid_to_greenhouse'])
+    np.testing.assert_array_equal(olab.ID_CITYSCAPES_TO_GREENHOUSE, g['lut_id_cityscapes_to_greenhouse'])
+    np.testing.assert_array_equal(olab.ID_FOREST_TO_GREENHOUSE, g['lut_id_forest_to_greenhouse'])
+
+
+@pytest.mark.parametrize('C', [5, 13, 20])
+def test_uncertainty_estimator(C, golden):
+    g = golden('labels')
+    d1 = synth_input((2, C, 12, 20), 50 + C) * 3
+    d2 = synth_input((2, C, 12, 20), 70 + C) * 3
+    prob, kld = olab.get_output(d1, d2)
+    torch.testing.assert_close(kld, torch.from_numpy(g['kld_C%d' % C]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(prob, torch.from_numpy(g['prob_C%d' % C]), rtol=1e-5, atol=1e-7)
+
+
+def test_uw_loss_value_and_grads(golden):
+    g = golden('loss')
+    pred = (synth_input((2, 5, 32, 48), 90) * 2).requires_grad_(True)
+    aux = (synth_input((2, 5, 32, 48), 91) * 2).requires_grad_(True)
+    tgt = synth_labels((2, 32, 48), 5, 92)
+    loss = olab.uest_train_loss(pred, aux, tgt, torch.from_numpy(g['cw']), ignore_idx=4)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), torch.from_numpy(g['loss']), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pred.grad, torch.from_numpy(g['dpred']), rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(aux.grad, torch.from_numpy(g['daux']), rtol=1e-4, atol=1e-8)
+
+
+def test_train_step(golden):
+    """One uest self-training step (frozen BN, Adam + weight decay, unused params skipped)."""
+    from oracle.train import train_step
+    c = TRAIN_CASE
+    g = golden('train_step')
+    sd = synth_state_dict(KEYS['espdnetue_s%s_c%d' % (c['s'], c['classes'])], c['sd_seed'])
+    x = synth_input(c['shape'], c['in_seed'])
+    labels = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed'])
+    names = [str(n) for n in g['names']]
+    loss, grads, new = train_step(sd, names, x, labels, torch.ones(c['classes']), c['ignore_idx'],
+                                  lr=c['lr'], weight_decay=c['weight_decay'])
+    torch.testing.assert_close(loss, torch.from_numpy(g['loss']), rtol=1e-5, atol=1e-6)
+    for n, gn, gs in zip(names, g['gnorm'], g['gsum']):
+        if gn < 0:
+            assert grads[n] is None, n
+        else:
+            assert grads[n] is not None, n
+            assert abs(float(grads[n].double().norm()) - gn) <= 2e-3 * gn + 1e-7, n
+    assert sum(1 for v in g['gnorm'] if v >= 0) == 340
+    for i, k in enumerate(str(s) for s in g['keep']):
+        torch.testing.assert_close(new[k], torch.from_numpy(g['after_%d' % i]), rtol=1e-5, atol=1e-6)
