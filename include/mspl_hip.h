@@ -1,0 +1,155 @@
+/*
+ * mspl_hip.h -- C ABI of libmspl_hip.so: hand-written HIP kernels (gfx950 / CDNA4) for the MSPL
+ * segmentation + multi-source pseudo-label hot path.
+ *
+ * The reference (ShigemichiMatsuzaki/MSPL) is pure Python on stock PyTorch: it has no FFI, so these
+ * entry points replace *ATen op sequences* inside the reference's Python modules.  Each entry cites
+ * the reference lines whose arithmetic it performs (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C types only; every tensor is a raw device pointer, dense NCHW fp32 unless stated.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *    frees or retains device memory.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *    re-entrant, capturable into a hipGraph (no host synchronisation inside).
+ *  - return value: MSPL_OK (0) or a negative mspl_status; mspl_last_error() gives the text for the
+ *    calling thread.  No C++ exception crosses the boundary.
+ *  - an output may be a channel slice of a larger tensor (free torch.cat): the epilogue carries the
+ *    destination tensor's total channel count and the channel offset of this op's first output.
+ */
+#ifndef MSPL_HIP_H
+#define MSPL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MSPL_OK = 0,
+    MSPL_ERR_BAD_SHAPE = -1,      /* non-positive / inconsistent dimensions */
+    MSPL_ERR_UNSUPPORTED = -2,    /* e.g. dilation set or class count outside the compiled variants */
+    MSPL_ERR_NULL_POINTER = -3,
+    MSPL_ERR_HIP = -4             /* launch failed; text carries hipGetErrorString */
+} mspl_status;
+
+/*
+ * Fused epilogue shared by the producer kernels.  For an accumulator value v of output channel c
+ * (absolute channel index in the destination tensor = out_coff + c), image n, pixel p:
+ *      v += pre_add[n, c, p]                                   (if pre_add)
+ *      v  = v * scale[c] + shift[c]                            (folded eval-mode BatchNorm / conv bias)
+ *      v += sum_j reinf_w[c*3+j] * reinf_r[n, j, p]            (DownSampler input reinforcement)
+ *      v += residual[n, c, p]                                  (EESP identity link)
+ *      v  = v > 0 ? v : alpha[c] * v                           (per-channel PReLU)
+ *      v *= gate[n, c]                                         (EfficientPWConv sigmoid gate)
+ * Every pointer may be NULL (step skipped).  scale/shift/alpha/reinf_w/gate are indexed by the
+ * ABSOLUTE destination channel; pre_add/residual have the destination tensor's shape.
+ */
+typedef struct {
+    const float* scale;
+    const float* shift;
+    const float* alpha;
+    const float* pre_add;
+    const float* residual;
+    const float* reinf_r;   /* (N, 3, Ho, Wo) */
+    const float* reinf_w;   /* (out_ctot, 3) */
+    const float* gate;      /* (N, out_ctot) */
+    int32_t out_ctot;       /* channels of the destination tensor */
+    int32_t out_coff;       /* first destination channel written by this call */
+} mspl_epilogue_t;
+
+const char* mspl_version(void);
+/* Copies the calling thread's last error text (NUL-terminated) into buf; returns its length. */
+size_t mspl_last_error(char* buf, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  EESP split/transform/HFF: 4 parallel dilated depthwise 3x3 convs of one (N,n,H,W) tensor,
+ *     hierarchical add out_k += out_{k-1}, channel concat, then the epilogue (br_after_cat).
+ *     Replaces nn_layers/eesp.py:68-80 (+ espnet_utils.py:118-142 CDilated, :39-60 BR).
+ *     w: (4, n, 3, 3) = spp_dw[0..3].conv.weight stacked; dil[4] in {1,2,3,4}, ascending sets
+ *     {1,2,3,4} {1,1,2,3} {1,1,1,2} are compiled; stride in {1,2}; padding = dilation.
+ *     out: (N, 4n, Ho, Wo) slice, Ho = (H-1)/stride + 1.
+ */
+int mspl_eesp_dw_hff_fwd(const float* x, const float* w, const int32_t dil[4], int32_t stride,
+                         int32_t N, int32_t n, int32_t H, int32_t W,
+                         const mspl_epilogue_t* ep, float* out, void* stream);
+
+/* K1/K3  grouped 1x1 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) + epilogue.
+ *     Replaces nn_layers/eesp.py:67 (proj_1x1), :77-93 (conv_1x1_exp + residual + module_act),
+ *     nn_layers/eesp.py:117-120,142 (inp_reinf), efficient_pyramid_pool.py:22,31 (projection / final
+ *     1x1), espnet_utils.py:8-37,62-89.   x: (N,Cin,HW)  w: (Cout, Cin/groups)  out: (N,.,HW) slice.
+ */
+int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
+                     int32_t groups, int32_t HW, const mspl_epilogue_t* ep, float* out, void* stream);
+
+/* Generic grouped 3x3 convolution, padding 1, dilation 1, stride 1 or 2 (direct, LDS-tiled) + epilogue.
+ *     Replaces model/classification/espnetv2.py:61 (level1 stem), nn_layers/eesp.py:118 (inp_reinf.0),
+ *     efficient_pyramid_pool.py:24 (depthwise stages), :30 (merge CBR), efficient_pt.py:21 (expansion).
+ *     shuffle_groups > 0 reads the input through the channel shuffle of cnn_utils.py:119-125
+ *     (logical channel j = physical channel (j % sg) * (Cin / sg) + j / sg), so Shuffle is never
+ *     materialised.  w: (Cout, Cin/groups, 3, 3).
+ */
+int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
+                     int32_t groups, int32_t H, int32_t W, int32_t stride, int32_t shuffle_groups,
+                     const mspl_epilogue_t* ep, float* out, void* stream);
+
+/* AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) + epilogue.
+ *     Replaces nn_layers/eesp.py:115,128 and the image pyramid of :136-140.
+ */
+int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                          const mspl_epilogue_t* ep, float* out, void* stream);
+
+/* Bilinear resize, align_corners=True (ATen index rule) + epilogue.
+ *     Replaces F.interpolate at efficient_pyramid_pool.py:48,50 and espdnet_ue.py:110,301-302.
+ */
+int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                      int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream);
+
+/* adaptive_avg_pool2d (window [floor(i*I/O), ceil((i+1)*I/O)) ) + epilogue.
+ *     Replaces efficient_pyramid_pool.py:46,52.
+ */
+int mspl_adaptive_avgpool_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                              int32_t Ho, int32_t Wo, const mspl_epilogue_t* ep, float* out,
+                              void* stream);
+
+/* Elementwise epilogue only (BatchNorm+PReLU "BR" blocks, espdnet_ue.py:89-97, cnn_utils.py:85-105).
+ * x has the destination tensor's shape (N, out_ctot, HW); channels [out_coff, out_coff+C) are processed. */
+int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t HW, const mspl_epilogue_t* ep,
+                       float* out, void* stream);
+
+/* EfficientPWConv gate: sigmoid(W . global_avg_pool(x)).  Replaces efficient_pt.py:13-17,26.
+ *     x: (N,Cin,HW)  w: (Cout,Cin)  mean_ws: (N,Cin) workspace  gate: (N,Cout).
+ */
+int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
+                      int32_t HW, float* mean_ws, float* gate, void* stream);
+
+/* K8+K9  label epilogue: bilinear(align_corners) upsample of both heads to (H,W), o = main + 0.5*aux,
+ *     class = first-max argmax_c o (== np.argmax of softmax2d(o) up to exp() rounding ties), optional
+ *     id LUT, optional softmax probabilities and KL(main||aux) map.
+ *     Replaces espdnet_ue.py:301-302 + uest_seg_multi_os.py:685-691 (get_output), :903-912 (argmax+LUT),
+ *     loss_fns/segmentation_loss.py:181-189 (PixelwiseKLD).
+ *     main: (N,C,Hm,Wm)  aux: (N,C,Ha,Wa) or NULL (single-head nets: o = main, kld = 0)
+ *     lut: C bytes or NULL;  labels: (N,H,W) uint8;  prob: (N,C,H,W) or NULL;  kld: (N,H,W) or NULL;
+ *     main_up/aux_up: (N,C,H,W) or NULL -- the upsampled logits themselves (what model(x) returns).
+ *     C <= 255 (labels are uint8).
+ */
+int mspl_label_epilogue_fwd(const float* main, const float* aux, int32_t N, int32_t C,
+                            int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                            const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
+                            float* main_up, float* aux_up, void* stream);
+
+/* K10  cross-source label merge + class histogram.  Replaces uest_seg_multi_os.py:695-718
+ *     (merge_outputs) and :919-921.  src[s]: npix uint8 class maps (already in target ids),
+ *     S <= 8, num_classes <= 16.  out[p] = first-max argmax_c count_c(p), or `fill` when the
+ *     winning count < thresh.  hist (num_classes x uint64, device) is ACCUMULATED into (caller zeroes).
+ */
+int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64_t npix, int32_t num_classes,
+                          int32_t thresh, int32_t fill, uint8_t* out, unsigned long long* hist,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSPL_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libmspl_hip.so (the C ABI declared in include/mspl_hip.h).
+
+There is no CPU or eager-PyTorch fallback: if the library is missing the import fails loudly, and
+every entry point raises RuntimeError with the library's own error text on a non-zero status --
+mirroring the reference's failure mode (a RuntimeError from ATen on a shape mismatch).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmspl_hip.so')
+
+c_f32p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+
+
+class Epilogue(ctypes.Structure):
+    """mspl_epilogue_t."""
+    _fields_ = [('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('alpha', ctypes.c_void_p),
+                ('pre_add', ctypes.c_void_p), ('residual', ctypes.c_void_p), ('reinf_r', ctypes.c_void_p),
+                ('reinf_w', ctypes.c_void_p), ('gate', ctypes.c_void_p),
+                ('out_ctot', c_i32), ('out_coff', c_i32)]
+
+
+_EP = ctypes.POINTER(Epilogue)
+
+# name -> argument types (all return int status); the single source for the symbol-export test
+SIGNATURES = {
+    'mspl_eesp_dw_hff_fwd': [c_f32p, c_f32p, ctypes.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_i32, _EP,
+                             c_f32p, ctypes.c_void_p],
+    'mspl_conv1x1_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_conv3x3_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
+                         ctypes.c_void_p],
+    'mspl_avgpool3x3s2_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_bilinear_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_adaptive_avgpool_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_pointwise_fwd': [c_f32p, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_gap_gate_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_label_epilogue_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
+                              ctypes.c_void_p, ctypes.c_void_p],
+}
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            'mspl_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C mspl_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.mspl_version.restype = ctypes.c_char_p
+    lib.mspl_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.mspl_last_error.restype = ctypes.c_size_t
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib.mspl_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError('mspl_hip (%d): %s' % (status, last_error()))
+
+
+def version():
+    return lib.mspl_version().decode()

@@ -1,0 +1,139 @@
+// Shared device/host helpers for libmspl_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mspl_hip.h"
+
+namespace mspl {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ host-side error plumbing
+void set_error(const char* fmt, ...);
+
+#define MSPL_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::mspl::set_error(__VA_ARGS__);      \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define MSPL_CHECK_LAUNCH(name)                                                      \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            ::mspl::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MSPL_ERR_HIP;                                                     \
+        }                                                                            \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ device epilogue
+// Device copy of mspl_epilogue_t with the destination geometry resolved.
+struct Epi {
+    const float* scale;
+    const float* shift;
+    const float* alpha;
+    const float* pre_add;
+    const float* residual;
+    const float* reinf_r;
+    const float* reinf_w;
+    const float* gate;
+    int ctot;   // destination tensor channels
+    int coff;   // first destination channel of this op
+    int hw;     // destination pixels per plane
+};
+
+static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
+    Epi e;
+    memset(&e, 0, sizeof(e));
+    e.ctot = C_default;
+    e.coff = 0;
+    e.hw = hw;
+    if (ep) {
+        e.scale = ep->scale; e.shift = ep->shift; e.alpha = ep->alpha;
+        e.pre_add = ep->pre_add; e.residual = ep->residual;
+        e.reinf_r = ep->reinf_r; e.reinf_w = ep->reinf_w; e.gate = ep->gate;
+        if (ep->out_ctot > 0) { e.ctot = ep->out_ctot; e.coff = ep->out_coff; }
+    }
+    return e;
+}
+
+static inline int check_epi(const mspl_epilogue_t* ep, int C, const char* who) {
+    if (!ep) return MSPL_OK;
+    if (ep->out_ctot > 0) {
+        MSPL_REQUIRE(ep->out_coff >= 0 && ep->out_coff + C <= ep->out_ctot, MSPL_ERR_BAD_SHAPE,
+                     "%s: channel slice [%d,%d) outside destination with %d channels", who,
+                     ep->out_coff, ep->out_coff + C, ep->out_ctot);
+    } else {
+        MSPL_REQUIRE(ep->out_coff == 0, MSPL_ERR_BAD_SHAPE, "%s: out_coff without out_ctot", who);
+    }
+    MSPL_REQUIRE((ep->reinf_r == nullptr) == (ep->reinf_w == nullptr), MSPL_ERR_NULL_POINTER,
+                 "%s: reinf_r and reinf_w must be given together", who);
+    return MSPL_OK;
+}
+
+// Per-channel constants of the epilogue, fetched once per (thread, channel).
+struct EpiCh {
+    float scale, shift, alpha, rw0, rw1, rw2;
+};
+
+__device__ __forceinline__ EpiCh epi_channel(const Epi& e, int cabs) {
+    EpiCh c;
+    c.scale = e.scale ? e.scale[cabs] : 1.0f;
+    c.shift = e.shift ? e.shift[cabs] : 0.0f;
+    c.alpha = e.alpha ? e.alpha[cabs] : 1.0f;
+    if (e.reinf_w) {
+        c.rw0 = e.reinf_w[cabs * 3 + 0];
+        c.rw1 = e.reinf_w[cabs * 3 + 1];
+        c.rw2 = e.reinf_w[cabs * 3 + 2];
+    } else {
+        c.rw0 = c.rw1 = c.rw2 = 0.0f;
+    }
+    return c;
+}
+
+// v: accumulator; n: image; cabs: absolute destination channel; p: pixel in plane.
+__device__ __forceinline__ float epi_apply(const Epi& e, const EpiCh& c, float v, int n, int cabs, int p) {
+    const size_t off = ((size_t)n * e.ctot + cabs) * (size_t)e.hw + p;
+    if (e.pre_add) v += e.pre_add[off];
+    v = fmaf(v, c.scale, c.shift);
+    if (e.reinf_r) {
+        const float* r = e.reinf_r + (size_t)n * 3 * e.hw + p;
+        v += c.rw0 * r[0] + c.rw1 * r[e.hw] + c.rw2 * r[2 * (size_t)e.hw];
+    }
+    if (e.residual) v += e.residual[off];
+    if (e.alpha) v = v > 0.0f ? v : c.alpha * v;
+    if (e.gate) v *= e.gate[(size_t)n * e.ctot + cabs];
+    return v;
+}
+
+__device__ __forceinline__ size_t epi_offset(const Epi& e, int n, int cabs, int p) {
+    return ((size_t)n * e.ctot + cabs) * (size_t)e.hw + p;
+}
+
+// ATen bilinear source index / weight, align_corners=True (UpSampleKernel: area_pixel_compute_source_index
+// + guard_index_and_lambda).  scale = (in-1)/(out-1) in fp32, 0 when out == 1.
+__device__ __forceinline__ void bilinear_src(float scale, int dst, int in_size, int& i0, int& i1, float& w0, float& w1) {
+    float real = scale * (float)dst;
+    int idx = (int)floorf(real);
+    if (idx > in_size - 1) idx = in_size - 1;
+    float lam = real - (float)idx;
+    lam = fminf(fmaxf(lam, 0.0f), 1.0f);
+    i0 = idx;
+    i1 = idx + ((idx < in_size - 1) ? 1 : 0);
+    w1 = lam;
+    w0 = 1.0f - lam;
+}
+
+static inline float bilinear_scale(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+}
+
+}  // namespace mspl

@@ -1,0 +1,188 @@
+// Generic grouped 3x3 convolution (padding 1, dilation 1, stride 1|2), direct and LDS-tiled, with the
+// shared fused epilogue.  Covers the small-K spatial convolutions of the path:
+//   level1 stem 3->32 s2            model/classification/espnetv2.py:61
+//   inp_reinf.0 3->3                nn_layers/eesp.py:118
+//   pyramid depthwise stages        nn_layers/efficient_pyramid_pool.py:24
+//   merge CBR (groups = proj)       nn_layers/efficient_pyramid_pool.py:30  (reads through Shuffle, :29)
+//   EfficientPWConv expansion       nn_layers/efficient_pt.py:21
+// A workgroup stages the cin_g input planes of one (image, group, spatial tile) in LDS (coalesced rows,
+// zero-filled halo); a thread produces a 1x4 output strip for COB output channels, so every LDS row
+// window is reused COB*3 times from registers.  Weight reads are LDS broadcasts.
+#include "common.hpp"
+
+namespace mspl {
+
+struct C3Geom {
+    int N, Cin, Cout, G, cin_g, cout_g, H, W, Ho, Wo, sg;
+    int TH, TW;        // output tile
+    int tiles_y, tiles_x;
+    int IH, IWS;       // staged input rows / LDS row stride (floats, multiple of 4)
+    int XS;            // TW / 4 strips per tile row
+    int coblks;        // cout_g / COB
+};
+
+template <int STRIDE, int COB>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      C3Geom g, Epi e, float* __restrict__ out) {
+    constexpr int NR = (STRIDE == 1) ? 6 : 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                         // cin_g * IH * IWS
+    float* wl = smem + (size_t)g.cin_g * g.IH * g.IWS;          // cout_g * cin_g * 9
+
+    int bid = blockIdx.x;
+    const int txi = bid % g.tiles_x;  bid /= g.tiles_x;
+    const int tyi = bid % g.tiles_y;  bid /= g.tiles_y;
+    const int grp = bid % g.G;
+    const int img = bid / g.G;
+    const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
+    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;   // input coords of LDS (0,0)
+    const int tid = threadIdx.x;
+
+    const int nw = g.cout_g * g.cin_g * 9;
+    const float* wg = w + (size_t)grp * nw;
+    for (int i = tid; i < nw; i += 256) wl[i] = wg[i];
+
+    // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j)
+    const int per_plane = g.IH * g.IWS;
+    for (int i = tid; i < g.cin_g * per_plane; i += 256) {
+        const int ci = i / per_plane, rem = i - ci * per_plane;
+        const int r = rem / g.IWS, j = rem - r * g.IWS;
+        const int iy = iy0 + r, ix = ix0 + j;
+        float v = 0.f;
+        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+            int lc = grp * g.cin_g + ci;
+            if (g.sg > 0) lc = (lc % g.sg) * (g.Cin / g.sg) + lc / g.sg;
+            v = x[(((size_t)img * g.Cin + lc) * g.H + iy) * (size_t)g.W + ix];
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int rows_here = min(g.TH, g.Ho - oy0);
+    const int items = g.coblks * rows_here * g.XS;
+    const int hw = g.Ho * g.Wo;
+    for (int it = tid; it < items; it += 256) {
+        const int xs = it % g.XS;
+        const int t2 = it / g.XS;
+        const int ty = t2 % rows_here;
+        const int cb = t2 / rows_here;
+        const int xb = ox0 + xs * 4;
+        if (xb >= g.Wo) continue;
+        float acc[COB][4];
+#pragma unroll
+        for (int c = 0; c < COB; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+        for (int ci = 0; ci < g.cin_g; ++ci) {
+            const float* lp = tile + (size_t)ci * per_plane + (size_t)(ty * STRIDE) * g.IWS + xs * 4 * STRIDE;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float rv[NR + 3];
+                const float* row = lp + ky * g.IWS;
+                const float4 a = *reinterpret_cast<const float4*>(row);
+                const float4 b = *reinterpret_cast<const float4*>(row + 4);
+                rv[0] = a.x; rv[1] = a.y; rv[2] = a.z; rv[3] = a.w;
+                rv[4] = b.x; rv[5] = b.y; rv[6] = b.z; rv[7] = b.w;
+                if (STRIDE == 2) rv[8] = row[8];
+#pragma unroll
+                for (int c = 0; c < COB; ++c) {
+                    const float* wp = wl + ((size_t)(cb * COB + c) * g.cin_g + ci) * 9 + ky * 3;
+                    const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[c][j] = fmaf(w0, rv[j * STRIDE], acc[c][j]);
+                        acc[c][j] = fmaf(w1, rv[j * STRIDE + 1], acc[c][j]);
+                        acc[c][j] = fmaf(w2, rv[j * STRIDE + 2], acc[c][j]);
+                    }
+                }
+            }
+        }
+        const int y = oy0 + ty;
+        const int pix = y * g.Wo + xb;
+#pragma unroll
+        for (int c = 0; c < COB; ++c) {
+            const int cabs = e.coff + grp * g.cout_g + cb * COB + c;
+            const EpiCh ec = epi_channel(e, cabs);
+            float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
+            if (((g.Wo & 3) == 0)) {
+                float4 v;
+                v.x = epi_apply(e, ec, acc[c][0], img, cabs, pix);
+                v.y = epi_apply(e, ec, acc[c][1], img, cabs, pix + 1);
+                v.z = epi_apply(e, ec, acc[c][2], img, cabs, pix + 2);
+                v.w = epi_apply(e, ec, acc[c][3], img, cabs, pix + 3);
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (xb + j < g.Wo) dst[j] = epi_apply(e, ec, acc[c][j], img, cabs, pix + j);
+            }
+        }
+    }
+}
+
+template <int STRIDE>
+static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float* out, hipStream_t s) {
+    int cob = 1;
+    if (g.cout_g % 8 == 0) cob = 8;
+    else if (g.cout_g % 4 == 0) cob = 4;
+    else if (g.cout_g % 3 == 0) cob = 3;
+    else if (g.cout_g % 2 == 0) cob = 2;
+    g.coblks = g.cout_g / cob;
+    const int wo4 = (g.Wo + 3) & ~3;
+    g.TW = wo4 <= 128 ? wo4 : 64;
+    g.XS = g.TW / 4;
+    g.tiles_x = ceil_div(g.Wo, g.TW);
+    g.IWS = (((g.TW - 1) * STRIDE + 3 + 3) & ~3) + 4;
+    auto lds_of = [&](int th) {
+        return ((size_t)g.cin_g * ((th - 1) * STRIDE + 3) * g.IWS + (size_t)g.cout_g * g.cin_g * 9) * sizeof(float);
+    };
+    int th = g.Ho < 16 ? g.Ho : 16;
+    while (th > 1 && lds_of(th) > 40 * 1024) th = (th + 1) / 2;
+    // keep 256 threads busy: shrink the tile only while it still holds >= 256 strips
+    while (th > 2 && (int64_t)g.coblks * (th / 2) * g.XS >= 512) th = th / 2;
+    MSPL_REQUIRE(lds_of(th) <= 64 * 1024, MSPL_ERR_UNSUPPORTED,
+                 "conv3x3: tile (cin_g=%d, cout_g=%d) does not fit LDS", g.cin_g, g.cout_g);
+    g.TH = th;
+    g.IH = (th - 1) * STRIDE + 3;
+    g.tiles_y = ceil_div(g.Ho, th);
+    const int64_t blocks = (int64_t)g.N * g.G * g.tiles_y * g.tiles_x;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv3x3: grid too large");
+    dim3 grid((unsigned)blocks), blk(256);
+    const size_t lds = lds_of(th);
+    switch (cob) {
+        case 8: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 8>), grid, blk, lds, s, x, w, g, e, out); break;
+        case 4: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 4>), grid, blk, lds, s, x, w, g, e, out); break;
+        case 3: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 3>), grid, blk, lds, s, x, w, g, e, out); break;
+        case 2: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 2>), grid, blk, lds, s, x, w, g, e, out); break;
+        default: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 1>), grid, blk, lds, s, x, w, g, e, out); break;
+    }
+    MSPL_CHECK_LAUNCH("conv3x3");
+    return MSPL_OK;
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
+                                int32_t groups, int32_t H, int32_t W, int32_t stride, int32_t shuffle_groups,
+                                const mspl_epilogue_t* ep, float* out, void* stream) {
+    MSPL_REQUIRE(x && w && out, MSPL_ERR_NULL_POINTER, "conv3x3: null pointer");
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && groups > 0 && H > 0 && W > 0, MSPL_ERR_BAD_SHAPE,
+                 "conv3x3: bad shape N=%d Cin=%d Cout=%d groups=%d H=%d W=%d", N, Cin, Cout, groups, H, W);
+    MSPL_REQUIRE(Cin % groups == 0 && Cout % groups == 0, MSPL_ERR_BAD_SHAPE,
+                 "conv3x3: channels (%d,%d) not divisible by groups %d", Cin, Cout, groups);
+    MSPL_REQUIRE(stride == 1 || stride == 2, MSPL_ERR_UNSUPPORTED, "conv3x3: stride %d (1 or 2)", stride);
+    MSPL_REQUIRE(shuffle_groups >= 0 && (shuffle_groups == 0 || Cin % shuffle_groups == 0), MSPL_ERR_BAD_SHAPE,
+                 "conv3x3: shuffle groups %d do not divide Cin=%d", shuffle_groups, Cin);
+    if (int rc = check_epi(ep, Cout, "conv3x3")) return rc;
+    C3Geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.cin_g = Cin / groups; g.cout_g = Cout / groups;
+    g.H = H; g.W = W; g.sg = shuffle_groups;
+    g.Ho = (H - 1) / stride + 1;
+    g.Wo = (W - 1) / stride + 1;
+    const Epi e = make_epi(ep, Cout, g.Ho * g.Wo);
+    hipStream_t s = (hipStream_t)stream;
+    return stride == 1 ? launch3<1>(x, w, g, e, out, s) : launch3<2>(x, w, g, e, out, s);
+}

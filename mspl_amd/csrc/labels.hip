@@ -1,0 +1,248 @@
+// K8/K9 label epilogue and K10 cross-source label merge -- the integer end of the pseudo-label pass.
+//
+// label_epilogue: model/segmentation/espdnet_ue.py:301-302 (final bilinear, align_corners=True) fused
+//   with uest_seg_multi_os.py:685-691 (get_output: pred + 0.5*aux -> Softmax2d; PixelwiseKLD,
+//   loss_fns/segmentation_loss.py:181-189) and :903-912 (np.argmax over classes, first max wins; id LUT).
+//   Full-resolution logits are never written unless the caller asks for them.
+// merge_labels: uest_seg_multi_os.py:695-718 (merge_outputs) + :919-921 (class histogram).  Pure integer,
+//   S bytes in + 1 byte out per pixel; bit-exact contract.
+#include "common.hpp"
+
+namespace mspl {
+
+struct LeGeom {
+    int N, C, Hm, Wm, Ha, Wa, H, W;
+    float shm, swm, sha, swa;
+};
+
+// One thread per output pixel, ONE pass over the classes with running (online) maxima, so nothing but a
+// handful of scalars lives in registers whatever C is:
+//   argmax_c o_c                      (strict '>' keeps the first maximum, like np.argmax)
+//   lse(main), lse(aux)               (running max + rescaled sum)
+//   E_p1[main - aux]                  (rescaled with lse(main)'s running max)
+//   KL(main || aux) = E_p1[main - aux] - lse(main) + lse(aux)
+// Softmax probabilities, when requested, take a second pass (get_output's drop-in form only).
+__global__ __launch_bounds__(256) void label_epilogue_kernel(const float* __restrict__ mainp,
+                                                             const float* __restrict__ auxp, LeGeom g,
+                                                             const uint8_t* __restrict__ lut,
+                                                             uint8_t* __restrict__ labels, float* __restrict__ prob,
+                                                             float* __restrict__ kld, float* __restrict__ main_up,
+                                                             float* __restrict__ aux_up, int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % g.W);  idx /= g.W;
+    const int y = (int)(idx % g.H);
+    const int n = (int)(idx / g.H);
+    const size_t hw = (size_t)g.H * g.W;
+    const size_t pix = (size_t)y * g.W + x;
+
+    int my0, my1, mx0, mx1;  float mwy0, mwy1, mwx0, mwx1;
+    bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);
+    bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
+    const size_t mplane = (size_t)g.Hm * g.Wm;
+    const float* mb = mainp + (size_t)n * g.C * mplane;
+    const int m00 = my0 * g.Wm + mx0, m01 = my0 * g.Wm + mx1, m10 = my1 * g.Wm + mx0, m11 = my1 * g.Wm + mx1;
+
+    int a00 = 0, a01 = 0, a10 = 0, a11 = 0;  float awy0 = 0.f, awy1 = 0.f, awx0 = 0.f, awx1 = 0.f;
+    size_t aplane = 0;
+    const float* ab = nullptr;
+    if (auxp) {
+        int ay0, ay1, ax0, ax1;
+        bilinear_src(g.sha, y, g.Ha, ay0, ay1, awy0, awy1);
+        bilinear_src(g.swa, x, g.Wa, ax0, ax1, awx0, awx1);
+        aplane = (size_t)g.Ha * g.Wa;
+        ab = auxp + (size_t)n * g.C * aplane;
+        a00 = ay0 * g.Wa + ax0; a01 = ay0 * g.Wa + ax1; a10 = ay1 * g.Wa + ax0; a11 = ay1 * g.Wa + ax1;
+    }
+    auto interp_main = [&](int c) {
+        const float* p = mb + c * mplane;
+        const float top = mwx0 * p[m00] + mwx1 * p[m01];
+        const float bot = mwx0 * p[m10] + mwx1 * p[m11];
+        return mwy0 * top + mwy1 * bot;
+    };
+    auto interp_aux = [&](int c) {
+        const float* q = ab + c * aplane;
+        const float top = awx0 * q[a00] + awx1 * q[a01];
+        const float bot = awx0 * q[a10] + awx1 * q[a11];
+        return awy0 * top + awy1 * bot;
+    };
+
+    float omax = -INFINITY;  int best = 0;
+    float M1 = -INFINITY, S1 = 0.f, T1 = 0.f;   // lse(main) state and sum exp(m - M1) * (m - a)
+    float M2 = -INFINITY, S2 = 0.f;             // lse(aux) state
+#pragma unroll 2
+    for (int c = 0; c < g.C; ++c) {
+        const float m = interp_main(c);
+        const float a = ab ? interp_aux(c) : 0.f;
+        const float o = m + 0.5f * a;
+        if (o > omax) { omax = o; best = c; }
+        if (main_up) main_up[((size_t)n * g.C + c) * hw + pix] = m;
+        if (aux_up && ab) aux_up[((size_t)n * g.C + c) * hw + pix] = a;
+        if (kld && ab) {
+            if (m > M1) { const float f = expf(M1 - m); S1 *= f; T1 *= f; M1 = m; }
+            const float e1 = expf(m - M1);
+            S1 += e1;
+            T1 = fmaf(e1, m - a, T1);
+            if (a > M2) { S2 *= expf(M2 - a); M2 = a; }
+            S2 += expf(a - M2);
+        }
+    }
+    if (labels) labels[(size_t)n * hw + pix] = lut ? lut[best] : (uint8_t)best;
+    if (kld) kld[(size_t)n * hw + pix] = ab ? (T1 / S1 - (M1 + logf(S1)) + (M2 + logf(S2))) : 0.f;
+    if (prob) {
+        float s = 0.f;
+        for (int c = 0; c < g.C; ++c) s += expf(interp_main(c) + 0.5f * (ab ? interp_aux(c) : 0.f) - omax);
+        const float inv = 1.0f / s;
+        for (int c = 0; c < g.C; ++c)
+            prob[((size_t)n * g.C + c) * hw + pix] = expf(interp_main(c) + 0.5f * (ab ? interp_aux(c) : 0.f) - omax) * inv;
+    }
+}
+
+struct MergeSrc {
+    const uint8_t* p[8];
+};
+
+template <int NCLS>
+__device__ __forceinline__ uint32_t merge_one(const uint32_t (&lab)[8], int S, int ncls, int thresh, int fill) {
+    int best = 0, bestc = -1;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        if (c < ncls) {
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < S) cnt += (lab[s] == (uint32_t)c);
+            if (cnt > bestc) { bestc = cnt; best = c; }     // first max (np.argmax)
+        }
+    }
+    return bestc < thresh ? (uint32_t)fill : (uint32_t)best;
+}
+
+// 16 pixels per thread (one 16-byte load per source), per-thread histogram in registers, wave + LDS
+// reduction, one 64-bit atomic per class per workgroup.
+__global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int S, int64_t npix, int ncls, int thresh,
+                                                           int fill, uint8_t* __restrict__ out,
+                                                           unsigned long long* __restrict__ hist, int vec_ok) {
+    constexpr int NCLS = 16;
+    uint32_t h[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) h[c] = 0;
+    const int64_t nchunks = (npix + 15) >> 4;
+    for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * 256) {
+        const int64_t p0 = ch << 4;
+        const int cnt = (int)((npix - p0) < 16 ? (npix - p0) : 16);
+        uint32_t words[8][4];
+        if (vec_ok && cnt == 16) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < S) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(src.p[s] + p0);
+                    words[s][0] = v.x; words[s][1] = v.y; words[s][2] = v.z; words[s][3] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < S) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t wv = 0;
+                        for (int b = 0; b < 4; ++b) {
+                            const int i = q * 4 + b;
+                            if (i < cnt) wv |= (uint32_t)src.p[s][p0 + i] << (8 * b);
+                        }
+                        words[s][q] = wv;
+                    }
+                }
+        }
+        uint32_t res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                uint32_t lab[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) lab[s] = (s < S) ? ((words[s][q] >> (8 * b)) & 0xFFu) : 0xFFFFu;
+                const uint32_t m = merge_one<NCLS>(lab, S, ncls, thresh, fill);
+                r |= m << (8 * b);
+                if (q * 4 + b < cnt) {
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) h[c] += (m == (uint32_t)c);
+                }
+            }
+            res[q] = r;
+        }
+        if (vec_ok && cnt == 16) {
+            *reinterpret_cast<uint4*>(out + p0) = make_uint4(res[0], res[1], res[2], res[3]);
+        } else {
+            for (int i = 0; i < cnt; ++i) out[p0 + i] = (uint8_t)(res[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+    if (hist) {
+        __shared__ uint32_t sh[NCLS];
+        if (threadIdx.x < NCLS) sh[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            uint32_t v = h[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[c], v);
+        }
+        __syncthreads();
+        if (threadIdx.x < ncls && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+    }
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
+                                       int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                                       const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
+                                       float* main_up, float* aux_up, void* stream) {
+    MSPL_REQUIRE(mainp, MSPL_ERR_NULL_POINTER, "label_epilogue: null main logits");
+    MSPL_REQUIRE(labels || prob || kld || main_up || aux_up, MSPL_ERR_NULL_POINTER, "label_epilogue: no output requested");
+    MSPL_REQUIRE(N > 0 && C > 0 && Hm > 0 && Wm > 0 && H > 0 && W > 0 && (!aux || (Ha > 0 && Wa > 0)),
+                 MSPL_ERR_BAD_SHAPE, "label_epilogue: bad shape N=%d C=%d main=%dx%d aux=%dx%d out=%dx%d",
+                 N, C, Hm, Wm, Ha, Wa, H, W);
+    MSPL_REQUIRE(C <= 255, MSPL_ERR_UNSUPPORTED, "label_epilogue: %d classes do not fit a uint8 label", C);
+    LeGeom g;
+    g.N = N; g.C = C; g.Hm = Hm; g.Wm = Wm; g.Ha = Ha; g.Wa = Wa; g.H = H; g.W = W;
+    g.shm = bilinear_scale(Hm, H); g.swm = bilinear_scale(Wm, W);
+    g.sha = aux ? bilinear_scale(Ha, H) : 0.f; g.swa = aux ? bilinear_scale(Wa, W) : 0.f;
+    const int64_t total = (int64_t)N * H * W;
+    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "label_epilogue: grid too large");
+    hipLaunchKernelGGL(label_epilogue_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       mainp, aux, g, lut, labels, prob, kld, main_up, aux_up, total);
+    MSPL_CHECK_LAUNCH("label_epilogue");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64_t npix, int32_t num_classes,
+                                     int32_t thresh, int32_t fill, uint8_t* out, unsigned long long* hist,
+                                     void* stream) {
+    MSPL_REQUIRE(src && out, MSPL_ERR_NULL_POINTER, "merge_labels: null pointer");
+    MSPL_REQUIRE(S >= 1 && S <= 8, MSPL_ERR_UNSUPPORTED, "merge_labels: %d sources (1..8)", S);
+    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 16, MSPL_ERR_UNSUPPORTED, "merge_labels: %d classes (1..16)", num_classes);
+    MSPL_REQUIRE(fill >= 0 && fill <= 255, MSPL_ERR_BAD_SHAPE, "merge_labels: fill %d", fill);
+    MSPL_REQUIRE(npix >= 0, MSPL_ERR_BAD_SHAPE, "merge_labels: negative pixel count");
+    if (npix == 0) return MSPL_OK;   // empty input: nothing to write, histogram untouched
+    MergeSrc ms;
+    int vec_ok = (((uintptr_t)out) & 15) == 0;
+    for (int s = 0; s < 8; ++s) {
+        ms.p[s] = s < S ? src[s] : nullptr;
+        if (s < S) {
+            MSPL_REQUIRE(src[s], MSPL_ERR_NULL_POINTER, "merge_labels: source %d is null", s);
+            vec_ok = vec_ok && ((((uintptr_t)src[s]) & 15) == 0);
+        }
+    }
+    const int64_t nchunks = (npix + 15) >> 4;
+    int64_t blocks = ceil_div64(nchunks, 256);
+    if (blocks > 2048) blocks = 2048;   // grid-stride; 256 CUs x 8
+    hipLaunchKernelGGL(merge_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ms, S, npix,
+                       num_classes, thresh, fill, out, hist, vec_ok);
+    MSPL_CHECK_LAUNCH("merge_labels");
+    return MSPL_OK;
+}

@@ -1,0 +1,260 @@
+// Pooling / resampling / pointwise kernels of the decoder and the DownSampler, all with the shared epilogue.
+//   avgpool3x3s2      nn_layers/eesp.py:115,128,136-140  (AvgPool2d(3, stride 2, pad 1), count_include_pad)
+//   bilinear          F.interpolate(mode='bilinear', align_corners=True): efficient_pyramid_pool.py:48,50;
+//                     model/segmentation/espdnet_ue.py:110,301-302
+//   adaptive_avgpool  F.adaptive_avg_pool2d: efficient_pyramid_pool.py:46,52
+//   pointwise         BatchNorm+PReLU blocks: espdnet_ue.py:89-97, cnn_utils.py:85-105
+//   gap_gate          EfficientPWConv.wt_layer: efficient_pt.py:13-17
+// All are streaming kernels: one thread per 4 consecutive output pixels of a row (16-byte stores when the
+// row length allows), source reads served by L1/L2 (every source line is touched by neighbouring lanes).
+#include "common.hpp"
+
+namespace mspl {
+
+struct RsGeom {
+    int N, C, Hi, Wi, Ho, Wo;
+    int XS;           // ceil(Wo / 4)
+    float sh, sw;     // bilinear scales
+};
+
+// Decode a flat strip index into (n, c, y, x0).
+__device__ __forceinline__ void strip_decode(int64_t idx, const RsGeom& g, int& n, int& c, int& y, int& x0) {
+    const int xs = (int)(idx % g.XS);  idx /= g.XS;
+    y = (int)(idx % g.Ho);  idx /= g.Ho;
+    c = (int)(idx % g.C);
+    n = (int)(idx / g.C);
+    x0 = xs * 4;
+}
+
+__device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n, int c, int y, int x0,
+                                            const float (&acc)[4], float* out) {
+    const int cabs = e.coff + c;
+    const EpiCh ec = epi_channel(e, cabs);
+    const int pix = y * g.Wo + x0;
+    float* dst = out + epi_offset(e, n, cabs, pix);
+    if ((g.Wo & 3) == 0) {
+        float4 v;
+        v.x = epi_apply(e, ec, acc[0], n, cabs, pix);
+        v.y = epi_apply(e, ec, acc[1], n, cabs, pix + 1);
+        v.z = epi_apply(e, ec, acc[2], n, cabs, pix + 2);
+        v.w = epi_apply(e, ec, acc[3], n, cabs, pix + 3);
+        *reinterpret_cast<float4*>(dst) = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + j < g.Wo) dst[j] = epi_apply(e, ec, acc[j], n, cabs, pix + j);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restrict__ x, RsGeom g, Epi e,
+                                                           float* __restrict__ out, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int n, c, y, x0;
+    strip_decode(idx, g, n, c, y, x0);
+    const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * y - 1 + ky;
+        if (iy < 0 || iy >= g.Hi) continue;
+        const float* row = src + (size_t)iy * g.Wi;
+        float rv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int ix = 2 * x0 - 1 + i;
+            rv[i] = (ix >= 0 && ix < g.Wi) ? row[ix] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += rv[2 * j] + rv[2 * j + 1] + rv[2 * j + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= (1.0f / 9.0f);   // count_include_pad=True: divisor is always 9
+    strip_store(e, g, n, c, y, x0, acc, out);
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, RsGeom g, Epi e,
+                                                       float* __restrict__ out, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int n, c, y, x0;
+    strip_decode(idx, g, n, c, y, x0);
+    const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
+    int y0i, y1i;  float wy0, wy1;
+    bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
+    const float* r0 = src + (size_t)y0i * g.Wi;
+    const float* r1 = src + (size_t)y1i * g.Wi;
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = min(x0 + j, g.Wo - 1);
+        int xa, xb;  float wx0, wx1;
+        bilinear_src(g.sw, xx, g.Wi, xa, xb, wx0, wx1);
+        const float top = wx0 * r0[xa] + wx1 * r0[xb];
+        const float bot = wx0 * r1[xa] + wx1 * r1[xb];
+        acc[j] = wy0 * top + wy1 * bot;
+    }
+    strip_store(e, g, n, c, y, x0, acc, out);
+}
+
+__device__ __forceinline__ int ada_start(int o, int I, int O) { return (int)(((int64_t)o * I) / O); }
+__device__ __forceinline__ int ada_end(int o, int I, int O) { return (int)((((int64_t)(o + 1)) * I + O - 1) / O); }
+
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ x, RsGeom g, Epi e,
+                                                               float* __restrict__ out, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int n, c, y, x0;
+    strip_decode(idx, g, n, c, y, x0);
+    const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
+    const int ys = ada_start(y, g.Hi, g.Ho), ye = ada_end(y, g.Hi, g.Ho);
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = min(x0 + j, g.Wo - 1);
+        const int xs = ada_start(xx, g.Wi, g.Wo), xe = ada_end(xx, g.Wi, g.Wo);
+        float s = 0.f;
+        for (int iy = ys; iy < ye; ++iy) {
+            const float* row = src + (size_t)iy * g.Wi;
+            for (int ix = xs; ix < xe; ++ix) s += row[ix];
+        }
+        acc[j] = s / (float)((ye - ys) * (xe - xs));
+    }
+    strip_store(e, g, n, c, y, x0, acc, out);
+}
+
+// x and out share the destination geometry (N, ctot, HW); 4 pixels per thread.
+__global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ x, int N, int C, Epi e,
+                                                        float* __restrict__ out, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int qs = (e.hw + 3) >> 2;
+    const int q = (int)(idx % qs);
+    int64_t r = idx / qs;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    const int cabs = e.coff + c;
+    const EpiCh ec = epi_channel(e, cabs);
+    const int p0 = q * 4;
+    const size_t off = epi_offset(e, n, cabs, p0);
+    if ((e.hw & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(x + off);
+        float4 o;
+        o.x = epi_apply(e, ec, v.x, n, cabs, p0);
+        o.y = epi_apply(e, ec, v.y, n, cabs, p0 + 1);
+        o.z = epi_apply(e, ec, v.z, n, cabs, p0 + 2);
+        o.w = epi_apply(e, ec, v.w, n, cabs, p0 + 3);
+        *reinterpret_cast<float4*>(out + off) = o;
+    } else {
+        for (int j = 0; j < 4 && p0 + j < e.hw; ++j) out[off + j] = epi_apply(e, ec, x[off + j], n, cabs, p0 + j);
+    }
+}
+
+// One workgroup per (n, c) plane: mean over HW with 16-byte loads, wave shuffles, then LDS across waves.
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, int HW, float* __restrict__ mean) {
+    const float* src = x + (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    if ((HW & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < (HW >> 2); i += 256) { const float4 v = s4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) s += src[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) mean[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)HW;
+}
+
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ mean, const float* __restrict__ w,
+                                                   int N, int Cin, int Cout, float* __restrict__ gate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * Cout) return;
+    const int n = idx / Cout, co = idx - n * Cout;
+    const float* m = mean + (size_t)n * Cin;
+    const float* wr = w + (size_t)co * Cin;
+    float s = 0.f;
+    for (int k = 0; k < Cin; ++k) s = fmaf(wr[k], m[k], s);
+    gate[idx] = 1.0f / (1.0f + expf(-s));
+}
+
+static int resample_common(const char* who, const float* x, float* out, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                           const mspl_epilogue_t* ep, RsGeom& g, Epi& e, int64_t& total) {
+    MSPL_REQUIRE(x && out, MSPL_ERR_NULL_POINTER, "%s: null pointer", who);
+    MSPL_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, MSPL_ERR_BAD_SHAPE,
+                 "%s: bad shape N=%d C=%d in=%dx%d out=%dx%d", who, N, C, Hi, Wi, Ho, Wo);
+    if (int rc = check_epi(ep, C, who)) return rc;
+    g.N = N; g.C = C; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo;
+    g.XS = ceil_div(Wo, 4);
+    g.sh = bilinear_scale(Hi, Ho);
+    g.sw = bilinear_scale(Wi, Wo);
+    e = make_epi(ep, C, Ho * Wo);
+    total = (int64_t)N * C * Ho * g.XS;
+    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "%s: grid too large", who);
+    return MSPL_OK;
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     const mspl_epilogue_t* ep, float* out, void* stream) {
+    RsGeom g; Epi e; int64_t total;
+    const int Ho = H > 0 ? (H - 1) / 2 + 1 : 0, Wo = W > 0 ? (W - 1) / 2 + 1 : 0;
+    if (int rc = resample_common("avgpool3x3s2", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
+    hipLaunchKernelGGL(avgpool3x3s2_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, g, e, out, total);
+    MSPL_CHECK_LAUNCH("avgpool3x3s2");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
+                                 int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream) {
+    RsGeom g; Epi e; int64_t total;
+    if (int rc = resample_common("bilinear", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, g, e, out, total);
+    MSPL_CHECK_LAUNCH("bilinear");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_adaptive_avgpool_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi,
+                                         int32_t Ho, int32_t Wo, const mspl_epilogue_t* ep, float* out,
+                                         void* stream) {
+    RsGeom g; Epi e; int64_t total;
+    if (int rc = resample_common("adaptive_avgpool", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, g, e, out, total);
+    MSPL_CHECK_LAUNCH("adaptive_avgpool");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t HW, const mspl_epilogue_t* ep,
+                                  float* out, void* stream) {
+    MSPL_REQUIRE(x && out, MSPL_ERR_NULL_POINTER, "pointwise: null pointer");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "pointwise: bad shape N=%d C=%d HW=%d", N, C, HW);
+    if (int rc = check_epi(ep, C, "pointwise")) return rc;
+    const Epi e = make_epi(ep, C, HW);
+    const int64_t total = (int64_t)N * C * ((HW + 3) / 4);
+    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "pointwise: grid too large");
+    hipLaunchKernelGGL(pointwise_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, N, C, e, out, total);
+    MSPL_CHECK_LAUNCH("pointwise");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
+                                 int32_t HW, float* mean_ws, float* gate, void* stream) {
+    MSPL_REQUIRE(x && w && mean_ws && gate, MSPL_ERR_NULL_POINTER, "gap_gate: null pointer");
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && HW > 0, MSPL_ERR_BAD_SHAPE,
+                 "gap_gate: bad shape N=%d Cin=%d Cout=%d HW=%d", N, Cin, Cout, HW);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)(N * Cin)), dim3(256), 0, s, x, HW, mean_ws);
+    MSPL_CHECK_LAUNCH("gap_gate(mean)");
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 256)), dim3(256), 0, s, mean_ws, w, N, Cin, Cout, gate);
+    MSPL_CHECK_LAUNCH("gap_gate(gate)");
+    return MSPL_OK;
+}

@@ -1,0 +1,401 @@
+"""Layer modules with the reference's class names, constructor signatures and state-dict keys, whose
+forward passes run on the HIP kernels of libmspl_hip.so.
+
+Reference surface mirrored (paths relative to the reference root):
+  nn_layers/espnet_utils.py  CBR:8 BR:39 CB:62 C:91 CDilated:118        (encoder dialect: .conv/.bn/.act)
+  nn_layers/cnn_utils.py     CBR:26 CB:56 BR:85 Shuffle:108              (decoder dialect: .cbr.0/1/2, .br.0/1)
+  nn_layers/eesp.py          EESP:15-93 DownSampler:96-144
+  nn_layers/efficient_pyramid_pool.py  EfficientPyrPool:12-61
+  nn_layers/efficient_pt.py  EfficientPWConv:10-29
+
+torch.nn.Conv2d / BatchNorm2d / PReLU objects are used as PARAMETER CONTAINERS only (so that
+state_dict() keys, shapes and init match the reference); their ATen forward is never called.
+BatchNorm runs in eval mode (running statistics), which is what the label pass and the uest
+self-training loop use (uest_seg_multi_os.py:605-608); it is folded into per-channel scale/shift
+vectors that are cached until a parameter changes.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import Epi
+
+config_inp_reinf = 3          # model/classification/espnetv2_config.py:20
+PYR_SCALES = (2.0, 1.5, 1.0, 0.5, 0.1)
+
+
+# ------------------------------------------------------------------ caching helpers
+def _key(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+def cached(module, name, deps, builder):
+    """Memoise builder() on `module` until any tensor in deps is modified, moved or replaced."""
+    store = module.__dict__.setdefault('_mspl_cache', {})
+    k = _key(deps)
+    hit = store.get(name)
+    if hit is None or hit[0] != k:
+        with torch.no_grad():
+            val = builder()
+        store[name] = hit = (k, val)
+    return hit[1]
+
+
+def _require_eval(bn):
+    if bn.training:
+        raise RuntimeError('mspl_amd: BatchNorm in training mode (batch statistics) is not implemented natively; '
+                           'call model.eval() -- the uest label pass and self-training loop run frozen BN '
+                           '(uest_seg_multi_os.py:605-608)')
+
+
+def bn_fold(bn):
+    """(scale, shift) with y = x*scale + shift == eval-mode BatchNorm2d."""
+    _require_eval(bn)
+
+    def build():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
+    return cached(bn, 'fold', [bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+
+def _no_grad_only():
+    if torch.is_grad_enabled():
+        raise RuntimeError('mspl_amd: this forward path has no autograd support; wrap it in torch.no_grad() '
+                           '(training goes through mspl_amd.training)')
+
+
+def _conv_fwd(x, conv, ep, out=None, shuffle_groups=0):
+    """Dispatch a bias-free Conv2d container to the matching kernel."""
+    k = conv.kernel_size[0]
+    if k == 1:
+        return ops.conv1x1(x, conv.weight, conv.groups, ep, out)
+    if k == 3 and conv.dilation[0] == 1:
+        return ops.conv3x3(x, conv.weight, conv.groups, conv.stride[0], shuffle_groups, ep, out)
+    raise RuntimeError('mspl_amd: no kernel for conv k=%d dilation=%d outside an EESP block' % (k, conv.dilation[0]))
+
+
+# ------------------------------------------------------------------ encoder dialect (espnet_utils)
+class CBR(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, groups=1):
+        super().__init__()
+        padding = int((kSize - 1) / 2)
+        self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, groups=groups)
+        self.bn = nn.BatchNorm2d(nOut)
+        self.act = nn.PReLU(nOut)
+
+    def forward(self, input):
+        _no_grad_only()
+        scale, shift = bn_fold(self.bn)
+        return _conv_fwd(input, self.conv, Epi(scale, shift, self.act.weight))
+
+
+class BR(nn.Module):
+    def __init__(self, nOut):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(nOut)
+        self.act = nn.PReLU(nOut)
+
+    def forward(self, input):
+        _no_grad_only()
+        scale, shift = bn_fold(self.bn)
+        return ops.pointwise(input, Epi(scale, shift, self.act.weight))
+
+
+class CB(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, groups=1):
+        super().__init__()
+        padding = int((kSize - 1) / 2)
+        self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, groups=groups)
+        self.bn = nn.BatchNorm2d(nOut)
+
+    def forward(self, input):
+        _no_grad_only()
+        scale, shift = bn_fold(self.bn)
+        return _conv_fwd(input, self.conv, Epi(scale, shift))
+
+
+class C(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, groups=1):
+        super().__init__()
+        padding = int((kSize - 1) / 2)
+        self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, groups=groups)
+
+    def forward(self, input):
+        _no_grad_only()
+        return _conv_fwd(input, self.conv, None)
+
+
+class CDilated(nn.Module):
+    """Parameter container of one dilated depthwise branch; EESP runs the four branches fused (K2)."""
+
+    def __init__(self, nIn, nOut, kSize, stride=1, d=1, groups=1):
+        super().__init__()
+        padding = int((kSize - 1) / 2) * d
+        self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, dilation=d,
+                              groups=groups)
+
+    def forward(self, input):
+        _no_grad_only()
+        return _conv_fwd(input, self.conv, None)
+
+
+# ------------------------------------------------------------------ decoder dialect (cnn_utils)
+class DecCBR(nn.Module):
+    def __init__(self, nIn, nOut, kSize, stride=1, dilation=1, groups=1, act_name='prelu'):
+        super().__init__()
+        if act_name != 'prelu':
+            raise NotImplementedError('mspl_amd: only PReLU activations are on the path')
+        padding = int((kSize - 1) / 2) * dilation
+        self.cbr = nn.Sequential(
+            nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, groups=groups, dilation=dilation),
+            nn.BatchNorm2d(nOut),
+            nn.PReLU(nOut))
+
+    def epi(self, **kw):
+        scale, shift = bn_fold(self.cbr[1])
+        return Epi(scale, shift, self.cbr[2].weight, **kw)
+
+    def forward(self, x):
+        _no_grad_only()
+        return _conv_fwd(x, self.cbr[0], self.epi())
+
+
+class DecBR(nn.Module):
+    def __init__(self, nOut, act_name='prelu'):
+        super().__init__()
+        if act_name != 'prelu':
+            raise NotImplementedError('mspl_amd: only PReLU activations are on the path')
+        self.br = nn.Sequential(nn.BatchNorm2d(nOut), nn.PReLU(nOut))
+
+    def forward(self, x):
+        _no_grad_only()
+        scale, shift = bn_fold(self.br[0])
+        return ops.pointwise(x, Epi(scale, shift, self.br[1].weight))
+
+
+class Shuffle(nn.Module):
+    """Channel shuffle (cnn_utils.py:108-125).  On the path it is folded into the next conv's input
+    indexing (mspl_conv3x3_fwd shuffle_groups); this standalone form only exists for API parity."""
+
+    def __init__(self, groups):
+        super().__init__()
+        self.groups = groups
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        return x.view(n, self.groups, c // self.groups, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+
+
+# ------------------------------------------------------------------ EESP / DownSampler
+def eesp_dilations(r_lim, k=4):
+    """nn_layers/eesp.py:38-53."""
+    ks = sorted((3 + 2 * i) if (3 + 2 * i) <= r_lim else 3 for i in range(k))
+    return [(s - 1) // 2 for s in ks]
+
+
+class EESP(nn.Module):
+    def __init__(self, nIn, nOut, stride=1, k=4, r_lim=7, down_method='esp'):
+        super().__init__()
+        self.stride = stride
+        n = int(nOut / k)
+        n1 = nOut - (k - 1) * n
+        assert down_method in ['avg', 'esp'], 'One of these is suppported (avg or esp)'
+        assert n == n1, "n(={}) and n1(={}) should be equal for Depth-wise Convolution ".format(n, n1)
+        if k != 4:
+            raise NotImplementedError('mspl_amd: the fused EESP kernel is built for k=4 branches')
+        self.proj_1x1 = CBR(nIn, n, 1, stride=1, groups=k)
+        self.dilations = eesp_dilations(r_lim, k)
+        self.spp_dw = nn.ModuleList(CDilated(n, n, kSize=3, stride=stride, groups=n, d=d) for d in self.dilations)
+        self.conv_1x1_exp = CB(nOut, nOut, 1, 1, groups=k)
+        self.br_after_cat = BR(nOut)
+        self.module_act = nn.PReLU(nOut)
+        self.downAvg = True if down_method == 'avg' else False
+        self.k = k
+
+    def _dw_weights(self):
+        ws = [m.conv.weight for m in self.spp_dw]
+        return cached(self, 'w4', ws, lambda: torch.stack([w.reshape(-1, 3, 3) for w in ws]).contiguous())
+
+    def reduce_transform(self, input):
+        """K1 + K2: returns the BN+PReLU'd concatenation that feeds conv_1x1_exp."""
+        o1 = self.proj_1x1(input)
+        scale, shift = bn_fold(self.br_after_cat.bn)
+        return ops.eesp_dw_hff(o1, self._dw_weights(), self.dilations, self.stride,
+                               Epi(scale, shift, self.br_after_cat.act.weight))
+
+    def forward(self, input):
+        _no_grad_only()
+        cat = self.reduce_transform(input)
+        scale, shift = bn_fold(self.conv_1x1_exp.bn)
+        if self.stride == 2 and self.downAvg:
+            return ops.conv1x1(cat, self.conv_1x1_exp.conv.weight, self.k, Epi(scale, shift))
+        residual = input if (self.stride == 1 and self.conv_1x1_exp.conv.out_channels == input.shape[1]) else None
+        return ops.conv1x1(cat, self.conv_1x1_exp.conv.weight, self.k,
+                           Epi(scale, shift, self.module_act.weight, residual=residual))
+
+
+class ImagePyramid:
+    """The input image and its repeated 3x3/s2 average pools, computed once per forward and shared by the
+    three DownSamplers (the reference recomputes the chain inside each one, nn_layers/eesp.py:136-140)."""
+
+    def __init__(self, image):
+        self.levels = [image]
+
+    def at_height(self, h):
+        """Pool at least once, then until the height matches (the reference's `while True` loop)."""
+        i = 1
+        while True:
+            if i == len(self.levels):
+                prev = self.levels[-1]
+                if prev.shape[2] == 1 and prev.shape[3] == 1:
+                    raise RuntimeError('mspl_amd: image pyramid never reaches height %d' % h)
+                self.levels.append(ops.avgpool3x3s2(prev))
+            if self.levels[i].shape[2] == h:
+                return self.levels[i]
+            i += 1
+
+
+class DownSampler(nn.Module):
+    def __init__(self, nin, nout, k=4, r_lim=9, reinf=True):
+        super().__init__()
+        nout_new = nout - nin
+        self.eesp = EESP(nin, nout_new, stride=2, k=k, r_lim=r_lim, down_method='avg')
+        self.avg = nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
+        if reinf:
+            self.inp_reinf = nn.Sequential(
+                CBR(config_inp_reinf, config_inp_reinf, 3, 1),
+                CB(config_inp_reinf, nout, 1, 1))
+        self.act = nn.PReLU(nout)
+        self.nin, self.nout = nin, nout
+
+    def _epilogue_vectors(self, with_reinf):
+        """Per-destination-channel constants for the two writers of the (N, nout, Ho, Wo) result:
+        channels [0,nin) <- avg-pool branch (scale 1), [nin,nout) <- conv_1x1_exp (its folded BN);
+        the reinforcement CB(3,nout,1) is folded to a (nout,3) matrix + shift added on both."""
+        bn = self.eesp.conv_1x1_exp.bn
+        deps = [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        if with_reinf:
+            cb = self.inp_reinf[1]
+            deps += [cb.conv.weight, cb.bn.weight, cb.bn.bias, cb.bn.running_mean, cb.bn.running_var]
+
+        def build():
+            es, eb = bn_fold(bn)
+            scale = torch.cat([torch.ones(self.nin, device=es.device), es])
+            shift = torch.cat([torch.zeros(self.nin, device=es.device), eb])
+            rw = None
+            if with_reinf:
+                rs, rb = bn_fold(cb.bn)
+                rw = (cb.conv.weight.reshape(self.nout, config_inp_reinf) * rs[:, None]).contiguous()
+                shift = shift + rb
+            return scale.contiguous(), shift.contiguous(), rw
+        return cached(self, 'epi%d' % int(with_reinf), deps, build)
+
+    def forward(self, input, input2=None):
+        _no_grad_only()
+        N, _, H, W = input.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((N, self.nout, Ho, Wo), device=input.device, dtype=torch.float32)
+        r = None
+        if input2 is not None:
+            pyr = input2 if isinstance(input2, ImagePyramid) else ImagePyramid(input2)
+            r = self.inp_reinf[0](pyr.at_height(Ho))
+            if r.shape[3] != Wo:
+                raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton '
+                                   'dimension 3' % (Wo, r.shape[3]))
+        scale, shift, rw = self._epilogue_vectors(r is not None)
+        ep = Epi(scale, shift, self.act.weight, reinf_r=r, reinf_w=rw)
+        ops.avgpool3x3s2(input, ep, out=(out, 0))
+        cat = self.eesp.reduce_transform(input)
+        ops.conv1x1(cat, self.eesp.conv_1x1_exp.conv.weight, self.eesp.k, ep, out=(out, self.nin))
+        return out
+
+
+# ------------------------------------------------------------------ decoder units
+class EfficientPyrPool(nn.Module):
+    def __init__(self, in_planes, proj_planes, out_planes, scales=[2.0, 1.5, 1.0, 0.5, 0.1], last_layer_br=True):
+        super().__init__()
+        scales = sorted(scales, reverse=True)   # the reference sorts its (shared, mutable) default in place
+        self.stages = nn.ModuleList()
+        self.projection_layer = DecCBR(in_planes, proj_planes, 1, 1)
+        for _ in scales:
+            self.stages.append(nn.Conv2d(proj_planes, proj_planes, kernel_size=3, stride=1, padding=1, bias=False,
+                                         groups=proj_planes))
+        self.merge_layer = nn.Sequential(
+            DecBR(proj_planes * len(scales)),
+            Shuffle(groups=len(scales)),
+            DecCBR(proj_planes * len(scales), proj_planes, 3, 1, groups=proj_planes),
+            nn.Conv2d(proj_planes, out_planes, kernel_size=1, stride=1, bias=not last_layer_br))
+        if last_layer_br:
+            self.br = DecBR(out_planes)
+        self.last_layer_br = last_layer_br
+        self.scales = scales
+        self.proj_planes = proj_planes
+
+    def _final_epilogue(self):
+        conv = self.merge_layer[3]
+        if not self.last_layer_br:
+            return Epi(shift=conv.bias)
+        bn, act = self.br.br[0], self.br.br[1]
+        scale, shift = bn_fold(bn)
+        return Epi(scale, shift, act.weight)
+
+    def forward(self, x):
+        _no_grad_only()
+        x = self.projection_layer(x)
+        N, P, height, width = x.shape
+        S = len(self.scales)
+        cat = torch.empty((N, P * S, height, width), device=x.device, dtype=torch.float32)
+        br = self.merge_layer[0].br
+        bscale, bshift = bn_fold(br[0])
+        ep = Epi(bscale, bshift, br[1].weight)       # merge_layer.0 (one big BN+PReLU) fused into each branch writer
+        for i, stage in enumerate(self.stages):
+            h_s = max(int(math.ceil(height * self.scales[i])), 5)
+            w_s = max(int(math.ceil(width * self.scales[i])), 5)
+            dst = (cat, i * P)
+            if self.scales[i] < 1.0:
+                h = ops.adaptive_avgpool(x, (h_s, w_s))
+                h = ops.conv3x3(h, stage.weight, P)
+                ops.bilinear(h, (height, width), ep, out=dst)
+            elif self.scales[i] > 1.0:
+                h = ops.bilinear(x, (h_s, w_s))
+                h = ops.conv3x3(h, stage.weight, P)
+                ops.adaptive_avgpool(h, (height, width), ep, out=dst)
+            else:
+                ops.conv3x3(x, stage.weight, P, ep=ep, out=dst)
+        mcbr = self.merge_layer[2]
+        m = ops.conv3x3(cat, mcbr.cbr[0].weight, P, 1, shuffle_groups=S, ep=mcbr.epi())
+        return ops.conv1x1(m, self.merge_layer[3].weight, 1, self._final_epilogue())
+
+
+class EfficientPWConv(nn.Module):
+    def __init__(self, nin, nout):
+        super().__init__()
+        self.wt_layer = nn.Sequential(
+            nn.AdaptiveAvgPool2d(output_size=1),
+            nn.Conv2d(nin, nout, kernel_size=1, stride=1, padding=0, groups=1, bias=False),
+            nn.Sigmoid())
+        self.groups = math.gcd(nin, nout)
+        self.expansion_layer = DecCBR(nin, nout, kSize=3, stride=1, groups=self.groups)
+        self.out_size = nout
+        self.in_size = nin
+
+    def forward(self, x):
+        _no_grad_only()
+        gate = ops.gap_gate(x, self.wt_layer[1].weight)
+        return ops.conv3x3(x, self.expansion_layer.cbr[0].weight, self.groups, ep=self.expansion_layer.epi(gate=gate))
+
+    def __repr__(self):
+        return '%s(in_channels=%d, out_channels=%d)' % (self.__class__.__name__, self.in_size, self.out_size)
+
+
+def decoder_merge(pw_out, bu_lowres, br_seq):
+    """bu_br(pw_out + upsample2(bu)): model/segmentation/espdnet_ue.py:276-280 in one kernel
+    (bilinear x2, align_corners=True, pre-add, folded BN, PReLU)."""
+    scale, shift = bn_fold(br_seq[0])
+    size = (bu_lowres.shape[2] * 2, bu_lowres.shape[3] * 2)
+    if tuple(pw_out.shape[2:]) != size:
+        raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 2'
+                           % (pw_out.shape[2], size[0]))
+    return ops.bilinear(bu_lowres, size, Epi(scale, shift, br_seq[1].weight, pre_add=pw_out))

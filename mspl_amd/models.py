@@ -1,0 +1,295 @@
+"""Segmentation networks with the reference's names, constructor arguments, state-dict keys and quirks.
+
+Reference surface mirrored (paths relative to the reference root):
+  model/classification/espnetv2.py:15-142         EESPNet (encoder; classifier/level5 dropped by the seg nets)
+  model/classification/espnetv2_config.py:6-23    channel tables, repetition counts, receptive-field limits
+  model/segmentation/espdnet_ue.py:18-302         ESPDNetwithUncertaintyEstimation, :304-382 espdnetue_seg2
+  model/segmentation/espnetv2.py:16-198           ESPNetv2Segmentation, espnetv2_seg
+  nn_layers/fusion_gate.py:11-47                  FusionGate (parameters only: RGB-D fusion is out of scope)
+
+Beyond the reference API each network offers `forward_lowres(x)` -- the decoder outputs before the final
+bilinear upsample -- which the pseudo-label pass feeds to the fused label epilogue so that full-resolution
+logits are never written to HBM.
+"""
+import copy
+import os
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from . import ops
+from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _no_grad_only,
+                     decoder_merge)
+
+sc_ch_dict = {
+    0.5: [16, 32, 64, 128, 256, 1024],
+    1.0: [32, 64, 128, 256, 512, 1024],
+    1.25: [32, 80, 160, 320, 640, 1024],
+    1.5: [32, 96, 192, 384, 768, 1024],
+    2.0: [32, 128, 256, 512, 1024, 1280],
+}
+rep_layers = [0, 3, 7, 3]
+recept_limit = [13, 11, 9, 7, 5]
+branches = 4
+input_reinforcement = True
+
+DEC_FEAT = {'pascal': 16, 'city': 16, 'coco': 32, 'greenhouse': 16, 'ishihara': 16, 'sun': 16, 'camvid': 16,
+            'forest': 16}
+
+
+def _init_params(model):
+    """init_params of the reference models (espdnet_ue.py:112-127)."""
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            init.kaiming_normal_(m.weight, mode='fan_out')
+            if m.bias is not None:
+                init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm2d):
+            init.constant_(m.weight, 1)
+            init.constant_(m.bias, 0)
+        elif isinstance(m, nn.Linear):
+            init.normal_(m.weight, std=0.001)
+            if m.bias is not None:
+                init.constant_(m.bias, 0)
+
+
+def _param_gen(modules):
+    for mod in modules:
+        for _, m in mod.named_modules():
+            if isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.PReLU)):
+                for p in m.parameters():
+                    if p.requires_grad:
+                        yield p
+
+
+class EESPNet(nn.Module):
+    """Encoder trunk.  Only the levels the segmentation nets keep (1-4) are built; the ImageNet head
+    (level5, classifier) is deleted by the reference right after construction (espdnet_ue.py:35-37)."""
+
+    def __init__(self, args):
+        super().__init__()
+        channels_in = getattr(args, 'channels', 3)
+        s = args.s
+        if s not in sc_ch_dict:
+            raise ValueError('Model at scale s={} is not supported yet'.format(s))
+        cm = sc_ch_dict[s]
+        K = [branches] * len(recept_limit)
+        self.input_reinforcement = getattr(args, 'input_reinforcement', input_reinforcement)
+        self.level1 = CBR(channels_in, cm[0], 3, 2)
+        self.level2_0 = DownSampler(cm[0], cm[1], k=K[0], r_lim=recept_limit[0], reinf=self.input_reinforcement)
+        self.level3_0 = DownSampler(cm[1], cm[2], k=K[1], r_lim=recept_limit[1], reinf=self.input_reinforcement)
+        self.level3 = nn.ModuleList(EESP(cm[2], cm[2], stride=1, k=K[2], r_lim=recept_limit[2])
+                                    for _ in range(rep_layers[1]))
+        self.level4_0 = DownSampler(cm[2], cm[3], k=K[2], r_lim=recept_limit[2], reinf=self.input_reinforcement)
+        self.level4 = nn.ModuleList(EESP(cm[3], cm[3], stride=1, k=K[3], r_lim=recept_limit[3])
+                                    for _ in range(rep_layers[2]))
+        self.config = cm
+        _init_params(self)
+
+
+class FusionGate(nn.Module):
+    """RGB-D fusion gate parameters (nn_layers/fusion_gate.py:11-47).  Present in every checkpoint, unused
+    when x_d is None (all multi-source scripts)."""
+
+    def __init__(self, nchannel, is_trainable=True):
+        super().__init__()
+        self.nchannel = nchannel
+        self.conv_1x1 = C(nIn=2 * nchannel, nOut=nchannel, kSize=1)
+        self.sigmoid = nn.Sigmoid()
+        self.is_trainable = is_trainable
+
+    def forward(self, rgb, depth):
+        raise NotImplementedError('mspl_amd: RGB-D fusion (x_d) is outside the hot path (SURVEY.md section 8f rank 3)')
+
+
+class _SegBase(nn.Module):
+    def _build_decoder(self, config, classes, dataset, pyr_plane_proj, with_aux, aux_layer=2):
+        base = DEC_FEAT[dataset]
+        dec = [4 * base, 3 * base, 2 * base, classes]
+        self.bu_dec_l1 = EfficientPyrPool(in_planes=config[3], proj_planes=pyr_plane_proj, out_planes=dec[0])
+        self.bu_dec_l2 = EfficientPyrPool(in_planes=dec[0], proj_planes=pyr_plane_proj, out_planes=dec[1])
+        self.bu_dec_l3 = EfficientPyrPool(in_planes=dec[1], proj_planes=pyr_plane_proj, out_planes=dec[2])
+        self.bu_dec_l4 = EfficientPyrPool(in_planes=dec[2], proj_planes=pyr_plane_proj, out_planes=dec[3],
+                                          last_layer_br=False)
+        self.merge_enc_dec_l2 = EfficientPWConv(config[2], dec[0])
+        self.merge_enc_dec_l3 = EfficientPWConv(config[1], dec[1])
+        self.merge_enc_dec_l4 = EfficientPWConv(config[0], dec[2])
+        self.bu_br_l2 = nn.Sequential(nn.BatchNorm2d(dec[0]), nn.PReLU(dec[0]))
+        self.bu_br_l3 = nn.Sequential(nn.BatchNorm2d(dec[1]), nn.PReLU(dec[1]))
+        self.bu_br_l4 = nn.Sequential(nn.BatchNorm2d(dec[2]), nn.PReLU(dec[2]))
+        if with_aux:
+            self.aux_layer = aux_layer
+            if 0 <= aux_layer < 3:
+                self.aux_decoder = EfficientPyrPool(in_planes=dec[aux_layer], proj_planes=pyr_plane_proj,
+                                                    out_planes=dec[3], last_layer_br=False)
+
+    def _encode(self, x, image_for_l2, l3_tail):
+        b = self.base_net
+        pyr = ImagePyramid(x) if b.input_reinforcement else None
+        l1 = b.level1(x)
+        l2 = b.level2_0(l1, pyr if image_for_l2 else None)
+        l3 = b.level3_0(l2, pyr)
+        for i, layer in enumerate(b.level3):
+            l3 = (layer if i == 0 else l3_tail[i])(l3)
+        l4 = b.level4_0(l3, pyr)
+        for layer in b.level4:
+            l4 = layer(l4)
+        return l1, l2, l3, l4
+
+    def _decode(self, l1, l2, l3, l4, aux_layer):
+        aux = None
+        bu = self.bu_dec_l1(l4)
+        if aux_layer == 0:
+            aux = self.aux_decoder(bu)
+        bu = decoder_merge(self.merge_enc_dec_l2(l3), bu, self.bu_br_l2)
+        bu = self.bu_dec_l2(bu)
+        if aux_layer == 1:
+            aux = self.aux_decoder(bu)
+        bu = decoder_merge(self.merge_enc_dec_l3(l2), bu, self.bu_br_l3)
+        bu = self.bu_dec_l3(bu)
+        if aux_layer == 2:
+            aux = self.aux_decoder(bu)
+        bu = decoder_merge(self.merge_enc_dec_l4(l1), bu, self.bu_br_l4)
+        bu = self.bu_dec_l4(bu)
+        return bu, aux
+
+    def get_basenet_params(self):
+        return _param_gen([self.base_net])
+
+    def get_segment_params(self):
+        return _param_gen([self.bu_dec_l1, self.bu_dec_l2, self.bu_dec_l3, self.bu_dec_l4, self.merge_enc_dec_l4,
+                           self.merge_enc_dec_l3, self.merge_enc_dec_l2, self.bu_br_l4, self.bu_br_l3, self.bu_br_l2])
+
+    def upsample(self, x):
+        return ops.bilinear(x, (x.shape[2] * 2, x.shape[3] * 2))
+
+
+def _check_input(x):
+    if x.dim() != 4:
+        raise RuntimeError('mspl_amd: expected an (N,C,H,W) batch, got %s' % (tuple(x.shape),))
+    if x.shape[2] % 16 or x.shape[3] % 16:
+        # the reference fails at the first decoder skip-add; fail up front with its message shape
+        raise RuntimeError('The size of tensor a must match the size of tensor b: input %dx%d is not a multiple of 16 '
+                           '(mspl_amd: H/W not multiple of 16)' % (x.shape[2], x.shape[3]))
+
+
+class ESPDNetwithUncertaintyEstimation(_SegBase):
+    def __init__(self, args, classes=21, dataset='pascal', dense_fuse=False, trainable_fusion=True, aux_layer=2,
+                 fix_pyr_plane_proj=False):
+        super().__init__()
+        self.base_net = EESPNet(args)
+        config = self.base_net.config
+        tmp_args = copy.deepcopy(args)
+        tmp_args.channels = 1
+        self.depth_base_net = EESPNet(tmp_args)
+        self.fusion_gate_level1 = FusionGate(nchannel=32, is_trainable=trainable_fusion)
+        self.fusion_gate_level2 = FusionGate(nchannel=128, is_trainable=trainable_fusion)
+        self.fusion_gate_level3 = FusionGate(nchannel=256, is_trainable=trainable_fusion)
+        self.fusion_gate_level4 = FusionGate(nchannel=512, is_trainable=trainable_fusion)
+        base = DEC_FEAT[dataset]
+        pyr = base if fix_pyr_plane_proj else min(classes // 2, base)
+        self._build_decoder(config, classes, dataset, pyr, True, aux_layer)
+        _init_params(self)
+        self.dense_fuse = dense_fuse
+        self.classes = classes
+
+    def get_depth_encoder_params(self):
+        return _param_gen([self.depth_base_net])
+
+    def get_classification_layer_params(self):
+        return self.get_segment_params()
+
+    def forward_lowres(self, x, x_d=None):
+        """(main at H/2 x W/2, aux at H/4 x W/4 for aux_layer=2): decoder outputs before espdnet_ue.py:301-302."""
+        _no_grad_only()
+        if x_d is not None:
+            raise NotImplementedError('mspl_amd: the depth branch (x_d) is outside the hot path (use_depth=False in every '
+                                      'multi-source script)')
+        _check_input(x)
+        # level3[1:] run through depth_base_net's layers (espdnet_ue.py:226) -- reproduced on purpose
+        l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3)
+        return self._decode(l1, l2, l3, l4, self.aux_layer)
+
+    def forward(self, x, x_d=None):
+        main, aux = self.forward_lowres(x, x_d)
+        r = ops.label_epilogue(main, aux, x.shape[2:], want_labels=False, want_logits=True)
+        return r['main_up'], r['aux_up']
+
+
+class ESPNetv2Segmentation(_SegBase):
+    def __init__(self, args, classes=21, dataset='pascal'):
+        super().__init__()
+        self.base_net = EESPNet(args)
+        config = self.base_net.config
+        self._build_decoder(config, classes, dataset, min(classes // 2, DEC_FEAT[dataset]), False)
+        _init_params(self)
+        self.classes = classes
+
+    def forward_lowres(self, x):
+        _no_grad_only()
+        _check_input(x)
+        # level2_0 is called WITHOUT the image (espnetv2.py:127)
+        l1, l2, l3, l4 = self._encode(x, False, self.base_net.level3)
+        return self._decode(l1, l2, l3, l4, -1)[0], None
+
+    def forward(self, x):
+        main, _ = self.forward_lowres(x)
+        return ops.bilinear(main, x.shape[2:])
+
+
+# ------------------------------------------------------------------ factories / checkpoint loaders
+def _load_file(weights):
+    if not os.path.isfile(weights):
+        raise FileNotFoundError('Weight file does not exist at {}. Please check.'.format(weights))
+    return torch.load(weights, map_location='cpu')
+
+
+def espdnetue_seg2(args, load_entire_weights=False, fix_pyr_plane_proj=False):
+    """espdnet_ue.py:304-382, including the lossy loader: after the main load, the SAME file refills
+    depth_base_net from its base_net.* entries (k.lstrip('base_net.'), level1 averaged over RGB)."""
+    model = ESPDNetwithUncertaintyEstimation(args, classes=args.classes, dataset=args.dataset,
+                                             dense_fuse=args.dense_fuse, trainable_fusion=args.trainable_fusion,
+                                             fix_pyr_plane_proj=fix_pyr_plane_proj)
+    weights = args.weights
+    if weights:
+        pretrained = _load_file(weights)
+        model_dict = model.state_dict()
+        if load_entire_weights:
+            overlap = {k: v for k, v in pretrained.items() if k in model_dict and model_dict[k].size() == v.size()}
+            if len(overlap) == 0:
+                raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+            model_dict.update(overlap)
+            model.load_state_dict(model_dict)
+        else:
+            base_dict = model.base_net.state_dict()
+            overlap = {k.replace('base_net.', ''): v for k, v in pretrained.items()
+                       if k.replace('base_net.', '') in base_dict}
+            if len(overlap) == 0:
+                raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+            base_dict.update(overlap)
+            model.base_net.load_state_dict(base_dict)
+        # depth_weights = weights (espdnet_ue.py:310,361-380)
+        d_dict = model.depth_base_net.state_dict()
+        overlap = {k.lstrip('base_net.'): v for k, v in pretrained.items() if k.lstrip('base_net.') in d_dict}
+        if 'level1.conv.weight' in overlap:
+            overlap['level1.conv.weight'] = torch.mean(overlap['level1.conv.weight'], dim=1, keepdim=True)
+        if len(overlap) == 0:
+            raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+        d_dict.update(overlap)
+        model.depth_base_net.load_state_dict(d_dict)
+    return model
+
+
+def espnetv2_seg(args):
+    """model/segmentation/espnetv2.py:170-198: only base_net.* keys are taken from the file."""
+    model = ESPNetv2Segmentation(args, classes=args.classes, dataset=args.dataset)
+    if args.weights:
+        pretrained = _load_file(args.weights)
+        base_dict = model.base_net.state_dict()
+        overlap = {k: v for k, v in pretrained.items() if k in base_dict}
+        if len(overlap) == 0:
+            raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+        base_dict.update(overlap)
+        model.base_net.load_state_dict(base_dict)
+    return model

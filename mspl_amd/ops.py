@@ -1,0 +1,244 @@
+"""Tensor-level wrappers of the C ABI (forward ops).
+
+PyTorch is plumbing only here: it owns device memory (caching allocator) and the stream.  Every wrapper
+checks device/dtype/contiguity on the host before a pointer reaches a kernel, allocates the output with
+torch.empty, and launches on torch's current stream so the calls are capturable by torch.cuda.graph().
+"""
+import ctypes
+
+import torch
+
+from . import _native as nat
+from ._native import Epilogue, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('mspl_amd: %s must be a CUDA (ROCm) tensor; there is no CPU path' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('mspl_amd: %s must be float32, got %s' % (name, t.dtype))
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _vec(t, n, name):
+    if t is None:
+        return None
+    t = _f32(t, name)
+    if t.numel() != n:
+        raise RuntimeError('mspl_amd: %s has %d elements, expected %d' % (name, t.numel(), n))
+    return t
+
+
+class Epi:
+    """Python mirror of mspl_epilogue_t (see include/mspl_hip.h for the exact order of operations)."""
+    __slots__ = ('scale', 'shift', 'alpha', 'pre_add', 'residual', 'reinf_r', 'reinf_w', 'gate')
+
+    def __init__(self, scale=None, shift=None, alpha=None, pre_add=None, residual=None, reinf_r=None,
+                 reinf_w=None, gate=None):
+        self.scale, self.shift, self.alpha = scale, shift, alpha
+        self.pre_add, self.residual = pre_add, residual
+        self.reinf_r, self.reinf_w, self.gate = reinf_r, reinf_w, gate
+
+
+def _build(ep, out, coff, N, C, hw):
+    """Validate an Epi against the destination tensor `out` (N, ctot, ...) and build the C struct."""
+    ctot = out.shape[1]
+    if coff < 0 or coff + C > ctot:
+        raise RuntimeError('mspl_amd: channel slice [%d,%d) outside destination with %d channels' % (coff, coff + C, ctot))
+    s = Epilogue()
+    s.out_ctot, s.out_coff = ctot, coff
+    keep = []
+    if ep is not None:
+        for f in ('scale', 'shift', 'alpha'):
+            v = _vec(getattr(ep, f), ctot, f)
+            keep.append(v)
+            setattr(s, f, None if v is None else v.data_ptr())
+        for f in ('pre_add', 'residual'):
+            v = getattr(ep, f)
+            if v is not None:
+                v = _f32(v, f)
+                if v.numel() != N * ctot * hw:
+                    raise RuntimeError('mspl_amd: %s shape %s does not match destination %s' % (f, tuple(v.shape), tuple(out.shape)))
+                keep.append(v)
+                setattr(s, f, v.data_ptr())
+        if ep.reinf_r is not None:
+            r = _vec(ep.reinf_r, N * 3 * hw, 'reinf_r')
+            w = _vec(ep.reinf_w, ctot * 3, 'reinf_w')
+            keep += [r, w]
+            s.reinf_r, s.reinf_w = r.data_ptr(), w.data_ptr()
+        if ep.gate is not None:
+            g = _vec(ep.gate, N * ctot, 'gate')
+            keep.append(g)
+            s.gate = g.data_ptr()
+    return s, keep
+
+
+def _dest(out, shape, like):
+    if out is None:
+        return torch.empty(shape, device=like.device, dtype=torch.float32), 0
+    dst, coff = out
+    if (dst.shape[0],) + tuple(dst.shape[2:]) != (shape[0],) + tuple(shape[2:]) or not dst.is_contiguous() \
+            or dst.dtype != torch.float32 or not dst.is_cuda:
+        raise RuntimeError('mspl_amd: destination %s incompatible with result %s' % (tuple(dst.shape), tuple(shape)))
+    return dst, coff
+
+
+def eesp_dw_hff(x, w4, dil, stride, ep=None, out=None):
+    """K2.  x (N,n,H,W), w4 (4,n,3,3) -> (N,4n,Ho,Wo); `out=(tensor, channel_offset)` writes a slice."""
+    x, w4 = _f32(x, 'x'), _f32(w4, 'w4')
+    N, n, H, W = x.shape
+    if tuple(w4.shape) != (4, n, 3, 3):
+        raise RuntimeError('mspl_amd: eesp_dw_hff weight %s, expected (4,%d,3,3)' % (tuple(w4.shape), n))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dst, coff = _dest(out, (N, 4 * n, Ho, Wo), x)
+    s, keep = _build(ep, dst, coff, N, 4 * n, Ho * Wo)
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dil])
+    check(lib.mspl_eesp_dw_hff_fwd(_p(x), _p(w4), d, stride, N, n, H, W, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def conv1x1(x, w, groups=1, ep=None, out=None):
+    """K1/K3.  x (N,Cin,H,W), w (Cout,Cin/groups[,1,1])."""
+    x, w = _f32(x, 'x'), _f32(w, 'w')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if w.numel() != Cout * (Cin // groups) or Cin % groups or Cout % groups:
+        raise RuntimeError('mspl_amd: conv1x1 weight %s does not match Cin=%d groups=%d' % (tuple(w.shape), Cin, groups))
+    dst, coff = _dest(out, (N, Cout, H, W), x)
+    s, keep = _build(ep, dst, coff, N, Cout, H * W)
+    check(lib.mspl_conv1x1_fwd(_p(x), _p(w), N, Cin, Cout, groups, H * W, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def conv3x3(x, w, groups=1, stride=1, shuffle_groups=0, ep=None, out=None):
+    x, w = _f32(x, 'x'), _f32(w, 'w')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape[2:]) != (3, 3) or Cin % groups or Cout % groups or w.shape[1] != Cin // groups:
+        raise RuntimeError('mspl_amd: conv3x3 weight %s does not match Cin=%d groups=%d' % (tuple(w.shape), Cin, groups))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dst, coff = _dest(out, (N, Cout, Ho, Wo), x)
+    s, keep = _build(ep, dst, coff, N, Cout, Ho * Wo)
+    check(lib.mspl_conv3x3_fwd(_p(x), _p(w), N, Cin, Cout, groups, H, W, stride, shuffle_groups, ctypes.byref(s),
+                               _p(dst), _stream()))
+    return dst
+
+
+def avgpool3x3s2(x, ep=None, out=None):
+    x = _f32(x, 'x')
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dst, coff = _dest(out, (N, C, Ho, Wo), x)
+    s, keep = _build(ep, dst, coff, N, C, Ho * Wo)
+    check(lib.mspl_avgpool3x3s2_fwd(_p(x), N, C, H, W, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def bilinear(x, size, ep=None, out=None):
+    """align_corners=True bilinear resize to size=(Ho,Wo)."""
+    x = _f32(x, 'x')
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    dst, coff = _dest(out, (N, C, Ho, Wo), x)
+    s, keep = _build(ep, dst, coff, N, C, Ho * Wo)
+    check(lib.mspl_bilinear_fwd(_p(x), N, C, H, W, Ho, Wo, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def adaptive_avgpool(x, size, ep=None, out=None):
+    x = _f32(x, 'x')
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    dst, coff = _dest(out, (N, C, Ho, Wo), x)
+    s, keep = _build(ep, dst, coff, N, C, Ho * Wo)
+    check(lib.mspl_adaptive_avgpool_fwd(_p(x), N, C, H, W, Ho, Wo, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def pointwise(x, ep, out=None):
+    """Apply the epilogue elementwise (BatchNorm+PReLU blocks)."""
+    x = _f32(x, 'x')
+    N, C = x.shape[:2]
+    hw = x[0, 0].numel()
+    dst = torch.empty_like(x) if out is None else out
+    s, keep = _build(ep, dst, 0, N, C, hw)
+    check(lib.mspl_pointwise_fwd(_p(x), N, C, hw, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
+def gap_gate(x, w):
+    """sigmoid(W . mean_hw(x)) -> (N, Cout)."""
+    x, w = _f32(x, 'x'), _f32(w, 'w')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if w.numel() != Cout * Cin:
+        raise RuntimeError('mspl_amd: gap_gate weight %s does not match Cin=%d' % (tuple(w.shape), Cin))
+    ws = torch.empty((N, Cin), device=x.device, dtype=torch.float32)
+    gate = torch.empty((N, Cout), device=x.device, dtype=torch.float32)
+    check(lib.mspl_gap_gate_fwd(_p(x), _p(w), N, Cin, Cout, H * W, _p(ws), _p(gate), _stream()))
+    return gate
+
+
+def label_epilogue(main, aux, size, lut=None, want_labels=True, want_prob=False, want_kld=False,
+                   want_logits=False):
+    """K8+K9.  Returns dict with any of labels (uint8 N,H,W), prob, kld, main_up, aux_up."""
+    main = _f32(main, 'main')
+    N, C, Hm, Wm = main.shape
+    Ha = Wa = 0
+    if aux is not None:
+        aux = _f32(aux, 'aux')
+        if aux.shape[0] != N or aux.shape[1] != C:
+            raise RuntimeError('mspl_amd: aux logits %s do not match main %s' % (tuple(aux.shape), tuple(main.shape)))
+        Ha, Wa = aux.shape[2:]
+    H, W = int(size[0]), int(size[1])
+    dev = main.device
+    res = {}
+    if lut is not None:
+        if lut.dtype != torch.uint8 or not lut.is_cuda or lut.numel() < C:
+            raise RuntimeError('mspl_amd: lut must be a CUDA uint8 tensor with >= %d entries' % C)
+    if want_labels:
+        res['labels'] = torch.empty((N, H, W), device=dev, dtype=torch.uint8)
+    if want_prob:
+        res['prob'] = torch.empty((N, C, H, W), device=dev, dtype=torch.float32)
+    if want_kld:
+        res['kld'] = torch.empty((N, H, W), device=dev, dtype=torch.float32)
+    if want_logits:
+        res['main_up'] = torch.empty((N, C, H, W), device=dev, dtype=torch.float32)
+        if aux is not None:
+            res['aux_up'] = torch.empty((N, C, H, W), device=dev, dtype=torch.float32)
+    check(lib.mspl_label_epilogue_fwd(_p(main), _p(aux), N, C, Hm, Wm, Ha, Wa, H, W, _p(lut), _p(res.get('labels')),
+                                      _p(res.get('prob')), _p(res.get('kld')), _p(res.get('main_up')),
+                                      _p(res.get('aux_up')), _stream()))
+    return res
+
+
+def merge_labels(sources, num_classes, thresh, fill=4, hist=None):
+    """K10.  sources: list of uint8 CUDA tensors of identical shape.  hist: uint64-as-int64 CUDA tensor of
+    num_classes entries, accumulated into (caller zeroes), or None."""
+    S = len(sources)
+    if S < 1:
+        raise RuntimeError('mspl_amd: merge_labels needs at least one source')
+    src = []
+    for t in sources:
+        if t.dtype != torch.uint8 or not t.is_cuda:
+            raise RuntimeError('mspl_amd: merge_labels sources must be CUDA uint8 tensors')
+        if t.shape != sources[0].shape:
+            raise RuntimeError('mspl_amd: merge_labels sources differ in shape')
+        src.append(t.contiguous())
+    out = torch.empty_like(src[0])
+    if hist is not None and (hist.dtype != torch.int64 or not hist.is_cuda or hist.numel() < num_classes):
+        raise RuntimeError('mspl_amd: hist must be a CUDA int64 tensor with >= num_classes entries')
+    arr = (ctypes.c_void_p * S)(*[t.data_ptr() for t in src])
+    check(lib.mspl_merge_labels_fwd(arr, S, out.numel(), num_classes, int(thresh), int(fill), _p(out), _p(hist),
+                                    _stream()))
+    return out

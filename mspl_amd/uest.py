@@ -1,0 +1,150 @@
+"""The pseudo-label pass of uest_seg_multi_os.py on the HIP path.
+
+Reference functions mirrored (same names / argument meaning; paths relative to the reference root):
+  get_output                          uest_seg_multi_os.py:669-693
+  merge_outputs                       uest_seg_multi_os.py:695-718
+  generate_pseudo_label_multi_model   uest_seg_multi_os.py:832-956  -> PseudoLabelPass (batched, on device)
+  id_*_to_greenhouse                  data_loader/segmentation/greenhouse.py:15-58
+
+The reference runs batch size 1, one source model after another, and post-processes on the host with
+numpy (two D2H copies of C*H*W floats per model per image).  Here a batch of images goes through all
+source models on the GPU; the only tensors that ever exist at full resolution are uint8 class maps
+(1 byte/pixel/source), merged by an integer kernel that also accumulates the class histogram.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+# data_loader/segmentation/greenhouse.py:15-58 (literal tables: source class id -> greenhouse class id)
+id_camvid_to_greenhouse = np.array([4, 2, 2, 3, 3, 1, 2, 2, 2, 4, 4, 2, 4])
+id_cityscapes_to_greenhouse = np.array([3, 3, 2, 2, 2, 2, 2, 2, 1, 3, 4, 4, 4, 2, 2, 2, 2, 2, 2, 4])
+id_forest_to_greenhouse = np.array([3, 1, 1, 2, 2])
+LUTS = {'camvid': id_camvid_to_greenhouse, 'cityscapes': id_cityscapes_to_greenhouse,
+        'forest': id_forest_to_greenhouse}
+GREENHOUSE_CLASSES = 5
+NO_AGREEMENT_CLASS = 4      # the literal written at uest_seg_multi_os.py:716
+
+
+def resolve_thresh(num_data, thresh):
+    """Vote threshold rule of merge_outputs (uest_seg_multi_os.py:697-705)."""
+    if thresh is None or thresh == 'half':
+        return num_data // 2 + 1
+    if thresh == 'all':
+        return num_data
+    if isinstance(thresh, int) and not isinstance(thresh, bool) and thresh <= num_data:
+        return thresh
+    return num_data // 2 + 1
+
+
+def _lowres(model, image):
+    out = model.forward_lowres(image)
+    return out if isinstance(out, tuple) else (out, None)
+
+
+def get_output(model, image, model_name='espdnetue', device='cuda'):
+    """Drop-in for uest_seg_multi_os.get_output: (softmax(pred + 0.5*aux) of batch element 0 as a numpy
+    (C,H,W) array, KL(pred||aux) map as numpy (H,W)).  The upsample, the softmax and the KLD run in one
+    kernel; only the two requested maps are copied to the host."""
+    with torch.no_grad():
+        image = image.to(device)
+        main, aux = _lowres(model, image)
+        r = ops.label_epilogue(main, aux, image.shape[2:], want_labels=False, want_prob=True, want_kld=True)
+    return r['prob'][0].cpu().numpy(), r['kld'][0].cpu().numpy()
+
+
+def merge_outputs(amax_outputs, seg_classes=GREENHOUSE_CLASSES, thresh=None):
+    """Drop-in for uest_seg_multi_os.merge_outputs.  amax_outputs: (S, ...) class maps, numpy or torch.
+    numpy in -> numpy int64 out (like counts_np.argmax); CUDA uint8 in -> CUDA uint8 out."""
+    is_np = isinstance(amax_outputs, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(amax_outputs).astype(np.uint8)).cuda() if is_np else amax_outputs
+    if t.dtype != torch.uint8:
+        t = t.to(torch.uint8)
+    S = t.shape[0]
+    if t[0].numel() == 0:
+        out = torch.empty_like(t[0])
+    else:
+        out = ops.merge_labels([t[s] for s in range(S)], seg_classes, resolve_thresh(S, thresh), NO_AGREEMENT_CLASS)
+    return out.cpu().numpy().astype(np.int64) if is_np else out
+
+
+def class_weights_from_histogram(class_array, policy='normal'):
+    """uest_seg_multi_os.py:942-947 (host-side, 5 float64 values)."""
+    class_array = np.asarray(class_array, dtype=np.float64)
+    if policy == 'normal':
+        freq = class_array / class_array.sum()
+        w = 1.0 / (freq + 1e-10)
+        w[0] = 0.0
+        return w
+    return np.ones(len(class_array))
+
+
+class PseudoLabelPass:
+    """Batched multi-source pseudo-label generation (the loop body of generate_pseudo_label_multi_model).
+
+    model_list / os_data_list as in the reference (os_data in {'camvid','cityscapes','forest', other=identity}).
+    __call__(images) -> merged uint8 label maps (N,H,W) on the device; the per-class pixel histogram
+    accumulates in self.hist (int64[classes], device) until reset().  With use_graph=True the whole pass
+    for one batch shape is captured once into a hipGraph and replayed.
+    """
+
+    def __init__(self, model_list, os_data_list, classes=GREENHOUSE_CLASSES, merge_label_policy='all',
+                 device='cuda', use_graph=False):
+        if len(model_list) != len(os_data_list) or not model_list:
+            raise ValueError('model_list and os_data_list must be non-empty and of equal length')
+        self.models = [m.to(device).eval() for m in model_list]
+        self.os_data = list(os_data_list)
+        self.classes = classes
+        self.thresh = resolve_thresh(len(model_list), merge_label_policy)
+        self.device = torch.device(device)
+        self.luts = []
+        for m, d in zip(self.models, self.os_data):
+            lut = LUTS.get(d)
+            self.luts.append(None if lut is None else torch.from_numpy(lut.astype(np.uint8)).to(self.device))
+        self.hist = torch.zeros(classes, dtype=torch.int64, device=self.device)
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    def reset(self):
+        self.hist.zero_()
+
+    def _run(self, images):
+        maps = []
+        for m, lut in zip(self.models, self.luts):
+            main, aux = _lowres(m, images)
+            maps.append(ops.label_epilogue(main, aux, images.shape[2:], lut=lut)['labels'])
+        return ops.merge_labels(maps, self.classes, self.thresh, NO_AGREEMENT_CLASS, self.hist), maps
+
+    def source_maps(self, images):
+        """Per-source class maps (after the id LUT) -- what the reference appends to output_list."""
+        with torch.no_grad():
+            return self._run(images.to(self.device))[1]
+
+    def __call__(self, images):
+        with torch.no_grad():
+            images = images.to(self.device)
+            if not self.use_graph:
+                return self._run(images)[0]
+            key = tuple(images.shape)
+            g = self._graphs.get(key)
+            if g is None:
+                static_in = images.clone()
+                hist_before = self.hist.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):       # warm-up: fills the folded-BN caches outside the capture
+                    self._run(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                self.hist.copy_(hist_before)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._run(static_in)[0]
+                self.hist.copy_(hist_before)        # capture does not execute, but keep the invariant explicit
+                g = self._graphs[key] = (graph, static_in, static_out)
+            graph, static_in, static_out = g
+            static_in.copy_(images)
+            graph.replay()
+            return static_out
+
+    def class_weights(self, policy='normal'):
+        return torch.from_numpy(class_weights_from_histogram(self.hist.cpu().numpy(), policy)).float().to(self.device)

@@ -1,0 +1,184 @@
+"""Per-kernel parity against plain torch-CPU fp32 statements of the same op (the oracle's primitives),
+over the awkward shapes: odd sizes, widths not divisible by 4, channel slices, every epilogue term."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, atol=2e-5, rtol=1e-4):
+    torch.testing.assert_close(a.cpu(), b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('dil', [[1, 2, 3, 4], [1, 1, 2, 3], [1, 1, 1, 2]])
+@pytest.mark.parametrize('stride', [1, 2])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 30), (1, 24, 33, 61), (2, 4, 128, 240), (1, 6, 5, 7), (3, 16, 32, 60)])
+def test_eesp_dw_hff(dil, stride, shape):
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, n, H, W = shape
+    x = rnd(*shape, seed=1)
+    w = rnd(4, n, 3, 3, seed=2, scale=0.3)
+    scale, shift, alpha = rnd(4 * n, seed=3).abs() + 0.5, rnd(4 * n, seed=4) * 0.1, rnd(4 * n, seed=5).abs() * 0.3
+    outs = []
+    for k in range(4):
+        o = F.conv2d(x, w[k].unsqueeze(1), None, stride, dil[k], dil[k], n)
+        outs.append(o if k == 0 else o + outs[-1])
+    ref = torch.cat(outs, 1)
+    ref = F.prelu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha)
+    got = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, stride, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV)))
+    close(got, ref)
+    raw = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, stride)       # no epilogue
+    close(raw, torch.cat(outs, 1))
+
+
+def test_eesp_dw_unsupported_dilation_raises():
+    from mspl_amd import ops
+    with pytest.raises(RuntimeError, match='unsupported dilation'):
+        ops.eesp_dw_hff(torch.zeros(1, 4, 8, 8, device=DEV), torch.zeros(4, 4, 3, 3, device=DEV), [1, 2, 4, 8], 1)
+
+
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, Cout, groups, H, W)
+    (2, 32, 24, 4, 16, 30), (1, 512, 512, 4, 16, 30), (2, 256, 64, 4, 9, 13), (1, 512, 16, 1, 16, 30),
+    (2, 96, 96, 4, 8, 12), (1, 16, 13, 1, 17, 23), (1, 48, 16, 1, 20, 20), (2, 16, 4, 4, 10, 10),
+    (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 1024, 64, 1, 4, 8)])
+def test_conv1x1_epilogues(cfg):
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, Cin, Cout, G, H, W = cfg
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin // G, 1, 1, seed=2, scale=(Cin // G) ** -0.5)
+    scale, shift, alpha = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4) * 0.1, rnd(Cout, seed=5).abs() * 0.3
+    res = rnd(N, Cout, H, W, seed=6)
+    base = F.conv2d(x, w, None, 1, 0, 1, G)
+    close(ops.conv1x1(x.to(DEV), w.to(DEV), G), base)
+    ref = F.prelu(base * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res, alpha)
+    got = ops.conv1x1(x.to(DEV), w.to(DEV), G, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), residual=res.to(DEV)))
+    close(got, ref)
+    # reinforcement + channel-slice destination + gate + pre_add
+    ctot, coff = Cout + 5, 3
+    r = rnd(N, 3, H, W, seed=7)
+    rw = rnd(ctot, 3, seed=8)
+    gate = torch.sigmoid(rnd(N, ctot, seed=9))
+    pre = rnd(N, ctot, H, W, seed=10)
+    sc, sh, al = rnd(ctot, seed=11).abs() + 0.5, rnd(ctot, seed=12) * 0.1, rnd(ctot, seed=13).abs() * 0.3
+    dst = torch.full((N, ctot, H, W), -7.0, device=DEV)
+    ops.conv1x1(x.to(DEV), w.to(DEV), G, Epi(sc.to(DEV), sh.to(DEV), al.to(DEV), pre_add=pre.to(DEV), reinf_r=r.to(DEV),
+                                             reinf_w=rw.to(DEV), gate=gate.to(DEV)), out=(dst, coff))
+    s = slice(coff, coff + Cout)
+    v = (base + pre[:, s]) * sc[s].view(1, -1, 1, 1) + sh[s].view(1, -1, 1, 1)
+    v = v + torch.einsum('cj,njhw->nchw', rw[s], r)
+    v = F.prelu(v, al[s]) * gate[:, s, None, None]
+    close(dst[:, s], v)
+    assert torch.all(dst[:, :coff] == -7.0) and torch.all(dst[:, coff + Cout:] == -7.0)
+
+
+@pytest.mark.parametrize('cfg', [
+    # (N, Cin, Cout, groups, H, W, stride, shuffle_groups)
+    (2, 3, 32, 1, 32, 48, 2, 0), (1, 3, 3, 1, 9, 15, 1, 0), (2, 16, 16, 16, 17, 29, 1, 0), (1, 80, 16, 16, 16, 30, 1, 5),
+    (1, 128, 48, 16, 12, 20, 1, 0), (1, 256, 64, 64, 8, 15, 1, 0), (1, 4, 4, 4, 256, 480, 1, 0), (1, 3, 32, 1, 31, 45, 2, 0),
+    (1, 20, 4, 4, 5, 5, 1, 5)])
+def test_conv3x3(cfg):
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, Cin, Cout, G, H, W, stride, sg = cfg
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin // G, 3, 3, seed=2, scale=0.2)
+    xin = x
+    if sg:
+        xin = x.view(N, sg, Cin // sg, H, W).transpose(1, 2).contiguous().view(N, Cin, H, W)
+    base = F.conv2d(xin, w, None, stride, 1, 1, G)
+    close(ops.conv3x3(x.to(DEV), w.to(DEV), G, stride, sg), base)
+    scale, shift, alpha = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4) * 0.1, rnd(Cout, seed=5).abs() * 0.3
+    gate = torch.sigmoid(rnd(N, Cout, seed=6))
+    ref = F.prelu(base * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha) * gate[:, :, None, None]
+    got = ops.conv3x3(x.to(DEV), w.to(DEV), G, stride, sg, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), gate=gate.to(DEV)))
+    close(got, ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 16, 30), (1, 3, 15, 21), (1, 2, 1, 1), (1, 3, 256, 480), (2, 7, 9, 10)])
+def test_avgpool3x3s2(shape):
+    from mspl_amd import ops
+    x = rnd(*shape, seed=1)
+    close(ops.avgpool3x3s2(x.to(DEV)), F.avg_pool2d(x, 3, 2, 1))
+
+
+@pytest.mark.parametrize('cfg', [((2, 4, 16, 30), (32, 60)), ((1, 3, 5, 5), (16, 30)), ((1, 2, 8, 15), (24, 45)),
+                                 ((1, 5, 13, 24), (128, 240)), ((2, 3, 7, 9), (7, 9)), ((1, 2, 1, 1), (4, 6)),
+                                 ((1, 2, 64, 120), (256, 480))])
+def test_bilinear_align_corners(cfg):
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    shape, size = cfg
+    x = rnd(*shape, seed=1)
+    ref = F.interpolate(x, size, mode='bilinear', align_corners=True)
+    close(ops.bilinear(x.to(DEV), size), ref, atol=1e-5)
+    C = shape[1]
+    pre = rnd(shape[0], C, *size, seed=2)
+    scale, shift, alpha = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4) * 0.1, rnd(C, seed=5).abs() * 0.3
+    got = ops.bilinear(x.to(DEV), size, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), pre_add=pre.to(DEV)))
+    close(got, F.prelu((ref + pre) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha))
+
+
+@pytest.mark.parametrize('cfg', [((2, 4, 32, 60), (16, 30)), ((1, 3, 24, 45), (16, 30)), ((1, 2, 16, 30), (5, 5)),
+                                 ((1, 2, 6, 9), (5, 5)), ((1, 3, 128, 240), (13, 24)), ((1, 2, 5, 7), (5, 7)),
+                                 ((1, 2, 192, 360), (128, 240))])
+def test_adaptive_avgpool(cfg):
+    from mspl_amd import ops
+    shape, size = cfg
+    x = rnd(*shape, seed=1)
+    close(ops.adaptive_avgpool(x.to(DEV), size), F.adaptive_avg_pool2d(x, size))
+
+
+def test_pointwise_and_gap_gate():
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    for shape in [(2, 6, 16, 30), (1, 5, 7, 9)]:
+        x = rnd(*shape, seed=1)
+        C = shape[1]
+        scale, shift, alpha = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4) * 0.1, rnd(C, seed=5).abs() * 0.3
+        got = ops.pointwise(x.to(DEV), Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV)))
+        close(got, F.prelu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha))
+        w = rnd(9, C, 1, 1, seed=6)
+        ref = torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(x, 1), w)).flatten(1)
+        close(ops.gap_gate(x.to(DEV), w.to(DEV)), ref, atol=1e-6)
+
+
+def test_label_epilogue_fused_upsample_vs_unfused():
+    """Fused (low-res in) label epilogue == the reference order: upsample both heads, then combine."""
+    from mspl_amd import ops
+    N, C, H, W = 2, 13, 64, 96
+    main = rnd(N, C, H // 2, W // 2, seed=1, scale=2.0)
+    aux = rnd(N, C, H // 4, W // 4, seed=2, scale=2.0)
+    mu = F.interpolate(main, (H, W), mode='bilinear', align_corners=True)
+    au = F.interpolate(aux, (H, W), mode='bilinear', align_corners=True)
+    r = ops.label_epilogue(main.to(DEV), aux.to(DEV), (H, W), want_prob=True, want_kld=True, want_logits=True)
+    close(r['main_up'], mu, atol=1e-5)
+    close(r['aux_up'], au, atol=1e-5)
+    p1, lp1, lp2 = F.softmax(mu, 1), F.log_softmax(mu, 1), F.log_softmax(au, 1)
+    close(r['kld'], (p1 * lp1 - p1 * lp2).sum(1), atol=2e-5, rtol=1e-3)
+    prob = F.softmax(mu + 0.5 * au, 1)
+    close(r['prob'], prob, atol=1e-6)
+    ref = np.argmax(prob.numpy().transpose(0, 2, 3, 1), axis=3).astype(np.uint8)
+    srt = torch.sort(prob, 1, descending=True)[0]
+    sure = (srt[:, 0] - srt[:, 1]).numpy() > 1e-5
+    assert np.array_equal(r['labels'].cpu().numpy()[sure], ref[sure])
+
+
+def test_bad_arguments_raise():
+    from mspl_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ops.avgpool3x3s2(torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match='float32'):
+        ops.avgpool3x3s2(torch.zeros(1, 1, 4, 4, device=DEV, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match='does not match'):
+        ops.conv1x1(torch.zeros(1, 8, 4, 4, device=DEV), torch.zeros(4, 3, 1, 1, device=DEV), 1)

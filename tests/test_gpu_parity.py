@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors produced by the reference and
+against the CPU oracle on the same seeded inputs.  Needs a real MI355X: run with `-m gpu`.
+
+Tolerances: logits within 1e-3 absolute (BASELINE.json north_star) -- tested much tighter (2e-4) --;
+integer label work (LUT, merge, histogram) bit-exact; argmax equal wherever the reference's own top-2
+probability margin exceeds rounding level.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels as olab
+from oracle import net as onet
+from tests.cases import LAYER_CASES, MODEL_CASES
+from tests.conftest import GOLDEN
+from tests.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+DEV = 'cuda'
+LOGIT_ATOL = 2e-4
+
+
+def _args(s):
+    return argparse.Namespace(s=s, channels=3, num_classes=1000)
+
+
+def _build_layer(kind, kw):
+    from mspl_amd import layers as L
+    cls = {'eesp': L.EESP, 'down': L.DownSampler, 'pyr': L.EfficientPyrPool, 'pw': L.EfficientPWConv}[kind]
+    return cls(**kw)
+
+
+def _build_model(kind, s, classes, dataset):
+    from mspl_amd import models as M
+    if kind == 'espdnetue':
+        return M.ESPDNetwithUncertaintyEstimation(_args(s), classes=classes, dataset=dataset, fix_pyr_plane_proj=True)
+    return M.ESPNetv2Segmentation(_args(s), classes=classes, dataset=dataset)
+
+
+def test_native_library_is_loaded():
+    import mspl_amd
+    from mspl_amd import _native
+    assert os.path.isfile(_native.LIB_PATH)
+    with open('/proc/self/maps') as f:
+        assert 'libmspl_hip.so' in f.read()
+
+
+@pytest.mark.parametrize('name', sorted(LAYER_CASES))
+def test_layer_vs_reference_golden(name, golden):
+    kind, kw, shp, shp2 = LAYER_CASES[name]
+    i = sorted(LAYER_CASES).index(name)
+    m = _build_layer(kind, kw)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 100 + i))
+    m = m.to(DEV).eval()
+    x = synth_input(shp, 200 + i).to(DEV)
+    with torch.no_grad():
+        y = m(x, synth_input(shp2, 300 + i).to(DEV)) if shp2 is not None else m(x)
+    ref = torch.from_numpy(golden('layers')[name])
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('name', sorted(MODEL_CASES))
+def test_model_vs_reference_golden(name, golden):
+    kind, s, classes, dataset, shp, sd_seed, in_seed = MODEL_CASES[name]
+    m = _build_model(kind, s, classes, dataset)
+    m.load_state_dict(synth_state_dict(KEYS['%s_s%s_c%d' % (kind, s, classes)], sd_seed))
+    m = m.to(DEV).eval()
+    x = synth_input(shp, in_seed).to(DEV)
+    g = golden('model_' + name)
+    st = int(g['stride'])
+    from mspl_amd import ops
+    with torch.no_grad():
+        if kind == 'espdnetue':
+            main, aux = m(x)
+            torch.testing.assert_close(main[:, :, ::st, ::st].cpu(), torch.from_numpy(g['main']), rtol=1e-4, atol=LOGIT_ATOL)
+            torch.testing.assert_close(aux[:, :, ::st, ::st].cpu(), torch.from_numpy(g['aux']), rtol=1e-4, atol=LOGIT_ATOL)
+            lo_main, lo_aux = m.forward_lowres(x)
+            r = ops.label_epilogue(lo_main, lo_aux, shp[2:], want_kld=True, want_prob=True)
+            torch.testing.assert_close(r['kld'][:, ::st, ::st].cpu(), torch.from_numpy(g['kld']), rtol=2e-3, atol=2e-4)
+            amax = r['labels'].cpu().numpy()
+            diff = amax != g['amax']
+            assert not np.any(diff & (g['margin'].astype(np.float32) > 1e-3)), 'argmax differs at a confident pixel'
+            assert diff.mean() < 2e-3
+            # the fused kernel's own argmax is consistent with its own probabilities (first max)
+            p = r['prob'].cpu().numpy()
+            assert np.array_equal(np.argmax(p, axis=1).astype(np.uint8)[~diff], amax[~diff])
+        else:
+            y = m(x)
+            torch.testing.assert_close(y[:, :, ::st, ::st].cpu(), torch.from_numpy(g['main']), rtol=1e-4, atol=LOGIT_ATOL)
+
+
+def test_zoo_real_weights_config1(golden):
+    """BASELINE config 1: ESPNetv2 s=0.5 with the real Cityscapes checkpoint on 288x480 inputs."""
+    zoo = np.load(os.path.join(GOLDEN, 'zoo_espnetv2_s0.5_city_512x256.npz'))
+    m = _build_model('espnetv2', 0.5, 20, 'city')
+    m.load_state_dict({k: torch.from_numpy(zoo[k]) for k in zoo.files}, strict=True)
+    m = m.to(DEV).eval()
+    x = synth_input((2, 3, 288, 480), 40).to(DEV)
+    g = golden('model_v2_zoo_288x480')
+    with torch.no_grad():
+        y = m(x)
+    torch.testing.assert_close(y[:, :, ::8, ::8].cpu(), torch.from_numpy(g['main']), rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(y.double().sum((0, 2, 3)).cpu().numpy(), g['class_sum'], rtol=2e-4)
+    amax = y.argmax(1).to(torch.uint8).cpu().numpy()
+    diff = amax != g['amax']
+    assert not np.any(diff & (g['margin'].astype(np.float32) > 2e-3))
+    assert diff.mean() < 1e-3
+
+
+@pytest.mark.parametrize('S', [1, 2, 3, 4])
+@pytest.mark.parametrize('pol', ['all', 'half', 'none'])
+def test_merge_truth_table_bit_exact(S, pol, golden):
+    from mspl_amd import uest
+    g = golden('labels')
+    got = uest.merge_outputs(g['tt_in_S%d' % S], 5, None if pol == 'none' else pol)
+    assert got.dtype == np.int64
+    np.testing.assert_array_equal(got.astype(np.uint8), g['tt_S%d_%s' % (S, pol)])
+
+
+def test_merge_random_maps_and_histogram(golden):
+    from mspl_amd import ops, uest
+    g = golden('labels')
+    np.testing.assert_array_equal(uest.merge_outputs(g['rnd_in'], 5, 'all'), g['rnd_all'])
+    np.testing.assert_array_equal(uest.merge_outputs(g['rnd_in'], 5, 'half'), g['rnd_half'])
+    # ragged sizes (tails of the 16-pixel vector path), unaligned views, histogram
+    rng = np.random.RandomState(3)
+    for npix in (1, 15, 16, 17, 4099, 256 * 480 * 3 + 5):
+        src = rng.randint(0, 5, size=(3, npix)).astype(np.uint8)
+        t = torch.from_numpy(src).to(DEV)
+        hist = torch.zeros(5, dtype=torch.int64, device=DEV)
+        out = ops.merge_labels([t[0], t[1], t[2]], 5, 2, 4, hist).cpu().numpy()
+        ref = olab.merge_outputs(src, 5, 'half')
+        np.testing.assert_array_equal(out, ref)
+        np.testing.assert_array_equal(hist.cpu().numpy(), olab.class_histogram(ref).astype(np.int64))
+    # labels outside the class range (e.g. 255) never win a vote
+    src = np.array([[255, 1, 0], [255, 1, 3], [2, 7, 3]], dtype=np.uint8)
+    out = uest.merge_outputs(src, 5, 'half')
+    np.testing.assert_array_equal(out, olab.merge_outputs(src, 5, 'half'))
+    # empty input
+    assert uest.merge_outputs(np.zeros((3, 0), dtype=np.uint8), 5, 'all').shape == (0,)
+
+
+@pytest.mark.parametrize('C', [5, 13, 20])
+def test_uncertainty_estimator_vs_reference(C, golden):
+    """get_output's softmax + PixelwiseKLD on full-resolution logits (identity upsample)."""
+    from mspl_amd import ops
+    g = golden('labels')
+    d1 = (synth_input((2, C, 12, 20), 50 + C) * 3).to(DEV)
+    d2 = (synth_input((2, C, 12, 20), 70 + C) * 3).to(DEV)
+    r = ops.label_epilogue(d1, d2, (12, 20), want_prob=True, want_kld=True, want_logits=True)
+    torch.testing.assert_close(r['kld'].cpu(), torch.from_numpy(g['kld_C%d' % C]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r['prob'].cpu(), torch.from_numpy(g['prob_C%d' % C]), rtol=1e-4, atol=1e-6)
+    assert torch.equal(r['main_up'], d1) and torch.equal(r['aux_up'], d2)      # same-size bilinear is the identity
+    ref = np.argmax(g['prob_C%d' % C].transpose(0, 2, 3, 1), axis=3).astype(np.uint8)
+    np.testing.assert_array_equal(r['labels'].cpu().numpy(), ref)
+
+
+def test_argmax_first_max_tie_rule_and_lut():
+    from mspl_amd import ops
+    main = torch.zeros((1, 13, 4, 8), device=DEV)
+    main[0, 5, :, :4] = 1.0
+    main[0, 9, :, :4] = 1.0           # tie between 5 and 9 -> 5 ; all-zero pixels -> class 0
+    lut = torch.from_numpy(olab.ID_CAMVID_TO_GREENHOUSE.astype(np.uint8)).to(DEV)
+    r = ops.label_epilogue(main, None, (4, 8), lut=lut)
+    exp = np.zeros((1, 4, 8), dtype=np.uint8)
+    exp[..., :4] = olab.ID_CAMVID_TO_GREENHOUSE[5]
+    exp[..., 4:] = olab.ID_CAMVID_TO_GREENHOUSE[0]
+    np.testing.assert_array_equal(r['labels'].cpu().numpy(), exp)
+
+
+def test_pseudo_label_pass_three_sources_vs_oracle():
+    """BASELINE config 3 (small shape): CamVid(13)+Cityscapes(20)+Forest(5) models -> LUT -> merge -> histogram."""
+    from mspl_amd import uest
+    x = synth_input((2, 3, 64, 96), 9)
+    specs = [(13, 'camvid', 'camvid'), (20, 'city', 'cityscapes'), (5, 'forest', 'forest')]
+    nets, sds = [], []
+    for i, (C, ds, _) in enumerate(specs):
+        m = _build_model('espdnetue', 2.0, C, ds)
+        sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % C], 60 + i)
+        m.load_state_dict(sd)
+        nets.append(m)
+        sds.append(sd)
+    for policy in ('all', 'half'):
+        for use_graph in (False, True):
+            p = uest.PseudoLabelPass(nets, [s[2] for s in specs], merge_label_policy=policy, device=DEV,
+                                     use_graph=use_graph)
+            merged = p(x).clone().cpu().numpy()
+            maps = [t.cpu().numpy() for t in p.source_maps(x)]
+            p.reset()
+            merged2 = p(x).clone().cpu().numpy()          # graph replay gives the same answer
+            np.testing.assert_array_equal(merged, merged2)
+            hist = p.hist.cpu().numpy()
+            with torch.no_grad():
+                for (C, ds, od), sd, got in zip(specs, sds, maps):
+                    main, aux = onet.espdnet_ue_forward(sd, x)
+                    prob, _ = olab.get_output(main, aux)
+                    ref = olab.to_greenhouse(olab.argmax_labels(prob), od)
+                    assert (got == ref).mean() > 0.999
+            ref_merged = olab.merge_outputs(np.stack(maps), 5, policy)          # integer stage: bit-exact
+            np.testing.assert_array_equal(merged, ref_merged.astype(np.uint8))
+            np.testing.assert_array_equal(hist, olab.class_histogram(ref_merged).astype(np.int64))
+
+
+def test_get_output_dropin_signature():
+    from mspl_amd import uest
+    m = _build_model('espdnetue', 2.0, 5, 'greenhouse')
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c5'], 70)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = synth_input((2, 3, 32, 48), 7)
+    out, kld = uest.get_output(m, x, device=DEV)
+    assert out.shape == (5, 32, 48) and kld.shape == (32, 48)            # batch element 0 only, like the reference
+    with torch.no_grad():
+        main, aux = onet.espdnet_ue_forward(sd, x)
+        prob, k = olab.get_output(main, aux)
+    np.testing.assert_allclose(out, prob[0].numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(kld, k[0].numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_input_not_multiple_of_16_raises_like_reference():
+    m = _build_model('espdnetue', 2.0, 5, 'greenhouse').to(DEV).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='must match'):
+        m(torch.randn(1, 3, 360, 480, device=DEV))

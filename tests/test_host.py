@@ -1,0 +1,158 @@
+"""CPU-side checks of the product's host logic: C-ABI symbols, state-dict parity with the reference,
+checkpoint-loader quirks, drop-in aliases, and loud failure without a GPU.  No kernel is launched."""
+import argparse
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mspl_amd
+from mspl_amd import _native, layers, models, uest
+from tests.cases import LAYER_CASES
+from tests.conftest import GOLDEN, ROOT
+
+KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+LAYER_KEYS = json.load(open(os.path.join(GOLDEN, 'layer_keys.json')))
+
+
+def _args(s):
+    return argparse.Namespace(s=s, channels=3, num_classes=1000)
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, 'include', 'mspl_hip.h')).read()
+    declared = set(re.findall(r'\b(mspl_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'mspl_status'}
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'include/mspl_hip.h declares %s but the library does not export it' % name
+    # and the Python binding table covers every compute entry point
+    assert set(_native.SIGNATURES) == declared - {'mspl_version', 'mspl_last_error'}
+    assert 'gfx950' in _native.version()
+
+
+@pytest.mark.parametrize('cfg', sorted(KEYS))
+def test_model_state_dict_matches_reference(cfg):
+    kind, s, c = re.match(r'(\w+)_s([\d.]+)_c(\d+)', cfg).groups()
+    s, c = float(s), int(c)
+    ds = {13: 'camvid', 5: 'greenhouse', 20: 'city'}[c]
+    if kind == 'espdnetue':
+        m = models.ESPDNetwithUncertaintyEstimation(_args(s), classes=c, dataset=ds, fix_pyr_plane_proj=True)
+    else:
+        m = models.ESPNetv2Segmentation(_args(s), classes=c, dataset=ds)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == KEYS[cfg]
+
+
+@pytest.mark.parametrize('name', sorted(LAYER_CASES))
+def test_layer_state_dict_matches_reference(name):
+    kind, kw, _, _ = LAYER_CASES[name]
+    cls = {'eesp': layers.EESP, 'down': layers.DownSampler, 'pyr': layers.EfficientPyrPool,
+           'pw': layers.EfficientPWConv}[kind]
+    got = {k: list(v.shape) for k, v in cls(**kw).state_dict().items()}
+    assert got == LAYER_KEYS[name]
+
+
+def test_eesp_dilations():
+    assert layers.eesp_dilations(13) == [1, 2, 3, 4]
+    assert layers.eesp_dilations(9) == [1, 2, 3, 4]
+    assert layers.eesp_dilations(7) == [1, 1, 2, 3]
+    assert layers.eesp_dilations(5) == [1, 1, 1, 2]
+
+
+def test_param_groups_and_unused_parameters():
+    m = models.ESPDNetwithUncertaintyEstimation(_args(2.0), classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    assert sum(p.numel() for p in m.parameters()) == 2234230
+    assert len(list(m.parameters())) == 570
+    base = sum(p.numel() for p in m.get_basenet_params())
+    seg = sum(p.numel() for p in m.get_segment_params())
+    depth = sum(p.numel() for p in m.get_depth_encoder_params())
+    assert base == sum(p.numel() for p in m.base_net.parameters())
+    assert depth == sum(p.numel() for p in m.depth_base_net.parameters())
+    assert seg > 0
+
+
+def test_lossy_checkpoint_loader(tmp_path):
+    """espdnetue_seg2 refills depth_base_net from the file's base_net.* entries."""
+    a = _args(2.0)
+    src = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save(src.state_dict(), path)
+    a2 = argparse.Namespace(s=2.0, channels=3, num_classes=1000, classes=5, dataset='greenhouse', weights=path,
+                            trainable_fusion=True, dense_fuse=False)
+    m = models.espdnetue_seg2(a2, load_entire_weights=True, fix_pyr_plane_proj=True)
+    sd, ref = m.state_dict(), src.state_dict()
+    assert torch.equal(sd['base_net.level3.1.proj_1x1.conv.weight'], ref['base_net.level3.1.proj_1x1.conv.weight'])
+    # the depth slot now holds the RGB encoder's tensor, not what was saved in that slot
+    assert torch.equal(sd['depth_base_net.level3.1.proj_1x1.conv.weight'], ref['base_net.level3.1.proj_1x1.conv.weight'])
+    assert not torch.equal(sd['depth_base_net.level3.1.proj_1x1.conv.weight'],
+                           ref['depth_base_net.level3.1.proj_1x1.conv.weight'])
+    assert torch.allclose(sd['depth_base_net.level1.conv.weight'], ref['base_net.level1.conv.weight'].mean(1, keepdim=True))
+    assert torch.equal(sd['aux_decoder.stages.0.weight'], ref['aux_decoder.stages.0.weight'])
+
+
+def test_thresh_rule():
+    assert uest.resolve_thresh(3, None) == 2
+    assert uest.resolve_thresh(3, 'half') == 2
+    assert uest.resolve_thresh(3, 'all') == 3
+    assert uest.resolve_thresh(3, 'bogus') == 2
+    assert uest.resolve_thresh(3, 1) == 1
+    assert uest.resolve_thresh(3, 7) == 2
+    assert uest.resolve_thresh(2, None) == 2
+    assert uest.resolve_thresh(1, 'all') == 1
+
+
+def test_luts_match_reference_tables():
+    g = np.load(os.path.join(GOLDEN, 'labels.npz'))
+    np.testing.assert_array_equal(uest.id_camvid_to_greenhouse, g['lut_id_camvid_to_greenhouse'])
+    np.testing.assert_array_equal(uest.id_cityscapes_to_greenhouse, g['lut_id_cityscapes_to_greenhouse'])
+    np.testing.assert_array_equal(uest.id_forest_to_greenhouse, g['lut_id_forest_to_greenhouse'])
+
+
+def test_class_weights_rule():
+    w = uest.class_weights_from_histogram([10, 20, 30, 40, 0])
+    assert w[0] == 0.0 and abs(w[1] - 5.0) < 1e-6 and w[4] == pytest.approx(1e10)
+    assert np.array_equal(uest.class_weights_from_histogram([1, 2, 3], 'other'), np.ones(3))
+
+
+def test_dropin_aliases():
+    import sys
+    for n in [k for k in sys.modules if k.split('.')[0] in ('nn_layers', 'model', 'loss_fns', 'data_loader')]:
+        del sys.modules[n]
+    mspl_amd.install_dropin()
+    from nn_layers.eesp import EESP, DownSampler  # noqa: F401
+    from nn_layers.efficient_pyramid_pool import EfficientPyrPool  # noqa: F401
+    from model.segmentation.espdnet_ue import espdnetue_seg2  # noqa: F401
+    from data_loader.segmentation.greenhouse import id_camvid_to_greenhouse  # noqa: F401
+    assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'mspl_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+                assert 'oracle.' not in src.replace('the oracle', ''), f
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only behaviour')
+def test_cpu_tensors_fail_loudly():
+    m = layers.EESP(32, 32, stride=1, k=4, r_lim=9).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='no CPU path'):
+        m(torch.randn(1, 32, 8, 8))
+
+
+def test_training_mode_bn_fails_loudly():
+    m = layers.CBR(3, 8, 3, 2)   # fresh modules are in training mode
+    with torch.no_grad(), pytest.raises(RuntimeError, match='training mode'):
+        m(torch.randn(1, 3, 8, 8))
