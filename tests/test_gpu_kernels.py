@@ -50,7 +50,7 @@ def test_eesp_dw_unsupported_dilation_raises():
     # (N, Cin, Cout, groups, H, W)
     (2, 32, 24, 4, 16, 30), (1, 512, 512, 4, 16, 30), (2, 256, 64, 4, 9, 13), (1, 512, 16, 1, 16, 30),
     (2, 96, 96, 4, 8, 12), (1, 16, 13, 1, 17, 23), (1, 48, 16, 1, 20, 20), (2, 16, 4, 4, 10, 10),
-    (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 1024, 64, 1, 4, 8)])
+    (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 512, 64, 1, 4, 8)])
 def test_conv1x1_epilogues(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
@@ -176,6 +176,8 @@ def test_label_epilogue_fused_upsample_vs_unfused():
 
 def test_bad_arguments_raise():
     from mspl_amd import ops
+    with pytest.raises(RuntimeError, match='exceeds the LDS weight tile'):     # K per group > ~700 is not on the path
+        ops.conv1x1(torch.zeros(1, 1024, 4, 8, device=DEV), torch.zeros(64, 1024, 1, 1, device=DEV), 1)
     with pytest.raises(RuntimeError, match='no CPU path'):
         ops.avgpool3x3s2(torch.zeros(1, 1, 4, 4))
     with pytest.raises(RuntimeError, match='float32'):
