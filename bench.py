@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the pseudo-label hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): ESPDNet-UE s=2.0, 13 classes, single-source pseudo-label generation
+(forward -> pred+0.5*aux -> argmax + KL uncertainty map -> class histogram), batch 16 of synthetic
+CamVid-shaped inputs.  "480x360" images are resized to the script's --crop-size before the network exactly
+as the reference's loaders do: the network input is 16x3x288x480 fp32.
+One step = one batch through the whole path; inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel = eesp_dw_hff (K2): algorithmic bytes per launch / mean launch time,
+               measured with HIP events on the launch stream inside this process.
+  cpu_baseline the CPU oracle (oracle/, a port of the reference's torch path) timed on the host cores on a
+               bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 16
+H, W = 288, 480
+CLASSES = 13
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def k2_algorithmic_bytes(model, n_img, h, w):
+    """Sum over the EESP blocks the forward executes of 4*n*(H*W + 4*Ho*Wo) bytes per image."""
+    from mspl_amd.layers import EESP
+    total, launches = 0, 0
+    # walk the encoder exactly as _encode does: resolution after level1 is h/2
+    b, d = model.base_net, getattr(model, 'depth_base_net', None)
+    seq = [(b.level2_0.eesp, 2), (b.level3_0.eesp, 4), (b.level3[0], 8)]
+    tail = d.level3 if d is not None else b.level3
+    seq += [(tail[i], 8) for i in range(1, len(b.level3))]
+    seq += [(b.level4_0.eesp, 8)] + [(m, 16) for m in b.level4]
+    for m, div in seq:
+        assert isinstance(m, EESP)
+        n = m.proj_1x1.conv.out_channels
+        hi, wi = h // div, w // div
+        ho, wo = (hi - 1) // m.stride + 1, (wi - 1) // m.stride + 1
+        total += 4 * n * (hi * wi + 4 * ho * wo)
+        launches += 1
+    return total * n_img, launches
+
+
+def cpu_baseline(sd, shape, seconds_budget=20.0):
+    """Oracle (CPU port) on the host cores: forward + softmax/KLD + argmax + histogram, bounded sample."""
+    import numpy as np
+    import torch
+    from oracle import labels as olab, net as onet
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only oversubscribe)
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    nb = 4
+    x = torch.randn((nb,) + tuple(shape[1:]))
+    sd = {k: v.cpu() for k, v in sd.items()}
+
+    def one():
+        with torch.no_grad():
+            main, aux = onet.espdnet_ue_forward(sd, x)
+            prob, kld = olab.get_output(main, aux)
+            lab = olab.argmax_labels(prob)
+            return olab.class_histogram(lab)
+    one()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += nb
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 64:
+            break
+    return {'value': round(n / el, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d images (batches of %d, %dx%d), torch-CPU oracle, %d threads' % (n, nb, shape[2], shape[3], cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL; used for barrier + timing only
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import mspl_amd
+    from mspl_amd import models, ops, uest
+    from tests.synth import synth_state_dict
+
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    model = models.ESPDNetwithUncertaintyEstimation(a, classes=CLASSES, dataset='camvid', fix_pyr_plane_proj=True)
+    sd = synth_state_dict(model.state_dict(), 0)          # random-init weights of the named architecture
+    model.load_state_dict(sd)
+    shape = (BATCH, 3, H, W)
+    g = torch.Generator().manual_seed(1234 + rank)        # every rank labels its own shard of the image list
+    x = torch.randn(shape, generator=g).to(dev)
+
+    lp = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=not args.no_graph)
+    lp(x)                                                  # builds caches / captures the graph
+    xin = lp.static_input(shape)
+    if xin is not None:
+        xin.copy_(x)
+        x = xin
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lp(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (K2), HIP events on the launch stream, same K steps (eager so that
+    # every launch can be bracketed)
+    k2_events = []
+    real = ops.eesp_dw_hff
+
+    def timed_k2(*a_, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real(*a_, **kw)
+        e1.record()
+        k2_events.append((e0, e1))
+        return r
+    eager = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=False)
+    from mspl_amd import layers as L
+    L.ops.eesp_dw_hff = timed_k2
+    try:
+        for _ in range(min(args.steps, 20)):
+            eager(x)
+        torch.cuda.synchronize()
+    finally:
+        L.ops.eesp_dw_hff = real
+    k2_ms = [e0.elapsed_time(e1) for e0, e1 in k2_events]
+    k2_bytes, k2_launches = k2_algorithmic_bytes(model, BATCH, H, W)
+    avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
+    achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec pseudo-label gen, ESPDNet-UE s=2.0 480x360(->288x480) bs=16',
+            'value': round(BATCH * world * args.steps / elapsed, 2),
+            'unit': 'images/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ESPDNet-UE s=2.0 C=13 single-source pseudo-label gen '
+                                   '(forward + pred+0.5aux argmax + KL uncertainty + histogram), bs=16/GPU, '
+                                   '16x3x288x480 fp32, hipGraph replay' + (' off' if args.no_graph else ''),
+                       'per_gpu_batch': BATCH, 'input': [BATCH, 3, H, W], 'classes': CLASSES,
+                       'sharding': 'image list sharded by rank, no data-path collective'},
+            'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff_kernel (K2, %d launches/forward)' % k2_launches,
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'algorithmic_bytes_per_launch': int(k2_bytes / k2_launches),
+                         'avg_launch_us': round(avg_launch_s * 1e6, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sd, shape)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

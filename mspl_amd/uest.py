@@ -148,3 +148,61 @@ class PseudoLabelPass:
 
     def class_weights(self, policy='normal'):
         return torch.from_numpy(class_weights_from_histogram(self.hist.cpu().numpy(), policy)).float().to(self.device)
+
+
+class SelfLabelPass:
+    """Batched single-model relabelling (the loop body of generate_pseudo_label, uest_seg_multi_os.py:730-830):
+    forward -> pred + 0.5*aux -> argmax -> class histogram, plus the KL(pred||aux) uncertainty map that
+    get_output computes (:691) -- kept on the device for the uncertainty-weighted loss instead of being
+    copied to the host and dropped.  __call__(images) -> (labels uint8 (N,H,W), kld fp32 (N,H,W))."""
+
+    def __init__(self, model, classes=GREENHOUSE_CLASSES, device='cuda', use_graph=False, with_kld=True):
+        self.model = model.to(device).eval()
+        self.classes = classes
+        self.device = torch.device(device)
+        self.hist = torch.zeros(classes, dtype=torch.int64, device=self.device)
+        self.use_graph = use_graph
+        self.with_kld = with_kld
+        self._graphs = {}
+
+    def reset(self):
+        self.hist.zero_()
+
+    def _run(self, images):
+        main, aux = _lowres(self.model, images)
+        r = ops.label_epilogue(main, aux, images.shape[2:], want_kld=self.with_kld)
+        # S = 1, threshold 1: the merge kernel is the identity on labels and accumulates the histogram
+        labels = ops.merge_labels([r['labels']], self.classes, 1, NO_AGREEMENT_CLASS, self.hist)
+        return labels, r.get('kld')
+
+    def __call__(self, images):
+        with torch.no_grad():
+            images = images.to(self.device)
+            if not self.use_graph:
+                return self._run(images)
+            key = tuple(images.shape)
+            g = self._graphs.get(key)
+            if g is None:
+                static_in = images.clone()
+                hist_before = self.hist.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._run(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                self.hist.copy_(hist_before)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._run(static_in)
+                self.hist.copy_(hist_before)
+                g = self._graphs[key] = (graph, static_in, static_out)
+            graph, static_in, static_out = g
+            if static_in.data_ptr() != images.data_ptr():
+                static_in.copy_(images)
+            graph.replay()
+            return static_out
+
+    def static_input(self, shape):
+        """The graph's own input buffer for `shape` (write batches straight into it to skip the copy)."""
+        g = self._graphs.get(tuple(shape))
+        return None if g is None else g[1]
