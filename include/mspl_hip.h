@@ -125,6 +125,22 @@ int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t HW, const m
 int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
                       int32_t HW, float* mean_ws, float* gate, void* stream);
 
+/* K6  fused EfficientPyrPool body: all branches + merge_layer.0 (BN+PReLU) + Shuffle + merge_layer.2 (grouped
+ *     3x3 + BN + PReLU) in one pass over the projected tensor.  Replaces nn_layers/efficient_pyramid_pool.py:39-58
+ *     (everything between projection_layer and the final 1x1) and cnn_utils.py:119-125.
+ *     x: (N,P,h,w) projection output.  Branch i works on an hs[i] x ws[i] grid:
+ *       hs>h : bilinear_up -> depthwise 3x3 (stage_w[i], (P,1,3,3)) -> adaptive_avg_pool, all inside the kernel;
+ *       hs==h: depthwise 3x3 (stage_w[i]);
+ *       hs<h : down_e[i] = (N,P,hs,ws) = dw3x3(adaptive_avg_pool(x)) computed beforehand; up-sampled here.
+ *     br_scale/shift/alpha: nb*P folded merge_layer.0 constants (branch-major, like torch.cat);
+ *     merge_w: (P, nb, 3, 3) = merge_layer.2 conv weight; ep: merge_layer.2's BN+PReLU; out: (N,P,h,w) slice.
+ */
+int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
+                           const int32_t* hs, const int32_t* ws, const float* const* stage_w,
+                           const float* const* down_e, const float* br_scale, const float* br_shift,
+                           const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
+                           float* out, void* stream);
+
 /* K8+K9  label epilogue: bilinear(align_corners) upsample of both heads to (H,W), o = main + 0.5*aux,
  *     class = first-max argmax_c o (== np.argmax of softmax2d(o) up to exp() rounding ties), optional
  *     id LUT, optional softmax probabilities and KL(main||aux) map.

@@ -37,6 +37,9 @@ SIGNATURES = {
     'mspl_adaptive_avgpool_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_pointwise_fwd': [c_f32p, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_gap_gate_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_pyrpool_fused_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f32p, c_f32p, c_f32p,
+                               c_f32p, _EP, c_f32p, ctypes.c_void_p],
     'mspl_label_epilogue_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                 ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,

@@ -4,16 +4,20 @@
 // DownSampler reinforcement / EESP residual, PReLU: nn_layers/eesp.py:36,55,67,77-93,117-120,142;
 // nn_layers/efficient_pyramid_pool.py:22,31; nn_layers/espnet_utils.py:8-37,62-89.
 //
-// Per (image, group) this is C[M x P] = Wg[M x K] . X[K x P] with P = H*W contiguous in NCHW.
+// Per group this is C[M x P] = Wg[M x K] . X[K x P]; pixels P are contiguous in NCHW.
 //
-// K >= 16: fp32 matrix cores.  v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain) at the
-//   vector-FMA rate, takes one VGPR per operand and leaves the VALU free for the epilogue.  A wave owns a
-//   32-pixel tile and MCW 32-row chunks of M.  The B operand X[k][p..p+31] is loaded straight from HBM
-//   (two coalesced 128-byte rows per wave-instruction) in software-pipelined groups of 16 k-steps; the A
-//   operand (weights) and the per-row epilogue constants sit in LDS (odd row stride: conflict-free
-//   ds_read_b32).  Every input element is fetched from HBM once per workgroup; stores are 128-byte rows.
-// K < 16: the matrix tile would be mostly padding, so a VALU kernel streams 4 pixels per lane with
-//   16-byte loads/stores and LDS-broadcast weights.
+// K >= 16, HW % 4 == 0 (the path's shapes): fp32 matrix cores, 16-byte memory ops.
+//   v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain) at the vector-FMA rate, takes one VGPR
+//   per operand and leaves the VALU free for the epilogue.  A wave owns 128 consecutive pixels of the
+//   flattened (image, pixel) axis and MCW 32-row chunks of M.  Lane (half, li) loads ONE float4
+//   X[k+half][4*li .. 4*li+3] per k-step and uses its four components as the B operand of four MFMAs
+//   (pixel sub-tile s = pixels 4*li+s), so every HBM access is 16 bytes per lane and the accumulators of a
+//   row come out as 4 consecutive pixels = one float4 store.  Weights (A operand) and per-row epilogue
+//   constants are staged once per workgroup in LDS (odd row stride: conflict-free ds_read_b32).
+// K >= 16 otherwise: same structure with one pixel per lane (4-byte accesses).
+// K < 16: the matrix tile would be mostly padding; a VALU kernel streams 4 pixels per lane.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -28,151 +32,221 @@ struct PwGeom {
     int mc_total;  // 32-row chunks inside one workgroup's MB
     int WM;        // waves along M (1,2,4); WP = 4 / WM waves along pixels
     int TPW;       // pixel tiles per wave (sequential)
-    int ptiles;    // ceil(HW / 32)
+    int ptiles;    // pixel tiles (32 px per image, or 128 px of the flattened batch for the float4 kernel)
     int pgroups;   // ceil(ptiles / (WP * TPW))
+    int vecw;      // 16-byte aligned weights: stage with float4 loads
 };
 
-// Per-row epilogue constants staged in LDS (one ds_read per row instead of six global loads).
-struct RowEpi { float scale, shift, alpha, rw0, rw1, rw2; };
+// Per-row epilogue constants staged in LDS as six arrays of MB floats (scale, shift, alpha, rw0, rw1, rw2), so
+// the four consecutive rows a lane owns per accumulator quad are one ds_read_b128 per constant.
+constexpr int ROWC = 6;
 
-template <int MCW>
-__global__ __launch_bounds__(256, (MCW == 1 ? 4 : (MCW == 2 ? 3 : 2))) void conv1x1_mfma_kernel(const float* __restrict__ x,
+// Stage rows [m0, m0+MB) of one group's weights into At[MB][KS] (zero padded to K32 columns) and the rows'
+// epilogue constants into rowc.  Loads are independent and unrolled so that they overlap.
+__device__ __forceinline__ void stage_weights(float* At, float* rowc, const float* __restrict__ wg,
+                                              const PwGeom& g, const Epi& e, int m0, int cbase, int tid) {
+    const int K32 = (g.K + 31) & ~31;
+    if (g.vecw) {
+        const int kv = K32 >> 2;
+        const int total = g.MB * kv;
+#pragma unroll 4
+        for (int i = tid; i < total; i += 256) {
+            const int m = i / kv, k = (i - m * kv) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + m < g.M && k < g.K) v = *reinterpret_cast<const float4*>(wg + (size_t)m * g.K + k);
+            float* d = At + m * g.KS + k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < g.MB * K32; i += 256) {
+            const int m = i / K32, k = i - m * K32;
+            At[m * g.KS + k] = (m0 + m < g.M && k < g.K) ? wg[(size_t)m * g.K + k] : 0.f;
+        }
+    }
+    for (int m = tid; m < g.MB; m += 256) {
+        EpiCh c = {1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+        if (m0 + m < g.M) c = epi_channel(e, cbase + m);
+        rowc[m] = c.scale; rowc[g.MB + m] = c.shift; rowc[2 * g.MB + m] = c.alpha;
+        rowc[3 * g.MB + m] = c.rw0; rowc[4 * g.MB + m] = c.rw1; rowc[5 * g.MB + m] = c.rw2;
+    }
+}
+
+// ------------------------------------------------------------------ MFMA kernel, NSUB pixels per lane
+template <int NSUB> struct PixVec;
+template <> struct PixVec<4> { typedef float4 T; };
+template <> struct PixVec<2> { typedef float2 T; };
+template <> struct PixVec<1> { typedef float T; };
+
+template <int NSUB>
+__device__ __forceinline__ void vec_load(const void* p, float (&v)[NSUB]) {
+    if constexpr (NSUB == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (NSUB == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else { v[0] = *reinterpret_cast<const float*>(p); }
+}
+template <int NSUB>
+__device__ __forceinline__ void vec_store(void* p, const float (&v)[NSUB]) {
+    if constexpr (NSUB == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (NSUB == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    else *reinterpret_cast<float*>(p) = v[0];
+}
+
+template <int NSUB>
+__global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(const float* __restrict__ x,
                                                                                const float* __restrict__ w,
                                                                                PwGeom g, Epi e,
                                                                                float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    RowEpi* rowc = reinterpret_cast<RowEpi*>(smem);                        // [MB]
-    float* Ct = smem + (size_t)g.MB * (sizeof(RowEpi) / sizeof(float));    // [4 waves][32][33]
-    float* At = Ct + 4 * 32 * 33;                                          // [MB][KS], zero padded to K32
+    float* rowc = smem;                                                    // [ROWC][MB]
+    float* At = smem + (size_t)g.MB * ROWC;                                // [MB][KS]
     int bid = blockIdx.x;
     const int pg = bid % g.pgroups;  bid /= g.pgroups;
-    const int mb = bid % g.mblocks;  bid /= g.mblocks;
-    const int grp = bid % g.G;
-    const int img = bid / g.G;
+    const int mb = bid % g.mblocks;
+    const int grp = bid / g.mblocks;
     const int tid = threadIdx.x;
     const int m0 = mb * g.MB;
-    const int K32 = (g.K + 31) & ~31;
     const int cbase = e.coff + grp * g.M + m0;   // absolute destination channel of local row 0
-
-    const float* wg = w + ((size_t)grp * g.M + m0) * g.K;
-    for (int i = tid; i < g.MB * K32; i += 256) {
-        const int m = i / K32, k = i - m * K32;
-        At[m * g.KS + k] = (m0 + m < g.M && k < g.K) ? wg[(size_t)m * g.K + k] : 0.f;
-    }
-    for (int m = tid; m < g.MB; m += 256) {
-        RowEpi r = {1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
-        if (m0 + m < g.M) {
-            const EpiCh c = epi_channel(e, cbase + m);
-            r.scale = c.scale; r.shift = c.shift; r.alpha = c.alpha; r.rw0 = c.rw0; r.rw1 = c.rw1; r.rw2 = c.rw2;
-        }
-        rowc[m] = r;
-    }
+    stage_weights(At, rowc, w + ((size_t)grp * g.M + m0) * g.K, g, e, m0, cbase, tid);
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
     const int WP = 4 / g.WM;
-    const int wm = wave % g.WM, wp = wave / g.WM;
+    const int chunk = wave % g.WM, wp = wave / g.WM;         // this wave's 32-row chunk of MB and pixel slot
     const int li = lane & 31, half = lane >> 5;
-    const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.K) * (size_t)g.HW;
-    const size_t obase = ((size_t)img * e.ctot + cbase) * (size_t)e.hw;      // uniform
-    const float* gate = e.gate ? e.gate + (size_t)img * e.ctot + cbase : nullptr;
-    const int mrem = g.M - m0;                                  // valid local rows
-    float* ct = Ct + wave * (32 * 33);                          // this wave's 32x32 staging tile (padded)
-    const size_t row2 = 2 * (size_t)g.HW;
+    const int mrem = g.M - m0;
+    const int total_px = g.N * g.HW;
+    const size_t rowbytes = (size_t)g.HW * sizeof(float);
+    if (chunk >= g.mc_total) return;                          // (no barrier follows)
+    const float* arow0 = At + (size_t)(chunk * 32 + li) * g.KS + half;
 
     for (int t = 0; t < g.TPW; ++t) {
         const int ptile = (pg * g.TPW + t) * WP + wp;
-        if (ptile >= g.ptiles) break;            // wave-uniform
-        const int p = ptile * 32 + li;
-        const bool pok = p < g.HW;
-        const int pc = pok ? p : g.HW - 1;       // clamped: loads stay in bounds, results masked
+        if (ptile >= g.ptiles) break;                         // wave-uniform
+        const int gp = (ptile * 32 + li) * NSUB;              // first of this lane's NSUB pixels (flattened batch)
+        const bool pok = gp < total_px;                       // HW % NSUB == 0: a lane's pixels share an image
+        const int gpc = pok ? gp : 0;
+        const int img = gpc / g.HW, p = gpc - img * g.HW;
+        // byte offset of X[img][grp*K + half][p] from x; k advances through a uniform (SGPR) base
+        const size_t voff = (((size_t)img * g.Cin + (size_t)grp * g.K + half) * g.HW + p) * sizeof(float);
+        // destination-shaped tensors (out / residual / pre_add): uniform row base + one 32-bit lane offset
+        const unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + chunk * 32 + 4 * half) * (size_t)e.hw + p) * sizeof(float));
+        const size_t orow = (size_t)e.hw * sizeof(float);
+        const int mlh = chunk * 32 + 4 * half;                // local row of accumulator register 0
 
-        // B rows kb0 + 2*kk + half, kk = 0..15, addressed as (uniform row base) + (32-bit lane byte offset)
-        // so that each load is `global_load_dword v, v_off, s[base]` with no per-load 64-bit VGPR address.
-        const unsigned vb0 = (unsigned)pc * 4u;
-        const unsigned vb = (unsigned)(half * g.HW + pc) * 4u;
-        auto load_group = [&](float (&b)[16], int kb0) {
-            if (kb0 + 32 <= g.K) {               // uniform: full group, no guards
-                const char* xr = reinterpret_cast<const char*>(xg + (size_t)kb0 * g.HW);
+        // residual rows: fetched before the K loop where registers allow (latency hides under the matrix work),
+        // after it for the 4-pixel variant (its accumulators + load ring already fill the register file)
+        float resv[16][NSUB];
+        auto load_residual = [&]() {
+            const char* rb = reinterpret_cast<const char*>(e.residual);
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    b[kk] = *reinterpret_cast<const float*>(xr + vb);
-                    xr += row2 * sizeof(float);
-                }
-            } else {                             // tail group: rows >= K contribute zeros
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int kr = kb0 + 2 * kk;
-                    float v = 0.f;
-                    if (kr < g.K) {              // uniform
-                        const char* xr = reinterpret_cast<const char*>(xg + (size_t)kr * g.HW);
-                        const bool both = kr + 1 < g.K;
-                        v = *reinterpret_cast<const float*>(xr + (both ? vb : vb0));
-                        if (!both && half) v = 0.f;
-                    }
-                    b[kk] = v;
-                }
+                for (int s = 0; s < NSUB; ++s) resv[r][s] = 0.f;
+                if (mlh + dr < mrem) vec_load<NSUB>(rb + dr * orow + ooff, resv[r]);
             }
         };
-        floatx16 acc[MCW];
-#pragma unroll
-        for (int j = 0; j < MCW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (NSUB < 4 && e.residual) load_residual();
 
-        float bcur[16], bnext[16];
-        load_group(bcur, 0);
+        // B rows kb0 + 2*kk + half, kk = 0..3.  K is even on this path; a pair beyond K is clamped to the last
+        // valid pair (finite data) and contributes nothing because A is zero padded to K32 columns.
+        const char* xb = reinterpret_cast<const char*>(x) + voff;
+        const int klast = g.K - 2;
+        auto load_group = [&](float (&b)[4][NSUB], int kb0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int kr = kb0 + 2 * kk;                        // uniform
+                kr = kr < klast ? kr : klast;
+                vec_load<NSUB>(xb + (size_t)kr * rowbytes, b[kk]);
+            }
+        };
+        floatx16 acc[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+        // K loop: a ring of RING groups (8 k-values each) stays in flight; slot i is refilled right after its
+        // MFMAs are issued, so ~3 groups of HBM loads overlap every group of matrix work.
+        constexpr int RING = 4;
+        float b[RING][4][NSUB];
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+            if (i * 8 < g.K) load_group(b[i], i * 8);
 #pragma unroll 1
-        for (int kb0 = 0; kb0 < g.K; kb0 += 32) {
-            const bool more = kb0 + 32 < g.K;
-            if (more) load_group(bnext, kb0 + 32);   // in flight under this group's MFMAs
+        for (int kb0 = 0; kb0 < g.K; kb0 += 8 * RING) {
 #pragma unroll
-            for (int j = 0; j < MCW; ++j) {
-                const int chunk = wm + j * g.WM;
-                if (chunk < g.mc_total) {            // wave-uniform
-                    const float* arow = At + (size_t)(chunk * 32 + li) * g.KS + kb0 + half;
+            for (int i = 0; i < RING; ++i) {
+                const int kb = kb0 + 8 * i;
+                if (kb < g.K) {                                   // uniform
+                    const float* arow = arow0 + kb;
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], bcur[kk], acc[j], 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const float a = arow[2 * kk];
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s)
+                            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i][kk][s], acc[s], 0, 0, 0);
+                    }
+                    if (kb + 8 * RING < g.K) load_group(b[i], kb + 8 * RING);
                 }
             }
-            if (more) {
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) bcur[kk] = bnext[kk];
-            }
         }
 
-        // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-        // The tile goes through a padded LDS image so that a ROLLED loop can walk rows in order (two
-        // 128-byte row segments per wave-instruction) -- an unrolled register epilogue makes hipcc hoist
-        // every row's loads and masks at once and spill.
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
+        if (NSUB == 4 && e.residual) load_residual();
+        float rr[3][NSUB];
         if (e.reinf_r) {
-            const float* rr = e.reinf_r + (size_t)img * 3 * e.hw + pc;
-            r0 = rr[0]; r1 = rr[e.hw]; r2 = rr[2 * (size_t)e.hw];
+            const float* rp = e.reinf_r + (size_t)img * 3 * e.hw + p;
+            vec_load<NSUB>(rp, rr[0]);
+            vec_load<NSUB>(rp + e.hw, rr[1]);
+            vec_load<NSUB>(rp + 2 * (size_t)e.hw, rr[2]);
         }
+        const float* gate = e.gate ? e.gate + (size_t)img * e.ctot + cbase : nullptr;
+        char* ob = reinterpret_cast<char*>(out);
+        const char* pb = reinterpret_cast<const char*>(e.pre_add);
 #pragma unroll
-        for (int j = 0; j < MCW; ++j) {
-            const int chunk = wm + j * g.WM;
-            if (chunk >= g.mc_total) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + li] = acc[j][r];
-            // same-wave LDS write -> read: ds ops of one wave complete in order; the waitcnt is the compiler's
-            const int rows = min(32, mrem - chunk * 32);
-#pragma unroll 2
-            for (int rr = half; rr < rows; rr += 2) {
-                const int ml = chunk * 32 + rr;
-                const RowEpi c = rowc[ml];
-                const size_t off = obase + (size_t)ml * e.hw + pc;
-                float v = ct[rr * 33 + li];
-                if (e.pre_add) v += e.pre_add[off];
-                v = fmaf(v, c.scale, c.shift);
-                if (e.reinf_r) v += c.rw0 * r0 + c.rw1 * r1 + c.rw2 * r2;
-                if (e.residual) v += e.residual[off];
-                if (e.alpha) v = v > 0.f ? v : c.alpha * v;
-                if (gate) v *= gate[ml];
-                if (pok) out[off] = v;
+        for (int rg = 0; rg < 4; ++rg) {
+            const int mlb = mlh + 8 * rg;                                    // first of 4 consecutive local rows
+            const float4 sc4 = *reinterpret_cast<const float4*>(rowc + mlb);
+            const float4 sh4 = *reinterpret_cast<const float4*>(rowc + g.MB + mlb);
+            const float4 al4 = *reinterpret_cast<const float4*>(rowc + 2 * g.MB + mlb);
+            float4 w04 = make_float4(0.f, 0.f, 0.f, 0.f), w14 = w04, w24 = w04;
+            if (e.reinf_r) {
+                w04 = *reinterpret_cast<const float4*>(rowc + 3 * g.MB + mlb);
+                w14 = *reinterpret_cast<const float4*>(rowc + 4 * g.MB + mlb);
+                w24 = *reinterpret_cast<const float4*>(rowc + 5 * g.MB + mlb);
             }
+            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float alv[4] = {al4.x, al4.y, al4.z, al4.w};
+            const float w0v[4] = {w04.x, w04.y, w04.z, w04.w}, w1v[4] = {w14.x, w14.y, w14.z, w14.w};
+            const float w2v[4] = {w24.x, w24.y, w24.z, w24.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q, ml = mlb + q;
+                const size_t rowoff = (size_t)(q + 8 * rg) * orow;           // uniform
+                if (ml < mrem && pok) {
+                    float v[NSUB];
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) v[s] = acc[s][r];
+                    if (pb) {
+                        float pa[NSUB];
+                        vec_load<NSUB>(pb + rowoff + ooff, pa);
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) v[s] += pa[s];
+                    }
+                    const float gv = gate ? gate[ml] : 1.f;
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) {
+                        float t2 = fmaf(v[s], scv[q], shv[q]);
+                        if (e.reinf_r) t2 += w0v[q] * rr[0][s] + w1v[q] * rr[1][s] + w2v[q] * rr[2][s];
+                        if (e.residual) t2 += resv[r][s];
+                        if (e.alpha) t2 = t2 > 0.f ? t2 : alv[q] * t2;
+                        v[s] = t2 * gv;
+                    }
+                    vec_store<NSUB>(ob + rowoff + ooff, v);
+                }
+            }
+            asm volatile("" ::: "memory");   // one row quad at a time: keeps hipcc from hoisting all 16 rows' work
         }
     }
 }
@@ -279,55 +353,68 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     const Epi e = make_epi(ep, Cout, HW);
     hipStream_t s = (hipStream_t)stream;
     PwGeom g;
+    memset(&g, 0, sizeof(g));
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.K = Cin / groups; g.M = Cout / groups; g.HW = HW;
-    if (g.K < 16 && (size_t)Cout * g.K * 4 <= 48 * 1024) return launch_small(x, w, N, Cin, Cout, groups, HW, e, out, s);
+    if ((g.K < 16 || (g.K & 1)) && (size_t)Cout * g.K * 4 <= 48 * 1024) return launch_small(x, w, N, Cin, Cout, groups, HW, e, out, s);
+    MSPL_REQUIRE((g.K & 1) == 0, MSPL_ERR_UNSUPPORTED, "conv1x1: odd K=%d per group with %d output channels is not supported", g.K, Cout);
 
     const int K32 = (g.K + 31) & ~31;
     g.KS = K32 | 1;
-    const size_t lds_cap = 96 * 1024;  // of the 160 KiB per CU
-    const int row_floats = g.KS + (int)(sizeof(RowEpi) / sizeof(float));
-    const size_t ct_bytes = 4 * 32 * 33 * sizeof(float);
-    MSPL_REQUIRE((size_t)32 * row_floats * 4 + ct_bytes <= lds_cap, MSPL_ERR_UNSUPPORTED,
+    g.vecw = ((g.K & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
+    const int rowf = ROWC;
+    MSPL_REQUIRE((size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32),
+                 MSPL_ERR_UNSUPPORTED, "conv1x1: tensor exceeds the 32-bit byte offsets of the matrix-core kernel");
+    const size_t lds_cap = 96 * 1024;       // hard cap (of the 160 KiB per CU)
+    static const int dbg_lds = getenv("MSPL_PW_LDS") ? atoi(getenv("MSPL_PW_LDS")) : 0;
+    const size_t lds_want = dbg_lds ? (size_t)dbg_lds * 1024 : 40 * 1024;      // preferred: several workgroups per CU
+    MSPL_REQUIRE((size_t)32 * (g.KS + rowf) * 4 <= lds_cap, MSPL_ERR_UNSUPPORTED,
                  "conv1x1: K=%d per group exceeds the LDS weight tile", g.K);
     int mb = ((g.M + 31) / 32) * 32;
     if (mb > 128) mb = 128;
-    while (mb > 32 && (size_t)mb * row_floats * 4 + ct_bytes > lds_cap) mb -= 32;
+    while (mb > 32 && (size_t)mb * (g.KS + rowf) * 4 > lds_want) mb -= 32;
     g.MB = mb;
     g.mblocks = ceil_div(g.M, mb);
     g.mc_total = mb / 32;
-    g.ptiles = ceil_div(HW, 32);
-    const int64_t wave_tiles = (int64_t)N * groups * g.mblocks * g.ptiles;
-    // few tiles: split M over the 4 waves (more waves in flight, B re-read through L1);
-    // many tiles: each wave keeps its B registers for all M chunks.
-    int wm = 1;
-    if (wave_tiles < 4096) wm = g.mc_total >= 4 ? 4 : (g.mc_total >= 2 ? 2 : 1);
-    else if (wave_tiles < 16384 && g.mc_total >= 2) wm = 2;
-    g.WM = wm;
-    const int mcw = ceil_div(g.mc_total, wm);
-    const int wp = 4 / wm;
-    int tpw = 1;
-    while (tpw < 8 && wave_tiles / (wp * tpw * 2) >= 4096) tpw *= 2;
-    g.TPW = tpw;
-    g.pgroups = ceil_div(g.ptiles, wp * tpw);
-    const int64_t blocks = (int64_t)N * groups * g.mblocks * g.pgroups;
-    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
-    const size_t lds = (size_t)g.MB * row_floats * sizeof(float) + ct_bytes;
-    dim3 grid((unsigned)blocks), blk(256);
+    g.WM = g.mc_total >= 3 ? 4 : g.mc_total;     // one 32-row chunk per wave; chunks share B loads through L1
+    const int wp = 4 / g.WM;
+    const size_t lds = (size_t)g.MB * (g.KS + rowf) * sizeof(float);
     static bool attr_done = false;   // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+        const int cap = (int)lds_cap;
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipGetLastError();
         attr_done = true;
     }
-    switch (mcw) {
-        case 1: hipLaunchKernelGGL(conv1x1_mfma_kernel<1>, grid, blk, lds, s, x, w, g, e, out); break;
-        case 2: hipLaunchKernelGGL(conv1x1_mfma_kernel<2>, grid, blk, lds, s, x, w, g, e, out); break;
-        case 3: hipLaunchKernelGGL(conv1x1_mfma_kernel<3>, grid, blk, lds, s, x, w, g, e, out); break;
-        default: hipLaunchKernelGGL(conv1x1_mfma_kernel<4>, grid, blk, lds, s, x, w, g, e, out); break;
-    }
+    // pixels per lane: the widest vector the shape/alignment allows that still yields enough waves to fill
+    // 256 CUs x 4 SIMDs (small feature maps prefer narrower tiles over idle CUs)
+    auto al = [](const void* p, int a) { return p == nullptr || (((uintptr_t)p) & (a - 1)) == 0; };
+    auto ok = [&](int ns) {
+        const int a = ns * 4;
+        return HW % ns == 0 && al(x, a) && al(out, a) && (!ep || (al(ep->pre_add, a) && al(ep->residual, a) && al(ep->reinf_r, a)));
+    };
+    auto waves_of = [&](int ns) { return (int64_t)groups * g.mblocks * g.mc_total * ceil_div64((int64_t)N * HW, 32 * ns); };
+    int nsub = 1;
+    if (ok(4) && waves_of(4) >= 2048) nsub = 4;
+    else if (ok(2) && waves_of(2) >= 2048) nsub = 2;
+    else if (ok(2) && !ok(1)) nsub = 2;
+    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;   // tuning override
+    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    if (dbg_nsub && ok(dbg_nsub)) nsub = dbg_nsub;
+    g.ptiles = (int)ceil_div64((int64_t)N * HW, 32 * nsub);
+    const int64_t wave_tiles = (int64_t)groups * g.mblocks * g.ptiles;
+    int tpw = 1;
+    while (tpw < 4 && wave_tiles / (wp * tpw * 2) >= 2048) tpw *= 2;
+    if (dbg_tpw) tpw = dbg_tpw;
+    g.TPW = tpw;
+    g.pgroups = ceil_div(g.ptiles, wp * tpw);
+    const int64_t blocks = (int64_t)groups * g.mblocks * g.pgroups;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
+    dim3 grid((unsigned)blocks), blk(256);
+    if (nsub == 4) hipLaunchKernelGGL(conv1x1_mfma_kernel<4>, grid, blk, lds, s, x, w, g, e, out);
+    else if (nsub == 2) hipLaunchKernelGGL(conv1x1_mfma_kernel<2>, grid, blk, lds, s, x, w, g, e, out);
+    else hipLaunchKernelGGL(conv1x1_mfma_kernel<1>, grid, blk, lds, s, x, w, g, e, out);
     MSPL_CHECK_LAUNCH("conv1x1");
     return MSPL_OK;
 }

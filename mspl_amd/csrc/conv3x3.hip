@@ -42,19 +42,42 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     const float* wg = w + (size_t)grp * nw;
     for (int i = tid; i < nw; i += 256) wl[i] = wg[i];
 
-    // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j)
+    // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j).  One wave per staged row: aligned 16-byte
+    // global loads (W % 4 == 0), scalar LDS writes, zero fill outside the image.
     const int per_plane = g.IH * g.IWS;
-    for (int i = tid; i < g.cin_g * per_plane; i += 256) {
-        const int ci = i / per_plane, rem = i - ci * per_plane;
-        const int r = rem / g.IWS, j = rem - r * g.IWS;
-        const int iy = iy0 + r, ix = ix0 + j;
-        float v = 0.f;
-        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int c_lo = (ix0 >= 0 ? ix0 : ix0 - 3) / 4 * 4;         // floor4(ix0)
+        const int nvec = (g.IWS + (ix0 - c_lo) + 3) >> 2;
+        const bool w4 = (g.W & 3) == 0;
+        for (int rr = wave; rr < g.cin_g * g.IH; rr += 4) {
+            const int ci = rr / g.IH, r = rr - ci * g.IH;
+            const int iy = iy0 + r;
+            const bool row_ok = iy >= 0 && iy < g.H;
             int lc = grp * g.cin_g + ci;
             if (g.sg > 0) lc = (lc % g.sg) * (g.Cin / g.sg) + lc / g.sg;
-            v = x[(((size_t)img * g.Cin + lc) * g.H + iy) * (size_t)g.W + ix];
+            const float* src = x + (((size_t)img * g.Cin + lc) * g.H + (row_ok ? iy : 0)) * (size_t)g.W;
+            float* dst = tile + (size_t)rr * g.IWS;
+            for (int v = lane; v < nvec; v += 64) {
+                const int c0 = c_lo + 4 * v;
+                float e4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (row_ok) {
+                    if (w4 && c0 >= 0 && c0 + 3 < g.W) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(src + c0);
+                        e4[0] = t4.x; e4[1] = t4.y; e4[2] = t4.z; e4[3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c0 + q >= 0 && c0 + q < g.W) e4[q] = src[c0 + q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = c0 + q - ix0;
+                    if (j >= 0 && j < g.IWS) dst[j] = e4[q];
+                }
+            }
         }
-        tile[i] = v;
     }
     __syncthreads();
 

@@ -67,36 +67,46 @@ __global__ __launch_bounds__(256) void eesp_dw_hff_kernel(const float* __restric
     }
 
     // ---- stage input rows (zero-filled outside the image).  LDS column j <-> input column j - 4.
+    // Loads are issued in batches of UL independent 16-byte loads per thread BEFORE any LDS write, so a
+    // workgroup has its whole tile in flight at once instead of one load-latency per loop iteration.
     {
-        const int lanes = 1 << g.txl_log2;
-        const int tx = tid & (lanes - 1), ty = tid >> g.txl_log2, rows_per_it = 256 >> g.txl_log2;
+        constexpr int UL = 8;
         const int nvec = g.LS >> 2;
-        const int total_rows = g.CP * g.RIN;
+        const int total = g.CP * g.RIN * nvec;
         const bool w4 = (g.W & 3) == 0, w2 = (g.W & 1) == 0;
-        for (int rr = ty; rr < total_rows; rr += rows_per_it) {
-            const int p = rr / g.RIN, r = rr - p * g.RIN;
-            const int iy = iy0 + r;
-            const bool row_ok = (iy >= 0) && (iy < g.H);
-            const float* src = x + (((size_t)img * g.n + (c0 + p)) * g.H + (row_ok ? iy : 0)) * (size_t)g.W;
-            float* dst = tile + (size_t)rr * g.LS;
-            for (int cv = tx; cv < nvec; cv += lanes) {
-                const int col0 = 4 * cv - 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_ok) {
-                    if (w4) {
-                        if (col0 >= 0 && col0 < g.W) v = *reinterpret_cast<const float4*>(src + col0);
-                    } else if (w2) {
-                        if (col0 >= 0 && col0 < g.W) { float2 a = *reinterpret_cast<const float2*>(src + col0); v.x = a.x; v.y = a.y; }
-                        if (col0 + 2 >= 0 && col0 + 2 < g.W) { float2 a = *reinterpret_cast<const float2*>(src + col0 + 2); v.z = a.x; v.w = a.y; }
-                    } else {
-                        if (col0 >= 0 && col0 < g.W) v.x = src[col0];
-                        if (col0 + 1 >= 0 && col0 + 1 < g.W) v.y = src[col0 + 1];
-                        if (col0 + 2 >= 0 && col0 + 2 < g.W) v.z = src[col0 + 2];
-                        if (col0 + 3 >= 0 && col0 + 3 < g.W) v.w = src[col0 + 3];
+        for (int base = 0; base < total; base += 256 * UL) {
+            float4 v[UL];
+            int dsto[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dsto[u] = -1;
+                if (i < total) {
+                    const int rr = i / nvec, cv = i - rr * nvec;
+                    const int p = rr / g.RIN, r = rr - p * g.RIN;
+                    const int iy = iy0 + r;
+                    const int col0 = 4 * cv - 4;
+                    dsto[u] = rr * g.LS + 4 * cv;
+                    if (iy >= 0 && iy < g.H) {
+                        const float* src = x + (((size_t)img * g.n + (c0 + p)) * g.H + iy) * (size_t)g.W;
+                        if (w4) {
+                            if (col0 >= 0 && col0 < g.W) v[u] = *reinterpret_cast<const float4*>(src + col0);
+                        } else if (w2) {
+                            if (col0 >= 0 && col0 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + col0); v[u].x = a.x; v[u].y = a.y; }
+                            if (col0 + 2 >= 0 && col0 + 2 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + col0 + 2); v[u].z = a.x; v[u].w = a.y; }
+                        } else {
+                            if (col0 >= 0 && col0 < g.W) v[u].x = src[col0];
+                            if (col0 + 1 >= 0 && col0 + 1 < g.W) v[u].y = src[col0 + 1];
+                            if (col0 + 2 >= 0 && col0 + 2 < g.W) v[u].z = src[col0 + 2];
+                            if (col0 + 3 >= 0 && col0 + 3 < g.W) v[u].w = src[col0 + 3];
+                        }
                     }
                 }
-                *reinterpret_cast<float4*>(dst + 4 * cv) = v;
             }
+#pragma unroll
+            for (int u = 0; u < UL; ++u)
+                if (dsto[u] >= 0) *reinterpret_cast<float4*>(tile + dsto[u]) = v[u];
         }
     }
     __syncthreads();

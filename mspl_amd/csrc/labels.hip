@@ -102,28 +102,13 @@ struct MergeSrc {
     const uint8_t* p[8];
 };
 
-template <int NCLS>
-__device__ __forceinline__ uint32_t merge_one(const uint32_t (&lab)[8], int S, int ncls, int thresh, int fill) {
-    int best = 0, bestc = -1;
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c) {
-        if (c < ncls) {
-            int cnt = 0;
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < S) cnt += (lab[s] == (uint32_t)c);
-            if (cnt > bestc) { bestc = cnt; best = c; }     // first max (np.argmax)
-        }
-    }
-    return bestc < thresh ? (uint32_t)fill : (uint32_t)best;
-}
-
-// 16 pixels per thread (one 16-byte load per source), per-thread histogram in registers, wave + LDS
-// reduction, one 64-bit atomic per class per workgroup.
-__global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int S, int64_t npix, int ncls, int thresh,
+// 16 pixels per thread (one 16-byte load per source), S and the class bound compile-time so the vote is a
+// short unrolled compare tree; per-thread histogram in registers, wave + LDS reduction, one 64-bit atomic per
+// class per workgroup.
+template <int S, int NCLS>
+__global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int64_t npix, int ncls, int thresh,
                                                            int fill, uint8_t* __restrict__ out,
                                                            unsigned long long* __restrict__ hist, int vec_ok) {
-    constexpr int NCLS = 16;
     uint32_t h[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) h[c] = 0;
@@ -131,28 +116,26 @@ __global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int S, 
     for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < nchunks; ch += (int64_t)gridDim.x * 256) {
         const int64_t p0 = ch << 4;
         const int cnt = (int)((npix - p0) < 16 ? (npix - p0) : 16);
-        uint32_t words[8][4];
+        uint32_t words[S][4];
         if (vec_ok && cnt == 16) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < S) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(src.p[s] + p0);
-                    words[s][0] = v.x; words[s][1] = v.y; words[s][2] = v.z; words[s][3] = v.w;
-                }
+            for (int s = 0; s < S; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src.p[s] + p0);
+                words[s][0] = v.x; words[s][1] = v.y; words[s][2] = v.z; words[s][3] = v.w;
+            }
         } else {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < S) {
+            for (int s = 0; s < S; ++s) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t wv = 0;
-                        for (int b = 0; b < 4; ++b) {
-                            const int i = q * 4 + b;
-                            if (i < cnt) wv |= (uint32_t)src.p[s][p0 + i] << (8 * b);
-                        }
-                        words[s][q] = wv;
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t wv = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = q * 4 + b;
+                        if (i < cnt) wv |= (uint32_t)src.p[s][p0 + i] << (8 * b);
                     }
+                    words[s][q] = wv;
                 }
+            }
         }
         uint32_t res[4];
 #pragma unroll
@@ -160,10 +143,20 @@ __global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int S, 
             uint32_t r = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                uint32_t lab[8];
+                uint32_t lab[S];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) lab[s] = (s < S) ? ((words[s][q] >> (8 * b)) & 0xFFu) : 0xFFFFu;
-                const uint32_t m = merge_one<NCLS>(lab, S, ncls, thresh, fill);
+                for (int s = 0; s < S; ++s) lab[s] = (words[s][q] >> (8 * b)) & 0xFFu;
+                int best = 0, bestc = -1;
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) {
+                    if (c < ncls) {
+                        int cn = 0;
+#pragma unroll
+                        for (int s = 0; s < S; ++s) cn += (lab[s] == (uint32_t)c);
+                        if (cn > bestc) { bestc = cn; best = c; }     // first max (np.argmax)
+                    }
+                }
+                const uint32_t m = bestc < thresh ? (uint32_t)fill : (uint32_t)best;
                 r |= m << (8 * b);
                 if (q * 4 + b < cnt) {
 #pragma unroll
@@ -192,6 +185,15 @@ __global__ __launch_bounds__(256) void merge_labels_kernel(MergeSrc src, int S, 
         __syncthreads();
         if (threadIdx.x < ncls && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
     }
+}
+
+template <int S>
+static void launch_merge(int ncls, dim3 grid, hipStream_t st, const MergeSrc& ms, int64_t npix, int thresh, int fill,
+                         uint8_t* out, unsigned long long* hist, int vec_ok) {
+    if (ncls <= 8)
+        hipLaunchKernelGGL((merge_labels_kernel<S, 8>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
+    else
+        hipLaunchKernelGGL((merge_labels_kernel<S, 16>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
 }
 
 }  // namespace mspl
@@ -240,9 +242,19 @@ extern "C" int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64
     }
     const int64_t nchunks = (npix + 15) >> 4;
     int64_t blocks = ceil_div64(nchunks, 256);
-    if (blocks > 2048) blocks = 2048;   // grid-stride; 256 CUs x 8
-    hipLaunchKernelGGL(merge_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ms, S, npix,
-                       num_classes, thresh, fill, out, hist, vec_ok);
+    if (blocks > 16384) blocks = 16384;   // grid-stride beyond that
+    dim3 grid((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    switch (S) {
+        case 1: launch_merge<1>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 2: launch_merge<2>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 3: launch_merge<3>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 4: launch_merge<4>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 5: launch_merge<5>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 6: launch_merge<6>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        case 7: launch_merge<7>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+        default: launch_merge<8>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
+    }
     MSPL_CHECK_LAUNCH("merge_labels");
     return MSPL_OK;
 }

@@ -54,16 +54,26 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
     strip_decode(idx, g, n, c, y, x0);
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // input columns 2*x0-1 .. 2*x0+7; 2*x0 is a multiple of 8, so with Wi % 4 == 0 the 8 interior columns are
+    // two aligned 16-byte loads and only the left neighbour is a scalar load
+    const bool vec = ((g.Wi & 3) == 0) && (2 * x0 + 7 < g.Wi);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = 2 * y - 1 + ky;
         if (iy < 0 || iy >= g.Hi) continue;
         const float* row = src + (size_t)iy * g.Wi;
         float rv[9];
+        if (vec) {
+            const float4 a = *reinterpret_cast<const float4*>(row + 2 * x0);
+            const float4 b = *reinterpret_cast<const float4*>(row + 2 * x0 + 4);
+            rv[0] = x0 > 0 ? row[2 * x0 - 1] : 0.f;
+            rv[1] = a.x; rv[2] = a.y; rv[3] = a.z; rv[4] = a.w; rv[5] = b.x; rv[6] = b.y; rv[7] = b.z; rv[8] = b.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int ix = 2 * x0 - 1 + i;
-            rv[i] = (ix >= 0 && ix < g.Wi) ? row[ix] : 0.f;
+            for (int i = 0; i < 9; ++i) {
+                const int ix = 2 * x0 - 1 + i;
+                rv[i] = (ix >= 0 && ix < g.Wi) ? row[ix] : 0.f;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] += rv[2 * j] + rv[2 * j + 1] + rv[2 * j + 2];
@@ -123,6 +133,37 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __re
     strip_store(e, g, n, c, y, x0, acc, out);
 }
 
+// Large windows (the 0.1-scale pyramid branch pools ~10x10..20x20 inputs per output): one wave per output
+// pixel, lanes stride over the window so that each window row is read coalesced; shuffle reduction.
+__global__ __launch_bounds__(256) void adaptive_avgpool_wave_kernel(const float* __restrict__ x, RsGeom g, Epi e,
+                                                                    float* __restrict__ out, int64_t total_out) {
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= total_out) return;                       // wave-uniform
+    const int lane = threadIdx.x & 63;
+    int64_t t = o;
+    const int ox = (int)(t % g.Wo);  t /= g.Wo;
+    const int oy = (int)(t % g.Ho);  t /= g.Ho;
+    const int c = (int)(t % g.C);
+    const int n = (int)(t / g.C);
+    const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
+    const int ys = ada_start(oy, g.Hi, g.Ho), ye = ada_end(oy, g.Hi, g.Ho);
+    const int xs = ada_start(ox, g.Wi, g.Wo), xe = ada_end(ox, g.Wi, g.Wo);
+    const int ww = xe - xs, cnt = (ye - ys) * ww;
+    float s = 0.f;
+    for (int i = lane; i < cnt; i += 64) {
+        const int r = i / ww, q = i - r * ww;
+        s += src[(size_t)(ys + r) * g.Wi + xs + q];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane == 0) {
+        const int cabs = e.coff + c;
+        const EpiCh ec = epi_channel(e, cabs);
+        const int pix = oy * g.Wo + ox;
+        out[epi_offset(e, n, cabs, pix)] = epi_apply(e, ec, s / (float)cnt, n, cabs, pix);
+    }
+}
+
 // x and out share the destination geometry (N, ctot, HW); 4 pixels per thread.
 __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ x, int N, int C, Epi e,
                                                         float* __restrict__ out, int64_t total) {
@@ -168,16 +209,20 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     if (threadIdx.x == 0) mean[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)HW;
 }
 
+// One wave per (n, co): lanes stride over Cin (coalesced weight row), shuffle reduction, sigmoid.
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ mean, const float* __restrict__ w,
                                                    int N, int Cin, int Cout, float* __restrict__ gate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= N * Cout) return;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= N * Cout) return;                      // wave-uniform
+    const int lane = threadIdx.x & 63;
     const int n = idx / Cout, co = idx - n * Cout;
     const float* m = mean + (size_t)n * Cin;
     const float* wr = w + (size_t)co * Cin;
     float s = 0.f;
-    for (int k = 0; k < Cin; ++k) s = fmaf(wr[k], m[k], s);
-    gate[idx] = 1.0f / (1.0f + expf(-s));
+    for (int k = lane; k < Cin; k += 64) s = fmaf(wr[k], m[k], s);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane == 0) gate[idx] = 1.0f / (1.0f + expf(-s));
 }
 
 static int resample_common(const char* who, const float* x, float* out, int N, int C, int Hi, int Wi, int Ho, int Wo,
@@ -226,6 +271,14 @@ extern "C" int mspl_adaptive_avgpool_fwd(const float* x, int32_t N, int32_t C, i
                                          void* stream) {
     RsGeom g; Epi e; int64_t total;
     if (int rc = resample_common("adaptive_avgpool", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
+    if ((int64_t)Hi * Wi >= 32ll * Ho * Wo) {         // mean window >= 32 inputs: wave per output
+        const int64_t total_out = (int64_t)N * C * Ho * Wo;
+        MSPL_REQUIRE(ceil_div64(total_out, 4) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "adaptive_avgpool: grid too large");
+        hipLaunchKernelGGL(adaptive_avgpool_wave_kernel, dim3((unsigned)ceil_div64(total_out, 4)), dim3(256), 0,
+                           (hipStream_t)stream, x, g, e, out, total_out);
+        MSPL_CHECK_LAUNCH("adaptive_avgpool(wave)");
+        return MSPL_OK;
+    }
     hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, x, g, e, out, total);
     MSPL_CHECK_LAUNCH("adaptive_avgpool");
@@ -254,7 +307,7 @@ extern "C" int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int3
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)(N * Cin)), dim3(256), 0, s, x, HW, mean_ws);
     MSPL_CHECK_LAUNCH("gap_gate(mean)");
-    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 256)), dim3(256), 0, s, mean_ws, w, N, Cin, Cout, gate);
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 4)), dim3(256), 0, s, mean_ws, w, N, Cin, Cout, gate);
     MSPL_CHECK_LAUNCH("gap_gate(gate)");
     return MSPL_OK;
 }

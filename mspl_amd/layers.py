@@ -341,18 +341,28 @@ class EfficientPyrPool(nn.Module):
         scale, shift = bn_fold(bn)
         return Epi(scale, shift, act.weight)
 
-    def forward(self, x):
-        _no_grad_only()
-        x = self.projection_layer(x)
+    def branch_sizes(self, height, width):
+        """efficient_pyramid_pool.py:41-44: ceil(size*scale), clamped to >= 5."""
+        return [(max(int(math.ceil(height * s)), 5), max(int(math.ceil(width * s)), 5)) for s in self.scales]
+
+    def _fusable(self, sizes, height, width):
+        """The fused kernel handles pure up / same / down branches with up-scales <= 4x."""
+        for hs, ws in sizes:
+            up, down = (hs >= height and ws >= width), (hs <= height and ws <= width)
+            if not (up or down) or hs > 4 * height or ws > 4 * width:
+                return False
+        return len(sizes) <= 5
+
+    def forward_unfused(self, x):
+        """Branch-by-branch form (one kernel per resample / depthwise step); kept for shapes the fused kernel
+        does not cover and as its cross-check."""
         N, P, height, width = x.shape
         S = len(self.scales)
         cat = torch.empty((N, P * S, height, width), device=x.device, dtype=torch.float32)
         br = self.merge_layer[0].br
         bscale, bshift = bn_fold(br[0])
         ep = Epi(bscale, bshift, br[1].weight)       # merge_layer.0 (one big BN+PReLU) fused into each branch writer
-        for i, stage in enumerate(self.stages):
-            h_s = max(int(math.ceil(height * self.scales[i])), 5)
-            w_s = max(int(math.ceil(width * self.scales[i])), 5)
+        for i, (stage, (h_s, w_s)) in enumerate(zip(self.stages, self.branch_sizes(height, width))):
             dst = (cat, i * P)
             if self.scales[i] < 1.0:
                 h = ops.adaptive_avgpool(x, (h_s, w_s))
@@ -365,7 +375,33 @@ class EfficientPyrPool(nn.Module):
             else:
                 ops.conv3x3(x, stage.weight, P, ep=ep, out=dst)
         mcbr = self.merge_layer[2]
-        m = ops.conv3x3(cat, mcbr.cbr[0].weight, P, 1, shuffle_groups=S, ep=mcbr.epi())
+        return ops.conv3x3(cat, mcbr.cbr[0].weight, P, 1, shuffle_groups=S, ep=mcbr.epi())
+
+    def forward_fused(self, x, sizes):
+        N, P, height, width = x.shape
+        stage_ws, down_es = [], []
+        for i, (stage, (h_s, w_s)) in enumerate(zip(self.stages, sizes)):
+            if self.scales[i] < 1.0 and (h_s, w_s) != (height, width):   # (same-size pool/resize are identities)
+                stage_ws.append(None)
+                down_es.append(ops.conv3x3(ops.adaptive_avgpool(x, (h_s, w_s)), stage.weight, P))
+            else:
+                stage_ws.append(stage.weight)
+                down_es.append(None)
+        br = self.merge_layer[0].br
+        bscale, bshift = bn_fold(br[0])
+        mcbr = self.merge_layer[2]
+        return ops.pyrpool_fused(x, sizes, stage_ws, down_es, bscale, bshift, br[1].weight, mcbr.cbr[0].weight,
+                                 mcbr.epi())
+
+    def forward(self, x, fused=True):
+        _no_grad_only()
+        x = self.projection_layer(x)
+        height, width = x.shape[2:]
+        sizes = self.branch_sizes(height, width)
+        # a scale<1 branch whose clamped size exceeds the map (tiny maps) or a scale>1 branch are "up" for the kernel
+        ok = fused and self._fusable(sizes, height, width) and all(
+            (s >= 1.0) or (hs <= height and ws <= width) for s, (hs, ws) in zip(self.scales, sizes))
+        m = self.forward_fused(x, sizes) if ok else self.forward_unfused(x)
         return ops.conv1x1(m, self.merge_layer[3].weight, 1, self._final_epilogue())
 
 

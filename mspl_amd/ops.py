@@ -189,6 +189,39 @@ def gap_gate(x, w):
     return gate
 
 
+def pyrpool_fused(x, sizes, stage_ws, down_es, br_scale, br_shift, br_alpha, merge_w, ep=None, out=None):
+    """K6.  x (N,P,h,w); sizes: [(hs,ws)] per branch; stage_ws / down_es: per-branch tensors or None."""
+    x = _f32(x, 'x')
+    N, P, h, w = x.shape
+    nb = len(sizes)
+    merge_w = _f32(merge_w, 'merge_w')
+    if tuple(merge_w.shape) != (P, nb, 3, 3):
+        raise RuntimeError('mspl_amd: pyrpool merge weight %s, expected (%d,%d,3,3)' % (tuple(merge_w.shape), P, nb))
+    hs = (ctypes.c_int32 * nb)(*[int(s[0]) for s in sizes])
+    ws = (ctypes.c_int32 * nb)(*[int(s[1]) for s in sizes])
+    keep = []
+    sw, de = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+    for i in range(nb):
+        if stage_ws[i] is not None:
+            t = _f32(stage_ws[i], 'stage weight')
+            if t.numel() != P * 9:
+                raise RuntimeError('mspl_amd: pyrpool stage weight %s, expected (%d,1,3,3)' % (tuple(t.shape), P))
+            keep.append(t)
+            sw[i] = t.data_ptr()
+        if down_es[i] is not None:
+            t = _f32(down_es[i], 'down map')
+            if tuple(t.shape) != (N, P, int(sizes[i][0]), int(sizes[i][1])):
+                raise RuntimeError('mspl_amd: pyrpool low-res map %s does not match branch size %s' % (tuple(t.shape), sizes[i]))
+            keep.append(t)
+            de[i] = t.data_ptr()
+    bs, bh, ba = _vec(br_scale, nb * P, 'br_scale'), _vec(br_shift, nb * P, 'br_shift'), _vec(br_alpha, nb * P, 'br_alpha')
+    dst, coff = _dest(out, (N, P, h, w), x)
+    s, k2 = _build(ep, dst, coff, N, P, h * w)
+    check(lib.mspl_pyrpool_fused_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(bs), _p(bh), _p(ba), _p(merge_w),
+                                     ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
 def label_epilogue(main, aux, size, lut=None, want_labels=True, want_prob=False, want_kld=False,
                    want_logits=False):
     """K8+K9.  Returns dict with any of labels (uint8 N,H,W), prob, kld, main_up, aux_up."""

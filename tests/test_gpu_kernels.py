@@ -184,3 +184,26 @@ def test_bad_arguments_raise():
         ops.avgpool3x3s2(torch.zeros(1, 1, 4, 4, device=DEV, dtype=torch.float16))
     with pytest.raises(RuntimeError, match='does not match'):
         ops.conv1x1(torch.zeros(1, 8, 4, 4, device=DEV), torch.zeros(4, 3, 1, 1, device=DEV), 1)
+
+
+@pytest.mark.parametrize('cfg', [(2, 24, 8, 12, 14, 22, True), (1, 12, 16, 5, 16, 30, False), (1, 8, 4, 6, 6, 9, True),
+                                 (1, 32, 16, 13, 72, 120, False), (2, 16, 16, 7, 33, 47, True), (1, 8, 16, 5, 4, 4, True),
+                                 (1, 16, 16, 20, 144, 240, False)])
+def test_pyrpool_fused_equals_unfused_and_oracle(cfg):
+    """Fused K6 kernel vs the branch-by-branch kernels vs the torch-CPU oracle, incl. odd sizes, tiles that do not
+    divide the map, the clamp-to-5 branch sizes and a map too small for the fused kernel (falls back)."""
+    from mspl_amd import layers as L
+    from oracle import net as onet
+    from tests.synth import synth_state_dict
+    N, cin, P, cout, h, w, lbr = cfg
+    m = L.EfficientPyrPool(cin, P, cout, last_layer_br=lbr)
+    sd = synth_state_dict(m.state_dict(), 5)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = rnd(N, cin, h, w, seed=3)
+    with torch.no_grad():
+        yf = m(x.to(DEV))
+        yu = m(x.to(DEV), fused=False)
+        ref = onet.pyr_pool(x, {'m.' + k: v for k, v in sd.items()}, 'm', lbr)
+    close(yu, ref, atol=5e-5)
+    close(yf, ref, atol=5e-5)

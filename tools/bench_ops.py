@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Micro-benchmark single ops at the shapes of ESPDNet-UE s=2.0 (bs=16, 288x480): time per launch (HIP events,
+median of batches), algorithmic GB/s and GFLOP/s.  Usage: python tools/bench_ops.py [conv1x1|k2|all]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mspl_amd import ops
+from mspl_amd.ops import Epi
+
+DEV = 'cuda'
+
+
+def timeit(fn, iters=20, reps=5):
+    """Device time per launch: `iters` launches captured into one hipGraph (no host launch overhead in between)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / iters * 1e3)
+    best.sort()
+    return best[len(best) // 2]
+
+
+def conv1x1_cases(N=16):
+    # (name, Cin, Cout, groups, H, W, residual)
+    return [('L2_0 exp 96->96 g4', 96, 96, 4, 72, 120, False), ('L3_0 proj 128->32', 128, 32, 4, 72, 120, False),
+            ('L3_0 exp 128->128', 128, 128, 4, 36, 60, False), ('L3 proj 256->64', 256, 64, 4, 36, 60, False),
+            ('L3 exp 256->256 +res', 256, 256, 4, 36, 60, True), ('L4_0 exp 256->256', 256, 256, 4, 18, 30, False),
+            ('L4 proj 512->128', 512, 128, 4, 18, 30, False), ('L4 exp 512->512 +res', 512, 512, 4, 18, 30, True),
+            ('dec1 proj 512->16', 512, 16, 1, 18, 30, False), ('dec1 out 16->64', 16, 64, 1, 18, 30, False),
+            ('dec2 proj 64->16', 64, 16, 1, 36, 60, False), ('dec3 proj 48->16', 48, 16, 1, 72, 120, False),
+            ('dec4 proj 32->16', 32, 16, 1, 144, 240, False), ('dec4 out 16->13', 16, 13, 1, 144, 240, False)]
+
+
+def bench_conv1x1():
+    N = 16
+    for name, ci, co, g, h, w, res in conv1x1_cases():
+        x = torch.randn(N, ci, h, w, device=DEV)
+        wt = torch.randn(co, ci // g, 1, 1, device=DEV) * 0.1
+        sc, sh, al = torch.rand(co, device=DEV) + 0.5, torch.randn(co, device=DEV), torch.rand(co, device=DEV) * 0.3
+        r = torch.randn(N, co, h, w, device=DEV) if res else None
+        out = torch.empty(N, co, h, w, device=DEV)
+        ep = Epi(sc, sh, al, residual=r)
+        t = timeit(lambda: ops.conv1x1(x, wt, g, ep, out=(out, 0)))
+        by = 4 * N * h * w * (ci + co * (2 if res else 1))
+        fl = 2 * N * h * w * co * ci // g
+        print('%-24s %8.1f us  %7.1f GB/s  %7.1f GFLOP/s' % (name, t, by / t / 1e3, fl / t / 1e3))
+
+
+def bench_k2():
+    N = 16
+    for name, n, h, w, stride, dil in [('L2_0 s2 n=24', 24, 144, 240, 2, [1, 2, 3, 4]), ('L3_0 s2 n=32', 32, 72, 120, 2, [1, 2, 3, 4]),
+                                       ('L3 s1 n=64', 64, 36, 60, 1, [1, 2, 3, 4]), ('L4_0 s2 n=64', 64, 36, 60, 2, [1, 2, 3, 4]),
+                                       ('L4 s1 n=128', 128, 18, 30, 1, [1, 1, 2, 3])]:
+        x = torch.randn(N, n, h, w, device=DEV)
+        w4 = torch.randn(4, n, 3, 3, device=DEV) * 0.2
+        sc, sh, al = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        out = torch.empty(N, 4 * n, ho, wo, device=DEV)
+        ep = Epi(sc, sh, al)
+        t = timeit(lambda: ops.eesp_dw_hff(x, w4, dil, stride, ep, out=(out, 0)))
+        by = 4 * N * n * (h * w + 4 * ho * wo)
+        print('%-24s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)' % (name, t, by / t / 1e3, by / t / 1e3 / 80))
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what in ('conv1x1', 'all'):
+        bench_conv1x1()
+    if what in ('k2', 'all'):
+        bench_k2()
