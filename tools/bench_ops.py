@@ -80,9 +80,35 @@ def bench_k2():
         print('%-24s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)' % (name, t, by / t / 1e3, by / t / 1e3 / 80))
 
 
+def bench_pyr():
+    from mspl_amd import layers as L
+    N = 16
+    for name, cin, cout, h, w in [('dec1 512->64 18x30', 512, 64, 18, 30), ('dec2 64->48 36x60', 64, 48, 36, 60),
+                                  ('dec3 48->32 72x120', 48, 32, 72, 120), ('dec4 32->13 144x240', 32, 13, 144, 240)]:
+        m = L.EfficientPyrPool(cin, 16, cout, last_layer_br=(cout != 13)).to(DEV).eval()
+        x = torch.randn(N, cin, h, w, device=DEV)
+        with torch.no_grad():
+            xp = m.projection_layer(x)
+            sizes = m.branch_sizes(h, w)
+            t_all = timeit(lambda: m(x))
+            t_fused = timeit(lambda: m.forward_fused(xp, sizes))
+            import mspl_amd.ops as O
+            down = [O.conv3x3(O.adaptive_avgpool(xp, sz), st.weight, 16) if sc < 1 else None for sc, sz, st in zip(m.scales, sizes, m.stages)]
+            sw = [None if sc < 1 else st.weight for sc, st in zip(m.scales, m.stages)]
+            br = m.merge_layer[0].br
+            bs, bh = L.bn_fold(br[0])
+            mc = m.merge_layer[2]
+            t_k = timeit(lambda: O.pyrpool_fused(xp, sizes, sw, down, bs, bh, br[1].weight, mc.cbr[0].weight, mc.epi()))
+            print('   kernel only %.1f us' % t_k)
+        by = 4 * N * 16 * h * w * 2
+        print('%-24s whole %8.1f us | fused body %8.1f us (%.0f GB/s of x+y traffic)' % (name, t_all, t_fused, by / t_fused / 1e3))
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('conv1x1', 'all'):
         bench_conv1x1()
     if what in ('k2', 'all'):
         bench_k2()
+    if what in ('pyr', 'all'):
+        bench_pyr()
