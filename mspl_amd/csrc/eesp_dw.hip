@@ -10,6 +10,8 @@
 // register-resident row windows (one aligned LDS row window feeds every tap of every branch), applies
 // the prefix sum across branches and the folded BN + PReLU, and writes the four concatenated planes
 // with 16-byte stores.  Algorithmic bytes: 4*n*(H*W + 4*Ho*Wo) per image.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -35,21 +37,34 @@ struct DwGeom {
     int CP;       // planes per workgroup (same image, consecutive channels)
     int bands;    // ceil(Ho / TH)
     int cgroups;  // n / CP
-    int LS;       // LDS row stride in floats (multiple of 4)
+    int LS;       // LDS row stride in floats: 4 zero columns + W (rounded to 4) + zero fill; chosen so that lane
+                  // addresses stay linear (mod 64 banks) across row ends -> conflict-free ds_read_b128
+    unsigned mag_xs;   // exact division of an item index by XS: (t * mag) >> 24
     int RIN;      // staged input rows per plane
-    int XS;       // ceil(Wo / 4) output strips per row
-    int txl_log2; // loader: lanes per LDS row = 1 << txl_log2 (>= LS/4)
+    int XS;       // output strips per row
+    int nocompute; // tuning aid (MSPL_DW_NOCOMPUTE): skip the stencil, keep loads/stores
+    unsigned long long* stamps;  // tuning aid (MSPL_DW_STAMP): 4 s_memrealtime stamps per workgroup, or null
 };
 
+// One-shot workgroups, branch-sequential compute, conflict-free LDS addressing.
+//  * A thread owns OW = 4/STRIDE adjacent output pixels, i.e. always a 12-float input window starting at
+//    input column 4*xs - 4 (three ds_read_b128).  Lanes of a wave are exactly 16 bytes apart.
+//  * Staged rows carry the horizontal zero padding (4 zero columns left, zero fill right) and the row stride is
+//    chosen with STRIDE*LS == 4*XS (mod 64 banks): the lane -> address map then stays linear across row ends and
+//    every ds_read_b128 is bank-conflict free (a plain W+8 stride made 60-75% of the LDS cycles conflict cycles).
+//  * The four branches are evaluated one after the other (3 row windows each), carrying the hierarchical sum
+//    out_k = conv_k + out_{k-1} in OW registers and storing each branch as soon as it is final: ~50 VGPRs, so
+//    6-8 waves/SIMD keep loads, LDS reads, FMAs and stores of different tiles overlapped.
 template <int STRIDE, class DS>
-__global__ __launch_bounds__(256) void eesp_dw_hff_kernel(const float* __restrict__ x,
-                                                          const float* __restrict__ w,
-                                                          DwGeom g, Epi e, float* __restrict__ out) {
+__global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             DwGeom g, Epi e, float* __restrict__ out) {
     constexpr int MAXD = DS::maxd();
-    constexpr int NR = (STRIDE == 1) ? 12 : 16;  // row-window floats per thread
+    constexpr int OW = 4 / STRIDE;                        // outputs per thread (4 or 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                   // CP * RIN * LS
-    float* wl = smem + (size_t)g.CP * g.RIN * g.LS;       // CP * 36 (branch, ky, kx)
+    float* tile = smem;                                   // CP * RIN * LS (+16 floats of tail pad)
+    float* wl = smem + (size_t)g.CP * g.RIN * g.LS + 16;  // CP * 36 (branch, ky, kx)
+    float* el = wl + g.CP * 36;                           // CP * 12 (branch, {scale, shift, alpha})
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int band = bid % g.bands;  bid /= g.bands;
@@ -59,16 +74,25 @@ __global__ __launch_bounds__(256) void eesp_dw_hff_kernel(const float* __restric
     const int y0 = band * g.TH;                 // first output row of the band
     const int iy0 = y0 * STRIDE - MAXD;         // input row of LDS row 0
     const int tid = threadIdx.x;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (g.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- stage weights: wl[p][k][ky][kx] = w[k][c0+p][ky][kx]
-    for (int i = tid; i < g.CP * 36; i += 256) {
-        const int p = i / 36, r = i - p * 36, k = r / 9, t = r - k * 9;
-        wl[i] = w[((size_t)k * g.n + (c0 + p)) * 9 + t];
+    // ---- stage weights and epilogue constants (loads issued before the tile's, written after)
+    float wreg = 0.f, ereg = 0.f;
+    const int nwts = g.CP * 36, neps = g.CP * 12;
+    if (tid < nwts) {
+        const int p = tid / 36, r = tid - p * 36, k = r / 9, t = r - k * 9;
+        wreg = w[((size_t)k * g.n + (c0 + p)) * 9 + t];
+    }
+    if (tid < neps) {
+        const int p = tid / 12, r = tid - p * 12, k = r / 3, f = r - k * 3;
+        const int cabs = e.coff + k * g.n + c0 + p;
+        const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
+        ereg = src ? src[cabs] : (f == 1 ? 0.f : 1.f);
     }
 
-    // ---- stage input rows (zero-filled outside the image).  LDS column j <-> input column j - 4.
-    // Loads are issued in batches of UL independent 16-byte loads per thread BEFORE any LDS write, so a
-    // workgroup has its whole tile in flight at once instead of one load-latency per loop iteration.
+    // ---- stage input rows (rows outside the image are zero).  Loads are issued in batches of UL independent
+    // 16-byte loads per thread BEFORE any LDS write, so a workgroup has its whole tile in flight at once.
     {
         constexpr int UL = 8;
         const int nvec = g.LS >> 2;
@@ -86,20 +110,20 @@ __global__ __launch_bounds__(256) void eesp_dw_hff_kernel(const float* __restric
                     const int rr = i / nvec, cv = i - rr * nvec;
                     const int p = rr / g.RIN, r = rr - p * g.RIN;
                     const int iy = iy0 + r;
-                    const int col0 = 4 * cv - 4;
-                    dsto[u] = rr * g.LS + 4 * cv;
-                    if (iy >= 0 && iy < g.H) {
-                        const float* src = x + (((size_t)img * g.n + (c0 + p)) * g.H + iy) * (size_t)g.W;
+                    const int col0 = 4 * cv - 4;             // LDS column j <-> input column j - 4
+                    dsto[u] = 4 * i;
+                    if (iy >= 0 && iy < g.H && col0 >= 0 && col0 < g.W) {
+                        const float* src = x + (((size_t)img * g.n + (c0 + p)) * g.H + iy) * (size_t)g.W + col0;
                         if (w4) {
-                            if (col0 >= 0 && col0 < g.W) v[u] = *reinterpret_cast<const float4*>(src + col0);
+                            v[u] = *reinterpret_cast<const float4*>(src);
                         } else if (w2) {
-                            if (col0 >= 0 && col0 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + col0); v[u].x = a.x; v[u].y = a.y; }
-                            if (col0 + 2 >= 0 && col0 + 2 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + col0 + 2); v[u].z = a.x; v[u].w = a.y; }
+                            { const float2 a = *reinterpret_cast<const float2*>(src); v[u].x = a.x; v[u].y = a.y; }
+                            if (col0 + 2 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + 2); v[u].z = a.x; v[u].w = a.y; }
                         } else {
-                            if (col0 >= 0 && col0 < g.W) v[u].x = src[col0];
-                            if (col0 + 1 >= 0 && col0 + 1 < g.W) v[u].y = src[col0 + 1];
-                            if (col0 + 2 >= 0 && col0 + 2 < g.W) v[u].z = src[col0 + 2];
-                            if (col0 + 3 >= 0 && col0 + 3 < g.W) v[u].w = src[col0 + 3];
+                            v[u].x = src[0];
+                            if (col0 + 1 < g.W) v[u].y = src[1];
+                            if (col0 + 2 < g.W) v[u].z = src[2];
+                            if (col0 + 3 < g.W) v[u].w = src[3];
                         }
                     }
                 }
@@ -109,85 +133,90 @@ __global__ __launch_bounds__(256) void eesp_dw_hff_kernel(const float* __restric
                 if (dsto[u] >= 0) *reinterpret_cast<float4*>(tile + dsto[u]) = v[u];
         }
     }
+    if (tid < nwts) wl[tid] = wreg;
+    if (tid < neps) el[tid] = ereg;
+    if (g.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
+    if (g.stamps) st2 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- compute: item = (plane p, band row ty, strip xs)
+    // ---- compute: item = (plane p, band row ty, strip xs); xs fastest so that lanes are 16 bytes apart
     const int rows_here = min(g.TH, g.Ho - y0);
     const int items = g.CP * rows_here * g.XS;
     const int hw = g.Ho * g.Wo;
-    const bool o4 = (g.Wo & 3) == 0;
+    const bool ovec = (g.Wo % OW) == 0;
+    const bool has_act = e.alpha != nullptr;
+    const size_t kstride = (size_t)g.n * hw * sizeof(float);
+    char* ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
+    const unsigned mag_rows = ((1u << 24) + (unsigned)rows_here - 1) / (unsigned)rows_here;   // uniform
     for (int it = tid; it < items; it += 256) {
-        const int xs = it % g.XS;
-        const int t2 = it / g.XS;
-        const int ty = t2 % rows_here;
-        const int p = t2 / rows_here;
-        const float* lp = tile + (size_t)p * g.RIN * g.LS + (size_t)(ty * STRIDE) * g.LS + xs * 4 * STRIDE;
-        float wr[36];
+        const int t2 = (int)(((unsigned)it * g.mag_xs) >> 24);
+        const int xs = it - t2 * g.XS;
+        const int p = (int)(((unsigned)t2 * mag_rows) >> 24);
+        const int ty = t2 - p * rows_here;
+        // window = LDS columns [4*xs, 4*xs + 12) = input columns [4*xs - 4, 4*xs + 8) of staged row ty*STRIDE + MAXD
+        const float* lp = tile + ((size_t)p * g.RIN + ty * STRIDE + MAXD) * g.LS + 4 * xs;
+        const float* wp = wl + p * 36;
+        const float* ep = el + p * 12;
+        const int xb = xs * OW;
+        // ONE 32-bit lane offset; the branch part of the address is uniform and goes in the scalar base
+        const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)(y0 + ty) * g.Wo + xb) * sizeof(float));
+        float prev[OW];
 #pragma unroll
-        for (int i = 0; i < 36; i += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(wl + p * 36 + i);
-            wr[i] = t.x; wr[i + 1] = t.y; wr[i + 2] = t.z; wr[i + 3] = t.w;
-        }
-        float acc[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
-
-#pragma unroll
-        for (int o = -MAXD; o <= MAXD; ++o) {
-            bool used = (o == 0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) used = used || (o == DS::d(k)) || (o == -DS::d(k));
-            if (!used) continue;
-            float rv[NR];
-            const float* row = lp + (size_t)(o + MAXD) * g.LS;
-#pragma unroll
-            for (int i = 0; i < NR; i += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(row + i);
-                rv[i] = t.x; rv[i + 1] = t.y; rv[i + 2] = t.z; rv[i + 3] = t.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                constexpr int dummy = 0; (void)dummy;
-                const int d = DS::d(k);
-                int ky = -1;
-                if (o == -d) ky = 0; else if (o == 0) ky = 1; else if (o == d) ky = 2;
-                if (ky < 0) continue;
-                const float w0 = wr[k * 9 + ky * 3 + 0], w1 = wr[k * 9 + ky * 3 + 1], w2 = wr[k * 9 + ky * 3 + 2];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ci = 4 + j * STRIDE;
-                    acc[k][j] = fmaf(w0, rv[ci - d], acc[k][j]);
-                    acc[k][j] = fmaf(w1, rv[ci], acc[k][j]);
-                    acc[k][j] = fmaf(w2, rv[ci + d], acc[k][j]);
-                }
-            }
-        }
-        // hierarchical feature fusion: out_k += out_{k-1}   (nn_layers/eesp.py:72-76)
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[k][j] += acc[k - 1][j];
-
-        const int y = y0 + ty, xb = xs * 4;
-        const int pix = y * g.Wo + xb;
+        for (int j = 0; j < OW; ++j) prev[j] = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int cabs = e.coff + k * g.n + c0 + p;
-            const EpiCh ec = epi_channel(e, cabs);
-            float v[4];
+            constexpr int dummy = 0; (void)dummy;
+            const int d = DS::d(k);
+            float a[OW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (xb + j < g.Wo) ? epi_apply(e, ec, acc[k][j], img, cabs, pix + j) : 0.f;
-            float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
-            if (o4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int j = 0; j < OW; ++j) a[j] = 0.f;
+            if (!g.nocompute) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* row = lp + (ky - 1) * d * g.LS;
+                    float rv[12];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float4 q = *reinterpret_cast<const float4*>(row + 4 * i);
+                        rv[4 * i] = q.x; rv[4 * i + 1] = q.y; rv[4 * i + 2] = q.z; rv[4 * i + 3] = q.w;
+                    }
+                    const float w0 = wp[k * 9 + ky * 3], w1 = wp[k * 9 + ky * 3 + 1], w2 = wp[k * 9 + ky * 3 + 2];
+#pragma unroll
+                    for (int j = 0; j < OW; ++j) {
+                        const int ci = 4 + j * STRIDE;
+                        a[j] = fmaf(w0, rv[ci - d], a[j]);
+                        a[j] = fmaf(w1, rv[ci], a[j]);
+                        a[j] = fmaf(w2, rv[ci + d], a[j]);
+                    }
+                }
+            }
+            // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
+            const float sc = ep[k * 3], sh = ep[k * 3 + 1], al = ep[k * 3 + 2];
+            float v[OW];
+#pragma unroll
+            for (int j = 0; j < OW; ++j) {
+                a[j] += prev[j];
+                prev[j] = a[j];
+                float q = fmaf(a[j], sc, sh);
+                if (has_act) q = q > 0.f ? q : al * q;
+                v[j] = q;
+            }
+            float* dst = reinterpret_cast<float*>(ob + k * kstride + voff);
+            if (ovec) {
+                if constexpr (OW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < OW; ++j)
                     if (xb + j < g.Wo) dst[j] = v[j];
             }
+            __builtin_amdgcn_sched_barrier(0);   // one branch at a time (keeps the register footprint small)
         }
+    }
+    if (g.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g.stamps + (size_t)blockIdx.x * 4;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -197,35 +226,72 @@ template <int STRIDE, class DS>
 static int launch(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out,
                   hipStream_t s) {
     constexpr int MAXD = DS::maxd();
+    constexpr int OW = 4 / STRIDE;
     DwGeom g;
+    memset(&g, 0, sizeof(g));
     g.N = N; g.n = n; g.H = H; g.W = W;
     g.Ho = (H - 1) / STRIDE + 1;
     g.Wo = (W - 1) / STRIDE + 1;
-    g.XS = ceil_div(g.Wo, 4);
-    g.LS = (STRIDE == 1) ? round_up4(W) + 8 : 2 * round_up4(g.Wo) + 8;
-    const size_t lds_budget = 40 * 1024;
+    g.XS = ceil_div(g.Wo, OW);
+    g.mag_xs = ((1u << 24) + (unsigned)g.XS - 1) / (unsigned)g.XS;
+    // row stride: >= 4 + W4 + 8 (window over-read), multiple of 4, and STRIDE*LS == 4*XS (mod 64 banks)
+    g.LS = round_up4(W) + 12;
+    {   // exact when 4*XS is a multiple of 4*STRIDE; otherwise the closest slip (4 floats) -- bounded search
+        int best_ls = g.LS, best_err = 1 << 30;
+        for (int cand = g.LS; cand < g.LS + 64; cand += 4) {
+            const int err = (STRIDE * cand - 4 * g.XS) & 63;
+            if (err < best_err) { best_err = err; best_ls = cand; }
+            if (err == 0) break;
+        }
+        g.LS = best_ls;
+    }
+    static const int dbg_nc = getenv("MSPL_DW_NOCOMPUTE") ? atoi(getenv("MSPL_DW_NOCOMPUTE")) : 0;
+    static const int dbg_lds = getenv("MSPL_DW_LDS") ? atoi(getenv("MSPL_DW_LDS")) : 0;     // KiB per workgroup
+    static const int dbg_cp = getenv("MSPL_DW_CP") ? atoi(getenv("MSPL_DW_CP")) : 0;
+    g.nocompute = dbg_nc;
+    static unsigned long long* stamp_buf = nullptr;
+    static const int dbg_stamp = getenv("MSPL_DW_STAMP") ? atoi(getenv("MSPL_DW_STAMP")) : 0;
+    if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)4 * 65536 * sizeof(unsigned long long));
+    // Tile = CP planes x one band.  Small tiles -> many workgroups per CU in different phases.
+    const size_t lds_budget = (size_t)(dbg_lds > 0 ? dbg_lds : 24) * 1024;
     auto rin_of = [&](int th) { return (th - 1) * STRIDE + 1 + 2 * MAXD; };
     int th = g.Ho;
     while (th > 1 && (size_t)rin_of(th) * g.LS * 4 > lds_budget) th = (th + 1) / 2;
-    MSPL_REQUIRE((size_t)rin_of(th) * g.LS * 4 + 144 <= 64 * 1024, MSPL_ERR_UNSUPPORTED,
+    MSPL_REQUIRE((size_t)rin_of(th) * g.LS * 4 + 512 <= 64 * 1024, MSPL_ERR_UNSUPPORTED,
                  "eesp_dw_hff: row of %d floats does not fit the LDS tile", W);
-    int cp = 1;
-    // small planes: several channels per workgroup so that 256 threads have work
-    while (cp * 2 <= 8 && n % (cp * 2) == 0 && th * g.XS * cp < 256 &&
-           (size_t)rin_of(th) * g.LS * 4 * (cp * 2) <= lds_budget)
-        cp *= 2;
+    const int bands = ceil_div(g.Ho, th);
+    int best_cp = 1;
+    double best = 1e30;
+    for (int cp = 1; cp <= 16; cp *= 2) {
+        if (n % cp || (size_t)rin_of(th) * g.LS * 4 * cp > lds_budget || cp * 36 > 256) break;
+        const int items = cp * th * g.XS;
+        const int64_t tiles = (int64_t)N * (n / cp) * bands;
+        const double waste = (double)(ceil_div(items, 256) * 256) / items;     // idle lanes in the item loop
+        const double starve = tiles >= 2048 ? 1.0 : 2048.0 / (double)tiles;    // too few workgroups to fill the chip
+        const double score = waste * starve;
+        if (score < best - 1e-9) { best = score; best_cp = cp; }
+    }
+    int cp = best_cp;
+    if (dbg_cp > 0 && n % dbg_cp == 0 && dbg_cp * 36 <= 256) cp = dbg_cp;
     g.TH = th; g.CP = cp;
     g.RIN = rin_of(th);
-    g.bands = ceil_div(g.Ho, th);
+    g.bands = bands;
     g.cgroups = n / cp;
-    int lg = 0;
-    while ((1 << lg) < (g.LS >> 2) && lg < 8) ++lg;
-    g.txl_log2 = lg;
-    const size_t lds = ((size_t)cp * g.RIN * g.LS + (size_t)cp * 36) * sizeof(float);
+    const size_t lds = ((size_t)cp * g.RIN * g.LS + 16 + (size_t)cp * 48) * sizeof(float);
     const int64_t blocks = (int64_t)N * g.cgroups * g.bands;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_dw_hff: grid too large");
+    g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
     hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, g, e, out);
     MSPL_CHECK_LAUNCH("eesp_dw_hff");
+    if (g.stamps) {   // debug only: synchronous dump of the phase timeline (100 MHz ticks)
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[4 * 65536];
+        (void)hipMemcpy(host, stamp_buf, (size_t)blocks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t3 = 0; double a = 0, b = 0, c = 0;
+        for (int64_t i = 0; i < blocks; ++i) { if (host[4*i] < t0) t0 = host[4*i]; if (host[4*i+3] > t3) t3 = host[4*i+3]; a += host[4*i+1]-host[4*i]; b += host[4*i+2]-host[4*i+1]; c += host[4*i+3]-host[4*i+2]; }
+        double late = 0; for (int64_t i = 0; i < blocks; ++i) late += host[4*i] - t0;
+        fprintf(stderr, "[k2 stamp] blocks=%lld span=%.2fus  avg: start-delay=%.2fus load+ldswrite=%.2fus barrier=%.2fus compute+store=%.2fus\n", (long long)blocks, (t3-t0)/100.0, late/blocks/100.0, a/blocks/100.0, b/blocks/100.0, c/blocks/100.0);
+    }
     return MSPL_OK;
 }
 
@@ -241,6 +307,8 @@ extern "C" int mspl_eesp_dw_hff_fwd(const float* x, const float* w, const int32_
                  "eesp_dw_hff: bad shape N=%d n=%d H=%d W=%d", N, n, H, W);
     MSPL_REQUIRE(stride == 1 || stride == 2, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: stride %d (1 or 2)", stride);
     if (int rc = check_epi(ep, 4 * n, "eesp_dw_hff")) return rc;
+    MSPL_REQUIRE(!ep || (!ep->pre_add && !ep->residual && !ep->reinf_r && !ep->gate), MSPL_ERR_UNSUPPORTED,
+                 "eesp_dw_hff: only scale/shift/alpha epilogue terms are supported (br_after_cat)");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const Epi e = make_epi(ep, 4 * n, Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
