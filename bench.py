@@ -141,28 +141,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (K2), HIP events on the launch stream, same K steps (eager so that
-    # every launch can be bracketed)
-    k2_events = []
+    # ---- roofline of the dominant kernel (K2): HIP events on the launch stream.  The 13 K2 launches of one
+    # forward are recorded (same tensors, same shapes), then each is re-issued REPS times back to back between one
+    # event pair while the stream is parked behind a spin kernel, so the interval is device execution (kernel +
+    # launch boundary), not the host's launch cadence.  avg launch = sum over the 13 shapes of (interval / REPS) / 13.
+    calls = []
     real = ops.eesp_dw_hff
 
-    def timed_k2(*a_, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    def record_k2(*a_, **kw):
         r = real(*a_, **kw)
-        e1.record()
-        k2_events.append((e0, e1))
+        calls.append((a_, dict(kw, out=(r, 0))))
         return r
     eager = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=False)
     from mspl_amd import layers as L
-    L.ops.eesp_dw_hff = timed_k2
+    L.ops.eesp_dw_hff = record_k2
     try:
-        for _ in range(min(args.steps, 20)):
-            eager(x)
+        eager(x)
         torch.cuda.synchronize()
     finally:
         L.ops.eesp_dw_hff = real
-    k2_ms = [e0.elapsed_time(e1) for e0, e1 in k2_events]
+    REPS = 20
+    k2_ms = []
+    for a_, kw in calls:
+        for _ in range(2):
+            real(*a_, **kw)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(2_000_000)
+            e0.record()
+            for _ in range(REPS):
+                real(*a_, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / REPS
+            best = t if best is None or t < best else best
+        k2_ms.append(best)
     k2_bytes, k2_launches = k2_algorithmic_bytes(model, BATCH, H, W)
     avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
     achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9

@@ -1,0 +1,84 @@
+"""One-process-per-GPU helpers (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+
+The reference's only multi-GPU mechanism is single-process nn.DataParallel (utilities/parallel_wrapper.py:17-106:
+per-step parameter broadcast, input scatter, gradient reduce to GPU 0).  Here weights stay resident on every rank:
+  * label pass  -- embarrassingly parallel over images (uest_seg_multi_os.py:849: batch_size=1, no cross-image state);
+                   the only exchange is the final sum of the class histogram (:887,920-921);
+  * train step  -- one all-reduce of a flat fp32 bucket holding the gradients of the parameters that actually receive
+                   gradients (340 of 570 tensors); loss = mean of per-rank means, which equals
+                   DataParallelCriteria + .mean() (utilities/train_eval_seg.py:202) for equal shards.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n_items, rank=None, world_size=None):
+    """Indices of the image list handled by this rank: i == rank (mod world), like a DistributedSampler without padding."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(range(rank, n_items, world_size))
+
+
+def reduce_histogram(hist):
+    """Sum the per-rank int64 class histograms in place (the label pass's only collective)."""
+    if world()[1] > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    return hist
+
+
+def gather_lists(local_items):
+    """Rank-ordered concatenation of per-rank python lists (image / label path lists of update_image_list)."""
+    _, w = world()
+    if w == 1:
+        return list(local_items)
+    out = [None] * w
+    dist.all_gather_object(out, list(local_items))
+    n = max(len(o) for o in out)
+    merged = []
+    for i in range(n):          # undo the i == rank (mod world) sharding
+        for o in out:
+            if i < len(o):
+                merged.append(o[i])
+    return merged
+
+
+class GradBucket:
+    """Flat fp32 gradient bucket over the parameters that receive gradients.
+
+    Call after the first backward (which reveals the unused parameters, exactly the set torch.optim.Adam skips):
+    `GradBucket(model.parameters())`.  The parameters' .grad tensors become views into one contiguous buffer, so
+    `all_reduce()` is a single collective (RCCL over xGMI on GPUs) and the optimizer can run on the flat views.
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad and p.grad is not None]
+        if not self.params:
+            raise RuntimeError('GradBucket: no parameter has a gradient yet (run one backward first)')
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            view = self.flat[off:off + k].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+            off += k
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self):
+        """Average the gradients over the ranks (sum / world): equals the reference's mean of per-replica mean losses."""
+        _, w = world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(w)
+        return self.flat
