@@ -165,6 +165,64 @@ int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64_t npix, in
                           int32_t thresh, int32_t fill, uint8_t* out, unsigned long long* hist,
                           void* stream);
 
+/* =============================================================================================
+ * Training step (uest_seg_multi_os.py:958-1089, BatchNorm frozen = eval mode).
+ * Backward of the forward ops above + K11 (loss) + Adam.  All gradients fp32, same layouts as the forward.
+ * ============================================================================================= */
+
+/* Data gradient of a bias-free grouped convolution (K in {1,3}, padding = dilation*(K-1)/2; the autograd backward
+ * of nn.Conv2d in espnet_utils.py / cnn_utils.py / efficient_pyramid_pool.py).  gy: (N,Cout,Ho,Wo)  w: (Cout,Cin/g,K,K)
+ * gx: (N,Cin,H,W), overwritten or accumulated into. */
+int mspl_conv_bwd_data(const float* gy, const float* w, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
+                       int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
+                       float* gx, void* stream);
+
+/* Weight gradient of the same convolution.  x: (N,Cin,H,W)  gw: (Cout,Cin/g,K,K). */
+int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
+                         int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
+                         float* gw, void* stream);
+
+/* Backward of y = PReLU((c + pre_add) * scale + shift + residual) (folded eval BatchNorm + PReLU, mspl_pointwise_fwd).
+ * Any of pre_add/residual/scale/shift/alpha may be NULL.  Outputs: gz = dL/d(pre-activation) (also the residual's
+ * gradient; may be NULL), gc = gz*scale (gradient of c and pre_add; may be NULL); gscale/gshift/galpha (C floats each,
+ * ACCUMULATED with atomics: caller zeroes; may be NULL). */
+int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy,
+                          const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
+                          int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha, void* stream);
+
+/* Backward of mspl_avgpool3x3s2_fwd (gather form, gx overwritten). */
+int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int32_t H, int32_t W, float* gx, void* stream);
+/* Backward of mspl_bilinear_fwd / mspl_adaptive_avgpool_fwd (atomic scatter: caller zero-fills gx). */
+int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                      float* gx, void* stream);
+int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                              float* gx, void* stream);
+
+/* out[i] = sum_p a[i,p] * b[i,p] over `planes` planes of HW elements (b NULL: plain sum).  Gate / GAP gradients. */
+int mspl_plane_dot(const float* a, const float* b, int32_t planes, int32_t HW, float* out, void* stream);
+/* gx[i,p] (+)= v[i] * mul. */
+int mspl_plane_broadcast(const float* v, int32_t planes, int32_t HW, float mul, int32_t accumulate, float* gx,
+                         void* stream);
+/* Backward of mspl_gap_gate_fwd's gate = sigmoid(W . mean): gw (Cout,Cin), gmean (N,Cin). */
+int mspl_gap_gate_bwd(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
+                      int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream);
+/* Backward of the hierarchical feature fusion of K2: out_k = sum_{j>=k} g_j over the 4 branch blocks of g (N,4n,HW);
+ * out is branch-major (4,N,n,HW). */
+int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream);
+
+/* K11  fused PixelwiseKLD + UncertaintyWeightedSegmentationLoss (loss_fns/segmentation_loss.py:146-189) as used at
+ *      uest_seg_multi_os.py:1020-1023:  loss = ce_scale * mean_pix(w[t] * -log_softmax(pred+0.5aux)[t] * exp(-kld))
+ *      + mean_pix(kld), kld NOT detached.  class_weights: C floats with the ignore class already zeroed; the mean runs
+ *      over ALL pixels.  loss_acc (1 float) is accumulated into (caller zeroes); gpred/gaux (N,C,HW) = d loss / d logits,
+ *      kld_out (N,HW) optional. */
+int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
+                         int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
+                         float* gaux, float* kld_out, void* stream);
+
+/* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
+int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,19 @@ SIGNATURES = {
                                c_f32p, _EP, c_f32p, ctypes.c_void_p],
     'mspl_label_epilogue_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                 ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
+    'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
+    'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
+    'mspl_avgpool3x3s2_bwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
+    'mspl_bilinear_bwd': [c_f32p] + [c_i32] * 6 + [c_f32p, ctypes.c_void_p],
+    'mspl_adaptive_avgpool_bwd': [c_f32p] + [c_i32] * 6 + [c_f32p, ctypes.c_void_p],
+    'mspl_plane_dot': [c_f32p, c_f32p, c_i32, c_i32, c_f32p, ctypes.c_void_p],
+    'mspl_plane_broadcast': [c_f32p, c_i32, c_i32, ctypes.c_float, c_i32, c_f32p, ctypes.c_void_p],
+    'mspl_gap_gate_bwd': [c_f32p] * 4 + [c_i32] * 3 + [c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_hff_suffix_sum': [c_f32p, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
+    'mspl_uw_loss_fwd_bwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p, c_i32, c_i32, c_i32, ctypes.c_float] + [c_f32p] * 4
+                            + [ctypes.c_void_p],
+    'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],
 }

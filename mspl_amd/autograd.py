@@ -1,0 +1,254 @@
+"""torch.autograd.Function wrappers: HIP forward + HIP backward for every op of the training step.
+
+Used when gradients are enabled (the uest self-training loop, uest_seg_multi_os.py:958-1089).  BatchNorm is frozen
+(eval mode, as in the reference's default run): it is a per-channel affine whose scale/shift are tiny differentiable
+expressions of gamma/beta and the running statistics, so gamma/beta still receive gradients.
+torch.cat / view / transpose in this path are pure data movement (no arithmetic).
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._native import check, lib
+from .ops import Epi, _p, _stream
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ConvFn(torch.autograd.Function):
+    """Bias-free grouped conv, K in {1,3} (dilation 1), stride 1|2."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, groups):
+        x, w = _c(x), _c(w)
+        k = w.shape[-1]
+        y = ops.conv1x1(x, w, groups) if k == 1 else ops.conv3x3(x, w, groups, stride)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride if k == 3 else 1, groups, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, groups, k = ctx.cfg
+        gy = _c(gy)
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gw), _stream()))
+        return gx, gw, None, None
+
+
+class EespDwFn(torch.autograd.Function):
+    """K2 without epilogue: 4 dilated depthwise 3x3 + hierarchical add + concat."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, w2, w3, dil, stride):
+        x = _c(x)
+        w4 = torch.stack([w.reshape(-1, 3, 3) for w in (w0, w1, w2, w3)]).contiguous()
+        y = ops.eesp_dw_hff(x, w4, dil, stride)
+        ctx.save_for_backward(x, w4)
+        ctx.cfg = (tuple(dil), stride, w0.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w4 = ctx.saved_tensors
+        dil, stride, wshape = ctx.cfg
+        gy = _c(gy)
+        N, n, H, W = x.shape
+        Ho, Wo = gy.shape[2:]
+        gs = torch.empty((4, N, n, Ho, Wo), device=x.device, dtype=torch.float32)
+        check(lib.mspl_hff_suffix_sum(_p(gy), N, n, Ho * Wo, _p(gs), _stream()))
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gws = []
+        for k in range(4):
+            gk, wk = gs[k], w4[k]
+            if gx is not None:
+                check(lib.mspl_conv_bwd_data(_p(gk), _p(wk), N, n, n, n, H, W, 3, stride, dil[k], 1 if k else 0, _p(gx), _stream()))
+            gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+            check(lib.mspl_conv_bwd_weight(_p(gk), _p(x), N, n, n, n, H, W, 3, stride, dil[k], 0, _p(gw), _stream()))
+            gws.append(gw)
+        return (gx, *gws, None, None)
+
+
+class AffinePReLUFn(torch.autograd.Function):
+    """y = PReLU((c + pre_add) * scale + shift + residual); any of scale/shift/alpha/pre_add/residual may be None."""
+
+    @staticmethod
+    def forward(ctx, c, scale, shift, alpha, pre_add, residual):
+        c = _c(c)
+        pre_add = None if pre_add is None else _c(pre_add)
+        residual = None if residual is None else _c(residual)
+        y = ops.pointwise(c, Epi(scale, shift, alpha, pre_add=pre_add, residual=residual))
+        ctx.save_for_backward(c, scale, shift, alpha, pre_add, residual)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        c, scale, shift, alpha, pre_add, residual = ctx.saved_tensors
+        gy = _c(gy)
+        N, C = c.shape[:2]
+        hw = c[0, 0].numel()
+        dev = c.device
+        gz = torch.empty_like(c) if residual is not None else None
+        gc = torch.empty_like(c)
+        gsc = torch.zeros(C, device=dev) if scale is not None else None
+        gsh = torch.zeros(C, device=dev) if shift is not None else None
+        gal = torch.zeros(C, device=dev) if alpha is not None else None
+        check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
+                                        _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
+        return gc, gsc, gsh, gal, (gc if pre_add is not None else None), gz
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.avgpool3x3s2(_c(x))
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
+        check(lib.mspl_avgpool3x3s2_bwd(_p(_c(gy)), N, C, H, W, _p(gx), _stream()))
+        return gx
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.shape = x.shape
+        return ops.bilinear(_c(x), size)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gx = torch.zeros(ctx.shape, device=gy.device, dtype=torch.float32)
+        check(lib.mspl_bilinear_bwd(_p(_c(gy)), N, C, H, W, gy.shape[2], gy.shape[3], _p(gx), _stream()))
+        return gx, None
+
+
+class AdaptivePoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.shape = x.shape
+        return ops.adaptive_avgpool(_c(x), size)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gx = torch.zeros(ctx.shape, device=gy.device, dtype=torch.float32)
+        check(lib.mspl_adaptive_avgpool_bwd(_p(_c(gy)), N, C, H, W, gy.shape[2], gy.shape[3], _p(gx), _stream()))
+        return gx, None
+
+
+class GapGateFn(torch.autograd.Function):
+    """gate = sigmoid(W . mean_hw(x)) -> (N, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _c(x), _c(w)
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        mean = torch.empty((N, Cin), device=x.device, dtype=torch.float32)
+        gate = torch.empty((N, Cout), device=x.device, dtype=torch.float32)
+        check(lib.mspl_gap_gate_fwd(_p(x), _p(w), N, Cin, Cout, H * W, _p(mean), _p(gate), _stream()))
+        ctx.save_for_backward(mean, gate, w)
+        ctx.shape = x.shape
+        return gate
+
+    @staticmethod
+    def backward(ctx, ggate):
+        mean, gate, w = ctx.saved_tensors
+        N, Cin, H, W = ctx.shape
+        Cout = w.shape[0]
+        gw = torch.empty_like(w)
+        gmean = torch.empty_like(mean)
+        check(lib.mspl_gap_gate_bwd(_p(_c(ggate)), _p(gate), _p(mean), _p(w), N, Cin, Cout, _p(gw), _p(gmean), _stream()))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(ctx.shape, device=w.device, dtype=torch.float32)
+            check(lib.mspl_plane_broadcast(_p(gmean), N * Cin, H * W, 1.0 / (H * W), 0, _p(gx), _stream()))
+        return gx, gw
+
+
+class ChannelScaleFn(torch.autograd.Function):
+    """y[n,c,:,:] * gate[n,c]."""
+
+    @staticmethod
+    def forward(ctx, y, gate):
+        y, gate = _c(y), _c(gate)
+        ctx.save_for_backward(y, gate)
+        return ops.pointwise(y, Epi(gate=gate))
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gate = ctx.saved_tensors
+        g = _c(g)
+        N, C = y.shape[:2]
+        hw = y[0, 0].numel()
+        gy = ops.pointwise(g, Epi(gate=gate))
+        ggate = torch.empty_like(gate)
+        check(lib.mspl_plane_dot(_p(g), _p(y), N * C, hw, _p(ggate), _stream()))
+        return gy, ggate
+
+
+class UWLossFn(torch.autograd.Function):
+    """K11: criterion(pred + 0.5*aux, target, kld) * ce_scale + kld.mean() with kld = PixelwiseKLD(pred, aux)."""
+
+    @staticmethod
+    def forward(ctx, pred, aux, target, class_weights, ce_scale):
+        pred, aux = _c(pred), _c(aux)
+        N, C = pred.shape[:2]
+        hw = pred[0, 0].numel()
+        target = _c(target.to(torch.int64))
+        loss = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        gpred, gaux = torch.empty_like(pred), torch.empty_like(aux)
+        check(lib.mspl_uw_loss_fwd_bwd(_p(pred), _p(aux), _p(target), _p(_c(class_weights.float())), N, C, hw, float(ce_scale),
+                                       _p(loss), _p(gpred), _p(gaux), None, _stream()))
+        ctx.save_for_backward(gpred, gaux)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gpred, gaux = ctx.saved_tensors
+        return gpred * g, gaux * g, None, None, None
+
+
+# functional spellings
+def conv(x, w, stride=1, groups=1):
+    return ConvFn.apply(x, w, stride, groups)
+
+
+def eesp_dw(x, ws, dil, stride):
+    return EespDwFn.apply(x, ws[0], ws[1], ws[2], ws[3], dil, stride)
+
+
+def affine_prelu(c, scale=None, shift=None, alpha=None, pre_add=None, residual=None):
+    return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual)
+
+
+def bn_affine(bn):
+    """Differentiable eval-mode BatchNorm fold: (scale, shift) as functions of gamma/beta (C-sized tensors)."""
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
+avgpool = AvgPoolFn.apply
+bilinear = BilinearFn.apply
+adaptive_avgpool = AdaptivePoolFn.apply
+gap_gate = GapGateFn.apply
+channel_scale = ChannelScaleFn.apply
+
+
+def uw_loss(pred, aux, target, class_weights, ce_scale=20.0):
+    return UWLossFn.apply(pred, aux, target, class_weights, ce_scale)

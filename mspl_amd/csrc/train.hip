@@ -1,0 +1,478 @@
+// Backward kernels, the fused uncertainty-weighted loss and Adam for one uest self-training step
+// (uest_seg_multi_os.py:958-1089: forward -> PixelwiseKLD -> UncertaintyWeightedSegmentationLoss*20 + kld.mean()
+//  -> backward -> torch.optim.Adam), BatchNorm frozen (eval mode, Appendix B-3 of SURVEY.md).
+//
+// Round-1 form: generic, direct and correct (gather-style data gradients, block-reduced weight gradients,
+// atomic scatter for the resampling ops).  They are native HIP behind the same C ABI; the specialised MFMA /
+// LDS-tiled versions of the hot ones (1x1 wgrad/dgrad, depthwise dilated dgrad) are the next optimisation step.
+#include "common.hpp"
+
+namespace mspl {
+
+struct ConvGeom {
+    int N, Cin, Cout, G, cin_g, cout_g, H, W, Ho, Wo, K, stride, dil, pad;
+};
+
+// ---- data gradient: gx[n,ci,iy,ix] = sum_{co in group, ky, kx} w[co,ci_g,ky,kx] * gy[n,co,oy,ox]
+//      with oy*stride = iy + pad - ky*dil (must divide), same for x.
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                            ConvGeom g, int accumulate, float* __restrict__ gx,
+                                                            int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % g.W);  int64_t t = idx / g.W;
+    const int iy = (int)(t % g.H);  t /= g.H;
+    const int ci = (int)(t % g.Cin);
+    const int n = (int)(t / g.Cin);
+    const int grp = ci / g.cin_g, cig = ci - grp * g.cin_g;
+    float acc = 0.f;
+    for (int ky = 0; ky < g.K; ++ky) {
+        const int ty = iy + g.pad - ky * g.dil;
+        if (ty < 0 || ty % g.stride) continue;
+        const int oy = ty / g.stride;
+        if (oy >= g.Ho) continue;
+        for (int kx = 0; kx < g.K; ++kx) {
+            const int tx = ix + g.pad - kx * g.dil;
+            if (tx < 0 || tx % g.stride) continue;
+            const int ox = tx / g.stride;
+            if (ox >= g.Wo) continue;
+            const float* gp = gy + (((size_t)n * g.Cout + (size_t)grp * g.cout_g) * g.Ho + oy) * (size_t)g.Wo + ox;
+            const float* wp = w + (((size_t)grp * g.cout_g) * g.cin_g + cig) * (size_t)(g.K * g.K) + ky * g.K + kx;
+            for (int co = 0; co < g.cout_g; ++co)
+                acc = fmaf(wp[(size_t)co * g.cin_g * g.K * g.K], gp[(size_t)co * g.Ho * g.Wo], acc);
+        }
+    }
+    if (accumulate) gx[idx] += acc; else gx[idx] = acc;
+}
+
+// ---- weight gradient: one workgroup per weight element, reduction over (n, oy, ox).
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                              ConvGeom g, int accumulate, float* __restrict__ gw) {
+    int b = blockIdx.x;
+    const int kx = b % g.K;  b /= g.K;
+    const int ky = b % g.K;  b /= g.K;
+    const int cig = b % g.cin_g;
+    const int co = b / g.cin_g;
+    const int grp = co / g.cout_g;
+    const int ci = grp * g.cin_g + cig;
+    const int npix = g.Ho * g.Wo;
+    const int64_t total = (int64_t)g.N * npix;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int n = (int)(i / npix), p = (int)(i - (int64_t)n * npix);
+        const int oy = p / g.Wo, ox = p - oy * g.Wo;
+        const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+        if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) continue;
+        acc = fmaf(gy[((size_t)n * g.Cout + co) * npix + p], x[(((size_t)n * g.Cin + ci) * g.H + iy) * (size_t)g.W + ix], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = (part[0] + part[1]) + (part[2] + part[3]);
+        if (accumulate) gw[blockIdx.x] += s; else gw[blockIdx.x] = s;
+    }
+}
+
+// ---- affine + PReLU backward.  Forward: z = (c + pre) * scale + shift + res ; y = z > 0 ? z : alpha * z.
+// Outputs gz (optional) and gc = gz * scale; per-channel sums into gscale / gshift / galpha (atomics; zeroed by caller).
+__global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __restrict__ c, const float* __restrict__ pre,
+                                                               const float* __restrict__ res, const float* __restrict__ gy,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ alpha, int C, int HW, int chunks,
+                                                               float* __restrict__ gz_out, float* __restrict__ gc_out,
+                                                               float* __restrict__ gscale, float* __restrict__ gshift,
+                                                               float* __restrict__ galpha) {
+    int b = blockIdx.x;
+    const int chunk = b % chunks;  b /= chunks;
+    const int ch = b % C;
+    const int n = b / C;
+    const float sc = scale ? scale[ch] : 1.f, sh = shift ? shift[ch] : 0.f;
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[ch] : 1.f;
+    const size_t base = ((size_t)n * C + ch) * (size_t)HW;
+    const int per = (HW + chunks - 1) / chunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const size_t o = base + p;
+        const float u = c[o] + (pre ? pre[o] : 0.f);
+        const float z = u * sc + sh + (res ? res[o] : 0.f);
+        const float g = gy[o];
+        const float gz = (!act || z > 0.f) ? g : al * g;
+        if (act && z <= 0.f) s_alpha += g * z;
+        s_scale += gz * u;
+        s_shift += gz;
+        if (gz_out) gz_out[o] = gz;
+        if (gc_out) gc_out[o] = gz * sc;
+    }
+    float v[3] = {s_scale, s_shift, s_alpha};
+    __shared__ float part[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (gscale) atomicAdd(&gscale[ch], (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+        if (gshift) atomicAdd(&gshift[ch], (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
+        if (galpha && act) atomicAdd(&galpha[ch], (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]));
+    }
+}
+
+// ---- resampling backward (atomic scatter of the output gradient; gx zeroed by the caller)
+struct RsG { int N, C, Hi, Wi, Ho, Wo; float sh, sw; };
+
+__global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % g.Wi);  int64_t t = idx / g.Wi;
+    const int iy = (int)(t % g.Hi);  t /= g.Hi;            // t = n*C + c
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    float acc = 0.f;                                         // gather: outputs whose 3x3/s2/p1 window covers (iy, ix)
+    for (int oy = max(0, iy / 2); oy <= min(g.Ho - 1, (iy + 1) / 2); ++oy) {
+        if (2 * oy - 1 > iy || 2 * oy + 1 < iy) continue;
+        for (int ox = max(0, ix / 2); ox <= min(g.Wo - 1, (ix + 1) / 2); ++ox) {
+            if (2 * ox - 1 > ix || 2 * ox + 1 < ix) continue;
+            acc += gp[(size_t)oy * g.Wo + ox];
+        }
+    }
+    gx[idx] = acc * (1.0f / 9.0f);
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % g.Wo);  int64_t t = idx / g.Wo;
+    const int oy = (int)(t % g.Ho);  t /= g.Ho;            // t = n*C + c
+    int y0, y1, x0, x1;  float wy0, wy1, wx0, wx1;
+    bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+    bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
+    const float v = gy[idx];
+    float* gp = gx + (size_t)t * g.Hi * g.Wi;
+    atomicAdd(&gp[(size_t)y0 * g.Wi + x0], v * wy0 * wx0);
+    atomicAdd(&gp[(size_t)y0 * g.Wi + x1], v * wy0 * wx1);
+    atomicAdd(&gp[(size_t)y1 * g.Wi + x0], v * wy1 * wx0);
+    atomicAdd(&gp[(size_t)y1 * g.Wi + x1], v * wy1 * wx1);
+}
+
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % g.Wo);  int64_t t = idx / g.Wo;
+    const int oy = (int)(t % g.Ho);  t /= g.Ho;
+    const int ys = (int)(((int64_t)oy * g.Hi) / g.Ho), ye = (int)((((int64_t)oy + 1) * g.Hi + g.Ho - 1) / g.Ho);
+    const int xs = (int)(((int64_t)ox * g.Wi) / g.Wo), xe = (int)((((int64_t)ox + 1) * g.Wi + g.Wo - 1) / g.Wo);
+    const float v = gy[idx] / (float)((ye - ys) * (xe - xs));
+    float* gp = gx + (size_t)t * g.Hi * g.Wi;
+    for (int iy = ys; iy < ye; ++iy)
+        for (int ix = xs; ix < xe; ++ix) atomicAdd(&gp[(size_t)iy * g.Wi + ix], v);
+}
+
+// ---- per-plane dot product: out[n*C + c] = sum_p a[n,c,p] * b[n,c,p]   (gate gradient; b == nullptr: plain sum)
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int HW,
+                                                        float* __restrict__ out) {
+    const size_t base = (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s = fmaf(a[base + i], b ? b[base + i] : 1.f, s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// ---- EfficientPWConv gate backward: gate = sigmoid(W . mean); given ggate (N,Cout):
+//      gs = ggate * gate * (1 - gate); gW[co,ci] = sum_n gs[n,co] * mean[n,ci]; gmean[n,ci] = sum_co gs[n,co] * W[co,ci]
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ggate, const float* __restrict__ gate,
+                                                       const float* __restrict__ mean, const float* __restrict__ w, int N,
+                                                       int Cin, int Cout, float* __restrict__ gw, float* __restrict__ gmean) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < Cout * Cin) {
+        const int co = idx / Cin, ci = idx - co * Cin;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float gt = gate[n * Cout + co];
+            s = fmaf(ggate[n * Cout + co] * gt * (1.f - gt), mean[n * Cin + ci], s);
+        }
+        gw[idx] = s;
+    }
+    if (idx < N * Cin) {
+        const int n = idx / Cin, ci = idx - n * Cin;
+        float s = 0.f;
+        for (int co = 0; co < Cout; ++co) {
+            const float gt = gate[n * Cout + co];
+            s = fmaf(ggate[n * Cout + co] * gt * (1.f - gt), w[co * Cin + ci], s);
+        }
+        gmean[idx] = s;
+    }
+}
+
+// ---- broadcast a per-plane value over the plane (gx = v[n*C+c] * mul), optionally accumulating
+__global__ __launch_bounds__(256) void plane_broadcast_kernel(const float* __restrict__ v, int HW, float mul, int accumulate,
+                                                              float* __restrict__ gx, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float val = v[idx / HW] * mul;
+    if (accumulate) gx[idx] += val; else gx[idx] = val;
+}
+
+// ---- K11: loss = 20 * mean_pix( -w[t] * log_softmax(pred + 0.5 aux)[t] * exp(-kld) ) + mean_pix(kld),
+//      kld = KL(softmax(pred) || softmax(aux)) per pixel (NOT detached: gradients flow through it, uest:1020-1023).
+//      One thread per pixel: forward terms and the closed-form gradients w.r.t. pred and aux.
+__global__ __launch_bounds__(256) void uw_loss_kernel(const float* __restrict__ pred, const float* __restrict__ aux,
+                                                      const int64_t* __restrict__ target, const float* __restrict__ cw,
+                                                      int N, int C, int HW, float ce_scale, float inv_npix,
+                                                      float* __restrict__ loss_acc, float* __restrict__ gpred,
+                                                      float* __restrict__ gaux, float* __restrict__ kld_out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * HW;
+    float contrib = 0.f;
+    if (idx < total) {
+        const int n = (int)(idx / HW), p = (int)(idx - (int64_t)n * HW);
+        const float* pp = pred + (size_t)n * C * HW + p;
+        const float* ap = aux + (size_t)n * C * HW + p;
+        float m1 = -INFINITY, m2 = -INFINITY, mo = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float a = pp[(size_t)c * HW], b = ap[(size_t)c * HW];
+            m1 = fmaxf(m1, a); m2 = fmaxf(m2, b); mo = fmaxf(mo, a + 0.5f * b);
+        }
+        float s1 = 0.f, s2 = 0.f, so = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float a = pp[(size_t)c * HW], b = ap[(size_t)c * HW];
+            s1 += expf(a - m1); s2 += expf(b - m2); so += expf(a + 0.5f * b - mo);
+        }
+        const float l1 = m1 + logf(s1), l2 = m2 + logf(s2), lo = mo + logf(so);
+        float kld = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float a = pp[(size_t)c * HW], b = ap[(size_t)c * HW];
+            const float p1 = expf(a - l1);
+            kld += p1 * (a - l1) - p1 * (b - l2);
+        }
+        const int t = (int)target[idx];
+        const float wt = (t >= 0 && t < C) ? cw[t] : 0.f;
+        const float ot = (t >= 0 && t < C) ? pp[(size_t)t * HW] + 0.5f * ap[(size_t)t * HW] : 0.f;
+        const float nll = -(ot - lo);                      // -log_softmax(o)[t]
+        const float u = expf(-kld);
+        const float ce = wt * nll * u;                     // per-pixel weighted CE
+        contrib = ce_scale * ce * inv_npix + kld * inv_npix;
+        if (kld_out) kld_out[idx] = kld;
+        if (gpred) {
+            // d loss / d kld = (1 - ce_scale * ce) / npix ; d ce / d o_c = wt * u * (softmax(o)_c - [c == t])
+            const float gk = (1.f - ce_scale * ce) * inv_npix;
+            const float go = ce_scale * wt * u * inv_npix;
+            for (int c = 0; c < C; ++c) {
+                const float a = pp[(size_t)c * HW], b = ap[(size_t)c * HW];
+                const float p1 = expf(a - l1), p2 = expf(b - l2), po = expf(a + 0.5f * b - lo);
+                const float d = (a - l1) - (b - l2);       // log p1 - log p2
+                const float dk_da = p1 * (d - kld);        // d kld / d pred_c
+                const float dk_db = p1 - p2;               // d kld / d aux_c   (= -(p1 - p2) * -1 ... see derivation)
+                const float dce = go * (po - (c == t ? 1.f : 0.f));
+                gpred[(size_t)n * C * HW + (size_t)c * HW + p] = dce + gk * dk_da;
+                gaux[(size_t)n * C * HW + (size_t)c * HW + p] = 0.5f * dce - gk * dk_db;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) contrib += __shfl_down(contrib, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// ---- Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias correction)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// ---- suffix sum over the 4 branch blocks of an (N, 4n, HW) gradient: out_k = sum_{j >= k} g_j  (HFF backward).
+//      Output is branch-major (4, N, n, HW) so that every branch is a contiguous (N, n, HW) tensor.
+__global__ __launch_bounds__(256) void hff_suffix_kernel(const float* __restrict__ g, int n, int HW, float* __restrict__ out,
+                                                         int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over N * n * HW
+    if (idx >= total) return;
+    const int64_t plane = (int64_t)n * HW;
+    const int64_t img = idx / plane, r = idx - img * plane;
+    const float* gp = g + img * 4 * plane + r;
+    const float g3 = gp[3 * plane], g2 = gp[2 * plane] + g3, g1 = gp[plane] + g2, g0 = gp[0] + g1;
+    out[idx] = g0; out[total + idx] = g1; out[2 * total + idx] = g2; out[3 * total + idx] = g3;
+}
+
+static int conv_geom(const char* who, int N, int Cin, int Cout, int groups, int H, int W, int K, int stride, int dil, ConvGeom& g) {
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && groups > 0 && H > 0 && W > 0, MSPL_ERR_BAD_SHAPE, "%s: bad shape", who);
+    MSPL_REQUIRE(Cin % groups == 0 && Cout % groups == 0, MSPL_ERR_BAD_SHAPE, "%s: channels not divisible by groups", who);
+    MSPL_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && dil >= 1, MSPL_ERR_UNSUPPORTED,
+                 "%s: kernel %d stride %d dilation %d", who, K, stride, dil);
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.cin_g = Cin / groups; g.cout_g = Cout / groups;
+    g.H = H; g.W = W; g.K = K; g.stride = stride; g.dil = dil; g.pad = dil * (K - 1) / 2;
+    g.Ho = (H + 2 * g.pad - dil * (K - 1) - 1) / stride + 1;
+    g.Wo = (W + 2 * g.pad - dil * (K - 1) - 1) / stride + 1;
+    return MSPL_OK;
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_conv_bwd_data(const float* gy, const float* w, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
+                                  int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
+                                  float* gx, void* stream) {
+    MSPL_REQUIRE(gy && w && gx, MSPL_ERR_NULL_POINTER, "conv_bwd_data: null pointer");
+    ConvGeom g;
+    if (int rc = conv_geom("conv_bwd_data", N, Cin, Cout, groups, H, W, K, stride, dilation, g)) return rc;
+    const int64_t total = (int64_t)N * Cin * H * W;
+    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_data: grid too large");
+    hipLaunchKernelGGL(conv_bwd_data_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, w, g,
+                       accumulate, gx, total);
+    MSPL_CHECK_LAUNCH("conv_bwd_data");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
+                                    int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
+                                    float* gw, void* stream) {
+    MSPL_REQUIRE(gy && x && gw, MSPL_ERR_NULL_POINTER, "conv_bwd_weight: null pointer");
+    ConvGeom g;
+    if (int rc = conv_geom("conv_bwd_weight", N, Cin, Cout, groups, H, W, K, stride, dilation, g)) return rc;
+    const int64_t blocks = (int64_t)Cout * g.cin_g * K * K;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_weight: grid too large");
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, x, g, accumulate, gw);
+    MSPL_CHECK_LAUNCH("conv_bwd_weight");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy,
+                                     const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
+                                     int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,
+                                     void* stream) {
+    MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
+    int chunks = 1;
+    while ((int64_t)N * C * chunks < 2048 && HW / (chunks * 2) >= 1024) chunks *= 2;
+    const int64_t blocks = (int64_t)N * C * chunks;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: grid too large");
+    hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, pre_add, residual, gy,
+                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha);
+    MSPL_CHECK_LAUNCH("affine_prelu_bwd");
+    return MSPL_OK;
+}
+
+static int rs_geom(const char* who, const float* gy, float* gx, int N, int C, int Hi, int Wi, int Ho, int Wo, RsG& g) {
+    MSPL_REQUIRE(gy && gx, MSPL_ERR_NULL_POINTER, "%s: null pointer", who);
+    MSPL_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, MSPL_ERR_BAD_SHAPE, "%s: bad shape", who);
+    g.N = N; g.C = C; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo;
+    g.sh = bilinear_scale(Hi, Ho); g.sw = bilinear_scale(Wi, Wo);
+    return MSPL_OK;
+}
+
+extern "C" int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int32_t H, int32_t W, float* gx, void* stream) {
+    RsG g;
+    if (int rc = rs_geom("avgpool3x3s2_bwd", gy, gx, N, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, g)) return rc;
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(avgpool3x3s2_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    MSPL_CHECK_LAUNCH("avgpool3x3s2_bwd");
+    return MSPL_OK;
+}
+
+/* gx must be zero-filled by the caller (atomic scatter). */
+extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                 float* gx, void* stream) {
+    RsG g;
+    if (int rc = rs_geom("bilinear_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
+    const int64_t total = (int64_t)N * C * Ho * Wo;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    MSPL_CHECK_LAUNCH("bilinear_bwd");
+    return MSPL_OK;
+}
+
+/* gx must be zero-filled by the caller (atomic scatter). */
+extern "C" int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                         float* gx, void* stream) {
+    RsG g;
+    if (int rc = rs_geom("adaptive_avgpool_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
+    const int64_t total = (int64_t)N * C * Ho * Wo;
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    MSPL_CHECK_LAUNCH("adaptive_avgpool_bwd");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_plane_dot(const float* a, const float* b, int32_t planes, int32_t HW, float* out, void* stream) {
+    MSPL_REQUIRE(a && out, MSPL_ERR_NULL_POINTER, "plane_dot: null pointer");
+    MSPL_REQUIRE(planes > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "plane_dot: bad shape");
+    hipLaunchKernelGGL(plane_dot_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, a, b, HW, out);
+    MSPL_CHECK_LAUNCH("plane_dot");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_plane_broadcast(const float* v, int32_t planes, int32_t HW, float mul, int32_t accumulate, float* gx,
+                                    void* stream) {
+    MSPL_REQUIRE(v && gx, MSPL_ERR_NULL_POINTER, "plane_broadcast: null pointer");
+    MSPL_REQUIRE(planes > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "plane_broadcast: bad shape");
+    const int64_t total = (int64_t)planes * HW;
+    hipLaunchKernelGGL(plane_broadcast_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, v, HW, mul,
+                       accumulate, gx, total);
+    MSPL_CHECK_LAUNCH("plane_broadcast");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_gap_gate_bwd(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
+                                 int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream) {
+    MSPL_REQUIRE(ggate && gate && mean && w && gw && gmean, MSPL_ERR_NULL_POINTER, "gap_gate_bwd: null pointer");
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0, MSPL_ERR_BAD_SHAPE, "gap_gate_bwd: bad shape");
+    const int n = max(Cout * Cin, N * Cin);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ggate, gate, mean, w, N,
+                       Cin, Cout, gw, gmean);
+    MSPL_CHECK_LAUNCH("gap_gate_bwd");
+    return MSPL_OK;
+}
+
+/* loss_acc (1 float, device) is ACCUMULATED into (caller zeroes).  gpred/gaux/kld_out may be NULL (forward only). */
+extern "C" int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
+                                    int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
+                                    float* gaux, float* kld_out, void* stream) {
+    MSPL_REQUIRE(pred && aux && target && class_weights && loss_acc, MSPL_ERR_NULL_POINTER, "uw_loss: null pointer");
+    MSPL_REQUIRE((gpred == nullptr) == (gaux == nullptr), MSPL_ERR_NULL_POINTER, "uw_loss: gpred and gaux go together");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "uw_loss: bad shape N=%d C=%d HW=%d", N, C, HW);
+    const int64_t total = (int64_t)N * HW;
+    hipLaunchKernelGGL(uw_loss_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, aux, target,
+                       class_weights, N, C, HW, ce_scale, 1.0f / (float)total, loss_acc, gpred, gaux, kld_out);
+    MSPL_CHECK_LAUNCH("uw_loss");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int32_t step, void* stream) {
+    MSPL_REQUIRE(p && g && m && v, MSPL_ERR_NULL_POINTER, "adam_step: null pointer");
+    MSPL_REQUIRE(n >= 0 && step >= 1, MSPL_ERR_BAD_SHAPE, "adam_step: n=%lld step=%d", (long long)n, step);
+    if (n == 0) return MSPL_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2s);
+    MSPL_CHECK_LAUNCH("adam_step");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream) {
+    MSPL_REQUIRE(g && out, MSPL_ERR_NULL_POINTER, "hff_suffix_sum: null pointer");
+    MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_suffix_sum: bad shape");
+    const int64_t total = (int64_t)N * n * HW;
+    hipLaunchKernelGGL(hff_suffix_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, g, n, HW, out, total);
+    MSPL_CHECK_LAUNCH("hff_suffix_sum");
+    return MSPL_OK;
+}

@@ -19,6 +19,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from .ops import Epi
 
@@ -27,8 +28,17 @@ PYR_SCALES = (2.0, 1.5, 1.0, 0.5, 0.1)
 
 
 # ------------------------------------------------------------------ caching helpers
+_PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    """Invalidate every cached fold / packed weight: call after parameters were modified through raw pointers
+    (the fused Adam kernel), which torch's version counters cannot see."""
+    _PARAM_EPOCH[0] += 1
+
+
 def _key(tensors):
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+    return (_PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in tensors)
 
 
 def cached(module, name, deps, builder):
@@ -60,10 +70,21 @@ def bn_fold(bn):
     return cached(bn, 'fold', [bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
 
 
-def _no_grad_only():
-    if torch.is_grad_enabled():
-        raise RuntimeError('mspl_amd: this forward path has no autograd support; wrap it in torch.no_grad() '
-                           '(training goes through mspl_amd.training)')
+def _training_path():
+    """True when gradients are enabled: the modules then run the autograd form (HIP forward + HIP backward per op,
+    mspl_amd/autograd.py) instead of the fused inference kernels."""
+    return torch.is_grad_enabled()
+
+
+def _conv_train(x, conv):
+    if conv.kernel_size[0] == 3 and conv.dilation[0] != 1:
+        raise RuntimeError('mspl_amd: dilated 3x3 convolutions only occur inside EESP (fused branch op)')
+    return ag.conv(x, conv.weight, conv.stride[0], conv.groups)
+
+
+def _bn_train(bn):
+    _require_eval(bn)
+    return ag.bn_affine(bn)
 
 
 def _conv_fwd(x, conv, ep, out=None, shuffle_groups=0):
@@ -86,7 +107,9 @@ class CBR(nn.Module):
         self.act = nn.PReLU(nOut)
 
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            scale, shift = _bn_train(self.bn)
+            return ag.affine_prelu(_conv_train(input, self.conv), scale, shift, self.act.weight)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift, self.act.weight))
 
@@ -98,7 +121,9 @@ class BR(nn.Module):
         self.act = nn.PReLU(nOut)
 
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            scale, shift = _bn_train(self.bn)
+            return ag.affine_prelu(input, scale, shift, self.act.weight)
         scale, shift = bn_fold(self.bn)
         return ops.pointwise(input, Epi(scale, shift, self.act.weight))
 
@@ -111,7 +136,9 @@ class CB(nn.Module):
         self.bn = nn.BatchNorm2d(nOut)
 
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            scale, shift = _bn_train(self.bn)
+            return ag.affine_prelu(_conv_train(input, self.conv), scale, shift)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift))
 
@@ -123,7 +150,8 @@ class C(nn.Module):
         self.conv = nn.Conv2d(nIn, nOut, kSize, stride=stride, padding=padding, bias=False, groups=groups)
 
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            return _conv_train(input, self.conv)
         return _conv_fwd(input, self.conv, None)
 
 
@@ -137,7 +165,8 @@ class CDilated(nn.Module):
                               groups=groups)
 
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            return _conv_train(input, self.conv)
         return _conv_fwd(input, self.conv, None)
 
 
@@ -158,7 +187,9 @@ class DecCBR(nn.Module):
         return Epi(scale, shift, self.cbr[2].weight, **kw)
 
     def forward(self, x):
-        _no_grad_only()
+        if _training_path():
+            scale, shift = _bn_train(self.cbr[1])
+            return ag.affine_prelu(_conv_train(x, self.cbr[0]), scale, shift, self.cbr[2].weight)
         return _conv_fwd(x, self.cbr[0], self.epi())
 
 
@@ -170,7 +201,9 @@ class DecBR(nn.Module):
         self.br = nn.Sequential(nn.BatchNorm2d(nOut), nn.PReLU(nOut))
 
     def forward(self, x):
-        _no_grad_only()
+        if _training_path():
+            scale, shift = _bn_train(self.br[0])
+            return ag.affine_prelu(x, scale, shift, self.br[1].weight)
         scale, shift = bn_fold(self.br[0])
         return ops.pointwise(x, Epi(scale, shift, self.br[1].weight))
 
@@ -225,8 +258,20 @@ class EESP(nn.Module):
         return ops.eesp_dw_hff(o1, self._dw_weights(), self.dilations, self.stride,
                                Epi(scale, shift, self.br_after_cat.act.weight))
 
+    def _forward_train(self, input):
+        o1 = self.proj_1x1(input)
+        cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
+        cat = self.br_after_cat(cat)
+        scale, shift = _bn_train(self.conv_1x1_exp.bn)
+        e = _conv_train(cat, self.conv_1x1_exp.conv)
+        if self.stride == 2 and self.downAvg:
+            return ag.affine_prelu(e, scale, shift)
+        residual = input if (self.stride == 1 and e.shape[1] == input.shape[1]) else None
+        return ag.affine_prelu(e, scale, shift, self.module_act.weight, residual=residual)
+
     def forward(self, input):
-        _no_grad_only()
+        if _training_path():
+            return self._forward_train(input)
         cat = self.reduce_transform(input)
         scale, shift = bn_fold(self.conv_1x1_exp.bn)
         if self.stride == 2 and self.downAvg:
@@ -292,8 +337,24 @@ class DownSampler(nn.Module):
             return scale.contiguous(), shift.contiguous(), rw
         return cached(self, 'epi%d' % int(with_reinf), deps, build)
 
+    def _forward_train(self, input, input2):
+        avg_out = ag.avgpool(input)
+        eesp_out = self.eesp(input)
+        out = torch.cat([avg_out, eesp_out], 1)           # data movement only
+        reinf = None
+        if input2 is not None:
+            with torch.no_grad():                          # the image carries no gradient
+                pyr = input2 if isinstance(input2, ImagePyramid) else ImagePyramid(input2)
+                img = pyr.at_height(out.shape[2])
+            if img.shape[3] != out.shape[3]:
+                raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton '
+                                   'dimension 3' % (out.shape[3], img.shape[3]))
+            reinf = self.inp_reinf(img)
+        return ag.affine_prelu(out, None, None, self.act.weight, residual=reinf)
+
     def forward(self, input, input2=None):
-        _no_grad_only()
+        if _training_path():
+            return self._forward_train(input, input2)
         N, _, H, W = input.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         out = torch.empty((N, self.nout, Ho, Wo), device=input.device, dtype=torch.float32)
@@ -393,8 +454,36 @@ class EfficientPyrPool(nn.Module):
         return ops.pyrpool_fused(x, sizes, stage_ws, down_es, bscale, bshift, br[1].weight, mcbr.cbr[0].weight,
                                  mcbr.epi())
 
+    def _forward_train(self, x):
+        x = self.projection_layer(x)
+        height, width = x.shape[2:]
+        P = self.proj_planes
+        hs = []
+        for stage, sc, (h_s, w_s) in zip(self.stages, self.scales, self.branch_sizes(height, width)):
+            if sc < 1.0:
+                h = ag.adaptive_avgpool(x, (h_s, w_s))
+                h = ag.conv(h, stage.weight, 1, P)
+                h = ag.bilinear(h, (height, width))
+            elif sc > 1.0:
+                h = ag.bilinear(x, (h_s, w_s))
+                h = ag.conv(h, stage.weight, 1, P)
+                h = ag.adaptive_avgpool(h, (height, width))
+            else:
+                h = ag.conv(x, stage.weight, 1, P)
+            hs.append(h)
+        out = self.merge_layer[0](torch.cat(hs, 1))        # BN+PReLU over the concatenation
+        out = self.merge_layer[1](out)                      # Shuffle: view/transpose copy
+        out = self.merge_layer[2](out)
+        conv = self.merge_layer[3]
+        c = ag.conv(out, conv.weight, 1, 1)
+        if self.last_layer_br:
+            scale, shift = _bn_train(self.br.br[0])
+            return ag.affine_prelu(c, scale, shift, self.br.br[1].weight)
+        return ag.affine_prelu(c, None, conv.bias, None)
+
     def forward(self, x, fused=True):
-        _no_grad_only()
+        if _training_path():
+            return self._forward_train(x)
         x = self.projection_layer(x)
         height, width = x.shape[2:]
         sizes = self.branch_sizes(height, width)
@@ -418,7 +507,9 @@ class EfficientPWConv(nn.Module):
         self.in_size = nin
 
     def forward(self, x):
-        _no_grad_only()
+        if _training_path():
+            gate = ag.gap_gate(x, self.wt_layer[1].weight)
+            return ag.channel_scale(self.expansion_layer(x), gate)
         gate = ops.gap_gate(x, self.wt_layer[1].weight)
         return ops.conv3x3(x, self.expansion_layer.cbr[0].weight, self.groups, ep=self.expansion_layer.epi(gate=gate))
 
@@ -429,9 +520,12 @@ class EfficientPWConv(nn.Module):
 def decoder_merge(pw_out, bu_lowres, br_seq):
     """bu_br(pw_out + upsample2(bu)): model/segmentation/espdnet_ue.py:276-280 in one kernel
     (bilinear x2, align_corners=True, pre-add, folded BN, PReLU)."""
-    scale, shift = bn_fold(br_seq[0])
     size = (bu_lowres.shape[2] * 2, bu_lowres.shape[3] * 2)
     if tuple(pw_out.shape[2:]) != size:
         raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 2'
                            % (pw_out.shape[2], size[0]))
+    if _training_path():
+        scale, shift = _bn_train(br_seq[0])
+        return ag.affine_prelu(ag.bilinear(bu_lowres, size), scale, shift, br_seq[1].weight, pre_add=pw_out)
+    scale, shift = bn_fold(br_seq[0])
     return ops.bilinear(bu_lowres, size, Epi(scale, shift, br_seq[1].weight, pre_add=pw_out))

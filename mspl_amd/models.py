@@ -19,7 +19,8 @@ from torch import nn
 from torch.nn import init
 
 from . import ops
-from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _no_grad_only,
+from . import autograd as ag
+from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path,
                      decoder_merge)
 
 sc_ch_dict = {
@@ -126,7 +127,7 @@ class _SegBase(nn.Module):
 
     def _encode(self, x, image_for_l2, l3_tail):
         b = self.base_net
-        pyr = ImagePyramid(x) if b.input_reinforcement else None
+        pyr = ImagePyramid(x.detach()) if b.input_reinforcement else None
         l1 = b.level1(x)
         l2 = b.level2_0(l1, pyr if image_for_l2 else None)
         l3 = b.level3_0(l2, pyr)
@@ -202,7 +203,6 @@ class ESPDNetwithUncertaintyEstimation(_SegBase):
 
     def forward_lowres(self, x, x_d=None):
         """(main at H/2 x W/2, aux at H/4 x W/4 for aux_layer=2): decoder outputs before espdnet_ue.py:301-302."""
-        _no_grad_only()
         if x_d is not None:
             raise NotImplementedError('mspl_amd: the depth branch (x_d) is outside the hot path (use_depth=False in every '
                                       'multi-source script)')
@@ -213,6 +213,8 @@ class ESPDNetwithUncertaintyEstimation(_SegBase):
 
     def forward(self, x, x_d=None):
         main, aux = self.forward_lowres(x, x_d)
+        if _training_path():
+            return ag.bilinear(main, tuple(x.shape[2:])), ag.bilinear(aux, tuple(x.shape[2:]))
         r = ops.label_epilogue(main, aux, x.shape[2:], want_labels=False, want_logits=True)
         return r['main_up'], r['aux_up']
 
@@ -227,7 +229,6 @@ class ESPNetv2Segmentation(_SegBase):
         self.classes = classes
 
     def forward_lowres(self, x):
-        _no_grad_only()
         _check_input(x)
         # level2_0 is called WITHOUT the image (espnetv2.py:127)
         l1, l2, l3, l4 = self._encode(x, False, self.base_net.level3)
@@ -235,6 +236,8 @@ class ESPNetv2Segmentation(_SegBase):
 
     def forward(self, x):
         main, _ = self.forward_lowres(x)
+        if _training_path():
+            return ag.bilinear(main, tuple(x.shape[2:]))
         return ops.bilinear(main, x.shape[2:])
 
 

@@ -1,0 +1,95 @@
+"""One uest self-training step on the HIP path (uest_seg_multi_os.py:958-1089, train()).
+
+    (pred, aux) = model(images)                               # frozen BatchNorm (model.eval(), Appendix B-3)
+    kld  = PixelwiseKLD()(pred, aux)                          # NOT detached
+    loss = criterion(pred + 0.5*aux, labels, kld) * 20 + kld.mean()
+    loss.backward(); optimizer.step()                         # Adam over model.parameters(), weight decay as L2
+
+`uest_loss` is K11 (one fused forward+backward kernel); `FlatAdam` keeps every gradient-bearing parameter, its
+gradient and the two Adam moments in four flat fp32 buffers, so the optimizer is ONE kernel and the multi-GPU
+gradient exchange ONE all-reduce (mspl_amd.dist).  Parameters whose gradient stays None (depth encoder, fusion gates,
+module_act of strided EESPs: 230 of 570 tensors) are left out, exactly like torch.optim.Adam skips them.
+"""
+import ctypes
+
+import torch
+
+from . import autograd as ag
+from . import dist as mdist
+from . import layers
+from ._native import check, lib
+from .ops import _p, _stream
+
+
+def uest_loss(pred, aux, labels, class_weights, ignore_idx=None, ce_scale=20.0):
+    """criterion(pred + 0.5*aux, labels, kld)*ce_scale + kld.mean() with kld = PixelwiseKLD(pred, aux).
+    class_weights: tensor of num_classes weights; class_weights[ignore_idx] is treated as 0 (the reference zeroes it
+    in place at construction, loss_fns/segmentation_loss.py:152-153)."""
+    cw = class_weights.detach().to(pred.device, torch.float32).clone()
+    if ignore_idx is not None:
+        cw[ignore_idx] = 0.0
+    return ag.uw_loss(pred, aux, labels, cw, ce_scale)
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (lr, betas, eps, L2 weight_decay, bias correction) on flat buffers.
+
+    Build it AFTER the first backward: the parameters that received a gradient define the flat layout.  Parameter
+    .data and .grad are re-pointed to views of the flat buffers (values preserved)."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad and p.grad is not None]
+        if not self.params:
+            raise RuntimeError('FlatAdam: run one backward before constructing the optimizer (no parameter has a gradient)')
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                pv, gv = self.flat_p[off:off + k].view_as(p), self.flat_g[off:off + k].view_as(p)
+                pv.copy_(p.data)
+                gv.copy_(p.grad)
+                p.data = pv
+                p.grad = gv
+                off += k
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def all_reduce_grads(self):
+        """Average gradients over the ranks: one collective on the flat bucket (RCCL over xGMI on GPUs)."""
+        _, w = mdist.world()
+        if w > 1:
+            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM)
+            self.flat_g.div_(w)
+
+    def step(self):
+        self.step_count += 1
+        check(lib.mspl_adam_step(_p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), self.flat_p.numel(),
+                                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                 float(self.weight_decay), self.step_count, _stream()))
+        layers.bump_param_epoch()       # the kernel wrote through raw pointers: invalidate folded-BN / packed-weight caches
+
+
+def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=None, lr=5e-4, weight_decay=5e-4,
+               ce_scale=20.0):
+    """One optimisation step; returns (loss tensor, optimizer).  Pass optimizer=None on the first call: it is built
+    after the first backward (which reveals the gradient-bearing parameters)."""
+    if optimizer is not None:
+        optimizer.zero_grad()
+    with torch.enable_grad():
+        pred, aux = model(images)
+        loss = uest_loss(pred, aux, labels, class_weights, ignore_idx, ce_scale)
+        loss.backward()
+    if optimizer is None:
+        optimizer = FlatAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    optimizer.all_reduce_grads()
+    optimizer.step()
+    return loss.detach(), optimizer

@@ -1,0 +1,172 @@
+"""Training-step parity on the GPU: autograd Functions (HIP forward + HIP backward) against torch-CPU autograd of the
+oracle, and one full uest self-training step against the reference's own golden (loss, per-parameter gradient norms,
+which parameters receive no gradient, parameters after one Adam step)."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import labels as olab
+from tests.cases import TRAIN_CASE
+from tests.conftest import GOLDEN
+from tests.synth import synth_input, synth_labels, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def grads_of(fn, inputs, seed=99):
+    outs = fn(*inputs)
+    go = rnd(*outs.shape, seed=seed).to(outs.device)
+    return outs, torch.autograd.grad(outs, [i for i in inputs if i.requires_grad], go, allow_unused=True)
+
+
+def check_op(gpu_fn, cpu_fn, tensors, atol=2e-4, rtol=2e-3):
+    cpu_in = [t.clone().requires_grad_(t.is_floating_point()) for t in tensors]
+    gpu_in = [t.clone().to(DEV).requires_grad_(t.is_floating_point()) for t in tensors]
+    yc, gc = grads_of(cpu_fn, cpu_in)
+    yg, gg = grads_of(gpu_fn, gpu_in)
+    torch.testing.assert_close(yg.detach().cpu(), yc.detach(), rtol=1e-4, atol=5e-5)
+    for a, b in zip(gg, gc):
+        torch.testing.assert_close(a.cpu(), b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 24, 4, 9, 13, 1, 1), (1, 64, 64, 4, 6, 10, 1, 1), (2, 3, 8, 1, 12, 16, 3, 2),
+                                 (1, 16, 16, 16, 11, 9, 3, 1), (1, 20, 4, 4, 7, 7, 3, 1), (1, 24, 12, 4, 8, 8, 3, 2)])
+def test_conv_fn(cfg):
+    from mspl_amd import autograd as ag
+    N, ci, co, g, h, w, k, s = cfg
+    x, wt = rnd(N, ci, h, w, seed=1), rnd(co, ci // g, k, k, seed=2, scale=0.3)
+    check_op(lambda a, b: ag.conv(a, b, s, g), lambda a, b: F.conv2d(a, b, None, s, (k - 1) // 2, 1, g), [x, wt])
+
+
+@pytest.mark.parametrize('dil,stride,shape', [([1, 2, 3, 4], 1, (2, 8, 12, 20)), ([1, 1, 2, 3], 1, (1, 16, 9, 15)),
+                                              ([1, 2, 3, 4], 2, (2, 4, 16, 24)), ([1, 2, 3, 4], 2, (1, 8, 15, 21))])
+def test_eesp_dw_fn(dil, stride, shape):
+    from mspl_amd import autograd as ag
+    N, n, h, w = shape
+    x = rnd(*shape, seed=1)
+    ws = [rnd(n, 1, 3, 3, seed=10 + k, scale=0.3) for k in range(4)]
+
+    def cpu(a, w0, w1, w2, w3):
+        outs = []
+        for k, wk in enumerate((w0, w1, w2, w3)):
+            o = F.conv2d(a, wk, None, stride, dil[k], dil[k], n)
+            outs.append(o if k == 0 else o + outs[-1])
+        return torch.cat(outs, 1)
+    check_op(lambda a, w0, w1, w2, w3: ag.eesp_dw(a, [w0, w1, w2, w3], dil, stride), cpu, [x] + ws)
+
+
+def test_affine_prelu_fn():
+    from mspl_amd import autograd as ag
+    c, pre, res = rnd(2, 6, 9, 11, seed=1), rnd(2, 6, 9, 11, seed=2), rnd(2, 6, 9, 11, seed=3)
+    sc, sh, al = rnd(6, seed=4).abs() + 0.5, rnd(6, seed=5), rnd(6, seed=6).abs() * 0.3
+    cpu = lambda c_, sc_, sh_, al_, pre_, res_: F.prelu((c_ + pre_) * sc_.view(1, -1, 1, 1) + sh_.view(1, -1, 1, 1) + res_, al_)
+    check_op(lambda *a: ag.affine_prelu(*a), cpu, [c, sc, sh, al, pre, res])
+    # no activation / no scale
+    check_op(lambda c_, sh_: ag.affine_prelu(c_, None, sh_, None), lambda c_, sh_: c_ + sh_.view(1, -1, 1, 1), [c, sh])
+
+
+def test_resample_fns():
+    from mspl_amd import autograd as ag
+    x = rnd(2, 3, 15, 21, seed=1)
+    check_op(lambda a: ag.avgpool(a), lambda a: F.avg_pool2d(a, 3, 2, 1), [x])
+    check_op(lambda a: ag.bilinear(a, (30, 42)), lambda a: F.interpolate(a, (30, 42), mode='bilinear', align_corners=True), [x])
+    check_op(lambda a: ag.bilinear(a, (7, 9)), lambda a: F.interpolate(a, (7, 9), mode='bilinear', align_corners=True), [x])
+    check_op(lambda a: ag.adaptive_avgpool(a, (5, 5)), lambda a: F.adaptive_avg_pool2d(a, (5, 5)), [x])
+    check_op(lambda a: ag.adaptive_avgpool(a, (10, 14)), lambda a: F.adaptive_avg_pool2d(a, (10, 14)), [x])
+
+
+def test_gate_fns():
+    from mspl_amd import autograd as ag
+    x, w = rnd(2, 8, 7, 9, seed=1), rnd(6, 8, 1, 1, seed=2)
+    y = rnd(2, 6, 7, 9, seed=3)
+
+    def cpu(a, b, c):
+        return c * torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(a, 1), b))
+    check_op(lambda a, b, c: ag.channel_scale(c, ag.gap_gate(a, b)), cpu, [x, w, y])
+
+
+def test_uw_loss_vs_reference_golden(golden):
+    from mspl_amd import training
+    g = golden('loss')
+    pred = (synth_input((2, 5, 32, 48), 90) * 2).to(DEV).requires_grad_(True)
+    aux = (synth_input((2, 5, 32, 48), 91) * 2).to(DEV).requires_grad_(True)
+    tgt = synth_labels((2, 32, 48), 5, 92).to(DEV)
+    loss = training.uest_loss(pred, aux, tgt, torch.from_numpy(g['cw']), ignore_idx=4)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), torch.from_numpy(g['loss']), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pred.grad.cpu(), torch.from_numpy(g['dpred']), rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(aux.grad.cpu(), torch.from_numpy(g['daux']), rtol=1e-3, atol=1e-8)
+
+
+def test_train_step_vs_reference_golden(golden):
+    """ESPDNet-UE C=5, frozen BN, one Adam step: loss, gradient norms, the 230 gradient-less tensors, updated weights."""
+    from mspl_amd import models, training
+    c = TRAIN_CASE
+    g = golden('train_step')
+    a = argparse.Namespace(s=c['s'], channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=c['classes'], dataset=c['dataset'], fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(KEYS['espdnetue_s%s_c%d' % (c['s'], c['classes'])], c['sd_seed']))
+    m = m.to(DEV).eval()
+    x = synth_input(c['shape'], c['in_seed']).to(DEV)
+    labels = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed']).to(DEV)
+    with torch.enable_grad():
+        pred, aux = m(x)
+        loss = training.uest_loss(pred, aux, labels, torch.ones(c['classes']), ignore_idx=c['ignore_idx'])
+        loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), torch.from_numpy(g['loss']), rtol=2e-5, atol=1e-5)
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g['names']]
+    assert names == list(params.keys())
+    n_with = 0
+    for n, gn in zip(names, g['gnorm']):
+        p = params[n]
+        if gn < 0:
+            assert p.grad is None, '%s should not receive a gradient' % n
+        else:
+            n_with += 1
+            assert p.grad is not None, n
+            got = float(p.grad.double().norm())
+            assert abs(got - gn) <= 5e-3 * gn + 1e-6, (n, got, gn)
+    assert n_with == 340
+    opt = training.FlatAdam(m.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
+    assert len(opt.params) == 340 and opt.flat_p.numel() == sum(p.numel() for p in opt.params)
+    opt.step()
+    torch.cuda.synchronize()
+    for i, k in enumerate(str(s) for s in g['keep']):
+        torch.testing.assert_close(params[k].detach().cpu(), torch.from_numpy(g['after_%d' % i]), rtol=1e-4, atol=2e-6)
+    # the step went through raw pointers: inference caches must notice
+    with torch.no_grad():
+        y1 = m(x)[0]
+    opt.step()
+    with torch.no_grad():
+        y2 = m(x)[0]
+    assert not torch.equal(y1, y2)
+
+
+def test_second_step_and_train_step_helper():
+    from mspl_amd import models, training
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(KEYS['espdnetue_s2.0_c5'], 3))
+    m = m.to(DEV).eval()
+    x = synth_input((2, 3, 32, 48), 8).to(DEV)
+    y = synth_labels((2, 32, 48), 5, 8).to(DEV)
+    cw = torch.ones(5)
+    l0, opt = training.train_step(m, x, y, cw, None, ignore_idx=4, lr=2e-3)
+    losses = [float(l0)]
+    for _ in range(5):
+        l, opt = training.train_step(m, x, y, cw, opt, ignore_idx=4)
+        losses.append(float(l))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses      # same batch: the loss must go down
