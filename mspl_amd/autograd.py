@@ -39,8 +39,19 @@ class ConvFn(torch.autograd.Function):
         Cout = w.shape[0]
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
+            if stride == 1:
+                # the data gradient of a stride-1 convolution is a convolution with the transposed (and, for 3x3,
+                # spatially flipped) weights: run it on the forward kernels (MFMA 1x1 / LDS-tiled 3x3).  The weight
+                # repack is a tiny permute copy (data movement).
+                cg_in, cg_out = Cin // groups, Cout // groups
+                wt = w.view(groups, cg_out, cg_in, k, k).transpose(1, 2)
+                if k == 3:
+                    wt = wt.flip(3, 4)
+                wt = wt.reshape(Cin, cg_out, k, k).contiguous()
+                gx = ops.conv1x1(gy, wt, groups) if k == 1 else ops.conv3x3(gy, wt, groups, 1)
+            else:
+                gx = torch.empty_like(x)
+                check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gw), _stream()))
@@ -132,7 +143,7 @@ class BilinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         N, C, H, W = ctx.shape
-        gx = torch.zeros(ctx.shape, device=gy.device, dtype=torch.float32)
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
         check(lib.mspl_bilinear_bwd(_p(_c(gy)), N, C, H, W, gy.shape[2], gy.shape[3], _p(gx), _stream()))
         return gx, None
 

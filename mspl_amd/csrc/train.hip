@@ -45,10 +45,13 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(const float* __restr
     if (accumulate) gx[idx] += acc; else gx[idx] = acc;
 }
 
-// ---- weight gradient: one workgroup per weight element, reduction over (n, oy, ox).
+// ---- weight gradient, generic: one workgroup per (weight element, pixel chunk); partial sums are combined with
+//      float atomics (gw zero-filled by the launcher unless accumulating).
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                              ConvGeom g, int accumulate, float* __restrict__ gw) {
+                                                              ConvGeom g, int chunks, float* __restrict__ gw) {
     int b = blockIdx.x;
+    const int chunk = b % chunks;  b /= chunks;
+    const int widx = b;
     const int kx = b % g.K;  b /= g.K;
     const int ky = b % g.K;  b /= g.K;
     const int cig = b % g.cin_g;
@@ -57,8 +60,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __res
     const int ci = grp * g.cin_g + cig;
     const int npix = g.Ho * g.Wo;
     const int64_t total = (int64_t)g.N * npix;
+    const int64_t per = (total + chunks - 1) / chunks;
+    const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < total; i += 256) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const int n = (int)(i / npix), p = (int)(i - (int64_t)n * npix);
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
         const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
@@ -70,10 +75,53 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __res
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float s = (part[0] + part[1]) + (part[2] + part[3]);
-        if (accumulate) gw[blockIdx.x] += s; else gw[blockIdx.x] = s;
+    if (threadIdx.x == 0) atomicAdd(&gw[widx], (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// ---- weight gradient of a grouped 1x1 convolution: gw[co, ci] = sum_{n,p} gy[n,co,p] * x[n,ci,p].
+//      A workgroup owns a 16 x 16 tile of one group's (co, ci) pairs and a chunk of pixels; both operand tiles
+//      (16 rows x 256 pixels) are staged in LDS with coalesced loads, each thread reduces one (co, ci) pair over the
+//      staged pixels (row reads are LDS broadcasts / conflict-free), partial sums combined with float atomics.
+__global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                 ConvGeom g, int chunks, int tiles_m, int tiles_k,
+                                                                 float* __restrict__ gw) {
+    __shared__ float A[16][260];      // gy rows (co), 256 pixels (+4 pad: rows land on different banks)
+    __shared__ float B[16][260];      // x rows (ci)
+    int b = blockIdx.x;
+    const int chunk = b % chunks;  b /= chunks;
+    const int tk = b % tiles_k;  b /= tiles_k;
+    const int tm = b % tiles_m;
+    const int grp = b / tiles_m;
+    const int M = g.cout_g, K = g.cin_g, HW = g.Ho * g.Wo;
+    const int m0 = tm * 16, k0 = tk * 16;
+    const int tid = threadIdx.x;
+    const int tmi = tid >> 4, tki = tid & 15;      // this thread's (co, ci) pair inside the tile
+    const int64_t total = (int64_t)g.N * HW;
+    const int64_t per = ((total + chunks - 1) / chunks + 255) / 256 * 256;
+    const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
+    float acc = 0.f;
+    for (int64_t base = i0; base < i1; base += 256) {
+        // stage: thread t loads pixel base+t of 16 rows of each operand (coalesced along pixels)
+        const int64_t i = base + tid;
+        const bool ok = i < i1;
+        const int n = ok ? (int)(i / HW) : 0, p = ok ? (int)(i - (int64_t)n * HW) : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + r, ci = k0 + r;
+            A[r][tid] = (ok && co < M) ? gy[((size_t)n * g.Cout + (size_t)grp * M + co) * HW + p] : 0.f;
+            B[r][tid] = (ok && ci < K) ? x[((size_t)n * g.Cin + (size_t)grp * K + ci) * HW + p] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 256; q += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&A[tmi][q]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&B[tki][q]);
+            acc = fmaf(a4.x, b4.x, acc); acc = fmaf(a4.y, b4.y, acc); acc = fmaf(a4.z, b4.z, acc); acc = fmaf(a4.w, b4.w, acc);
+        }
+        __syncthreads();
     }
+    if (m0 + tmi < M && k0 + tki < K)
+        atomicAdd(&gw[((size_t)grp * M + m0 + tmi) * K + k0 + tki], acc);
 }
 
 // ---- affine + PReLU backward.  Forward: z = (c + pre) * scale + shift + res ; y = z > 0 ? z : alpha * z.
@@ -144,20 +192,34 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __re
     gx[idx] = acc * (1.0f / 9.0f);
 }
 
+// Gather form (deterministic, no atomics): one thread per INPUT pixel, loops over the output rows/columns whose
+// two bilinear sources include it.  Output y uses source rows floor(y*sh) and +1, so the candidates for input row iy
+// are y in [ceil((iy-1)/sh), floor((iy+1)/sh)] (clamped); same along x.
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int ox = (int)(idx % g.Wo);  int64_t t = idx / g.Wo;
-    const int oy = (int)(t % g.Ho);  t /= g.Ho;            // t = n*C + c
-    int y0, y1, x0, x1;  float wy0, wy1, wx0, wx1;
-    bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
-    bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
-    const float v = gy[idx];
-    float* gp = gx + (size_t)t * g.Hi * g.Wi;
-    atomicAdd(&gp[(size_t)y0 * g.Wi + x0], v * wy0 * wx0);
-    atomicAdd(&gp[(size_t)y0 * g.Wi + x1], v * wy0 * wx1);
-    atomicAdd(&gp[(size_t)y1 * g.Wi + x0], v * wy1 * wx0);
-    atomicAdd(&gp[(size_t)y1 * g.Wi + x1], v * wy1 * wx1);
+    const int ix = (int)(idx % g.Wi);  int64_t t = idx / g.Wi;
+    const int iy = (int)(t % g.Hi);  t /= g.Hi;            // t = n*C + c
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    int ylo = 0, yhi = g.Ho - 1, xlo = 0, xhi = g.Wo - 1;
+    if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
+    if (g.sw > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)ceilf((float)(ix + 1) / g.sw) + 1); }
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        int y0, y1;  float wy0, wy1;
+        bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+        const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+        if (wy == 0.f) continue;
+        float rowacc = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            int x0, x1;  float wx0, wx1;
+            bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
+            const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+            if (wx != 0.f) rowacc = fmaf(wx, gp[(size_t)oy * g.Wo + ox], rowacc);
+        }
+        acc = fmaf(wy, rowacc, acc);
+    }
+    gx[idx] = acc;
 }
 
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
@@ -349,9 +411,29 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
     MSPL_REQUIRE(gy && x && gw, MSPL_ERR_NULL_POINTER, "conv_bwd_weight: null pointer");
     ConvGeom g;
     if (int rc = conv_geom("conv_bwd_weight", N, Cin, Cout, groups, H, W, K, stride, dilation, g)) return rc;
-    const int64_t blocks = (int64_t)Cout * g.cin_g * K * K;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nw = (int64_t)Cout * g.cin_g * K * K;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(gw, 0, (size_t)nw * sizeof(float), s);      // async memset node: graph-capturable
+        MSPL_REQUIRE(e == hipSuccess, MSPL_ERR_HIP, "conv_bwd_weight: memset failed: %s", hipGetErrorString(e));
+    }
+    const int64_t total = (int64_t)N * g.Ho * g.Wo;
+    if (K == 1 && g.cin_g >= 4 && g.cout_g >= 4) {
+        const int tiles_m = ceil_div(g.cout_g, 16), tiles_k = ceil_div(g.cin_g, 16);
+        int64_t base = (int64_t)groups * tiles_m * tiles_k;
+        int chunks = 1;
+        while (base * chunks < 2048 && total / (chunks * 2) >= 1024) chunks *= 2;
+        const int64_t blocks = base * chunks;
+        MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_weight: grid too large");
+        hipLaunchKernelGGL(conv1x1_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, chunks, tiles_m, tiles_k, gw);
+        MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
+        return MSPL_OK;
+    }
+    int chunks = 1;
+    while (nw * chunks < 2048 && total / (chunks * 2) >= 4096) chunks *= 2;
+    const int64_t blocks = nw * chunks;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_weight: grid too large");
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, x, g, accumulate, gw);
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, chunks, gw);
     MSPL_CHECK_LAUNCH("conv_bwd_weight");
     return MSPL_OK;
 }
@@ -389,12 +471,12 @@ extern "C" int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int3
     return MSPL_OK;
 }
 
-/* gx must be zero-filled by the caller (atomic scatter). */
+/* Gather form: gx is overwritten. */
 extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                                  float* gx, void* stream) {
     RsG g;
     if (int rc = rs_geom("bilinear_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
-    const int64_t total = (int64_t)N * C * Ho * Wo;
+    const int64_t total = (int64_t)N * C * Hi * Wi;
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("bilinear_bwd");
     return MSPL_OK;
