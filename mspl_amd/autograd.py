@@ -112,9 +112,10 @@ class AffinePReLUFn(torch.autograd.Function):
         dev = c.device
         gz = torch.empty_like(c) if residual is not None else None
         gc = torch.empty_like(c)
-        gsc = torch.zeros(C, device=dev) if scale is not None else None
-        gsh = torch.zeros(C, device=dev) if shift is not None else None
-        gal = torch.zeros(C, device=dev) if alpha is not None else None
+        gacc = torch.zeros(3, C, device=dev)            # one fill for the three per-channel accumulators
+        gsc = gacc[0] if scale is not None else None
+        gsh = gacc[1] if shift is not None else None
+        gal = gacc[2] if alpha is not None else None
         check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
                                         _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
         return gc, gsc, gsh, gal, (gc if pre_add is not None else None), gz
@@ -248,10 +249,35 @@ def affine_prelu(c, scale=None, shift=None, alpha=None, pre_add=None, residual=N
     return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual)
 
 
+class BNFoldFn(torch.autograd.Function):
+    """(scale, shift) = (gamma*inv, beta - mean*gamma*inv) with inv = rsqrt(running_var + eps) frozen (eval-mode BN):
+    two C-sized kernels forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, gamma, beta, mean, inv):
+        scale = gamma * inv
+        shift = torch.addcmul(beta, mean, scale, value=-1.0)
+        ctx.save_for_backward(mean, inv)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, gsc, gsh):
+        mean, inv = ctx.saved_tensors
+        return torch.addcmul(gsc, mean, gsh, value=-1.0).mul_(inv), gsh, None, None
+
+
 def bn_affine(bn):
-    """Differentiable eval-mode BatchNorm fold: (scale, shift) as functions of gamma/beta (C-sized tensors)."""
-    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-    return scale, bn.bias - bn.running_mean * scale
+    """Differentiable eval-mode BatchNorm fold: (scale, shift) as functions of gamma/beta (C-sized tensors).  The
+    running statistics are frozen on this path (uest_seg_multi_os.py:605-608), so rsqrt(var+eps) is cached on the
+    module and refreshed only when running_var is written."""
+    rv = bn.running_var
+    key = (rv.data_ptr(), rv._version)
+    c = bn.__dict__.get('_mspl_inv')
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, torch.rsqrt(rv + bn.eps))
+        bn.__dict__['_mspl_inv'] = c
+    return BNFoldFn.apply(bn.weight, bn.bias, bn.running_mean, c[1])
 
 
 avgpool = AvgPoolFn.apply

@@ -78,6 +78,53 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __res
     if (threadIdx.x == 0) atomicAdd(&gw[widx], (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// ---- weight gradient of a depthwise 3x3 convolution (cin_g = cout_g = 1; any stride / dilation): one workgroup per
+//      (channel, pixel chunk); a thread walks output pixels (coalesced gy reads, the nine x taps hit L1/L2) carrying the
+//      nine tap sums in registers, so gy and x are streamed once instead of once per tap.
+__global__ __launch_bounds__(256) void dw3x3_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                               ConvGeom g, int chunks, float* __restrict__ gw) {
+    const int chunk = blockIdx.x % chunks, c = blockIdx.x / chunks;
+    const int npix = g.Ho * g.Wo;
+    const int64_t total = (int64_t)g.N * npix;
+    const int64_t per = (total + chunks - 1) / chunks;
+    const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int n = (int)(i / npix), p = (int)(i - (int64_t)n * npix);
+        const int oy = p / g.Wo, ox = p - oy * g.Wo;
+        const float gv = gy[((size_t)n * g.Cout + c) * npix + p];
+        const float* xp = x + ((size_t)n * g.Cin + c) * g.H * (size_t)g.W;
+        const int by = oy * g.stride - g.pad, bx = ox * g.stride - g.pad;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = by + ky * g.dil;
+            const bool oky = iy >= 0 && iy < g.H;
+            const int iyc = min(max(iy, 0), g.H - 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = bx + kx * g.dil;
+                const bool okx = ix >= 0 && ix < g.W;
+                const float xv = xp[(size_t)iyc * g.W + min(max(ix, 0), g.W - 1)];
+                acc[ky * 3 + kx] = fmaf(gv, (oky && okx) ? xv : 0.f, acc[ky * 3 + kx]);
+            }
+        }
+    }
+    __shared__ float part[4][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        atomicAdd(&gw[(size_t)c * 9 + threadIdx.x],
+                  (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
 // ---- weight gradient of a grouped 1x1 convolution: gw[co, ci] = sum_{n,p} gy[n,co,p] * x[n,ci,p].
 //      A workgroup owns a 16 x 16 tile of one group's (co, ci) pairs and a chunk of pixels; both operand tiles
 //      (16 rows x 256 pixels) are staged in LDS with coalesced loads, each thread reduces one (co, ci) pair over the
@@ -101,15 +148,24 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(const float* __
     const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
     float acc = 0.f;
     for (int64_t base = i0; base < i1; base += 256) {
-        // stage: thread t loads pixel base+t of 16 rows of each operand (coalesced along pixels)
+        // stage: thread t loads pixel base+t of 16 rows of each operand (coalesced along pixels).  Row and pixel
+        // indices are clamped so all 32 loads are unconditional and issue back to back; masked to zero afterwards.
         const int64_t i = base + tid;
         const bool ok = i < i1;
-        const int n = ok ? (int)(i / HW) : 0, p = ok ? (int)(i - (int64_t)n * HW) : 0;
+        const int64_t ic = ok ? i : i1 - 1;
+        const int n = (int)(ic / HW), p = (int)(ic - (int64_t)n * HW);
+        const float* ga = gy + ((size_t)n * g.Cout + (size_t)grp * M) * HW + p;
+        const float* xb = x + ((size_t)n * g.Cin + (size_t)grp * K) * HW + p;
+        float ra[16], rb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = m0 + r, ci = k0 + r;
-            A[r][tid] = (ok && co < M) ? gy[((size_t)n * g.Cout + (size_t)grp * M + co) * HW + p] : 0.f;
-            B[r][tid] = (ok && ci < K) ? x[((size_t)n * g.Cin + (size_t)grp * K + ci) * HW + p] : 0.f;
+            ra[r] = ga[(size_t)min(m0 + r, M - 1) * HW];
+            rb[r] = xb[(size_t)min(k0 + r, K - 1) * HW];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            A[r][tid] = (ok && m0 + r < M) ? ra[r] : 0.f;
+            B[r][tid] = (ok && k0 + r < K) ? rb[r] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -427,6 +483,13 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_weight: grid too large");
         hipLaunchKernelGGL(conv1x1_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, chunks, tiles_m, tiles_k, gw);
         MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
+        return MSPL_OK;
+    }
+    if (K == 3 && g.cin_g == 1 && g.cout_g == 1) {
+        int chunks = 1;
+        while ((int64_t)Cout * chunks < 4096 && total / (chunks * 2) >= 2048) chunks *= 2;
+        hipLaunchKernelGGL(dw3x3_bwd_weight_kernel, dim3((unsigned)(Cout * chunks)), dim3(256), 0, s, gy, x, g, chunks, gw);
+        MSPL_CHECK_LAUNCH("conv_bwd_weight(dw3x3)");
         return MSPL_OK;
     }
     int chunks = 1;
