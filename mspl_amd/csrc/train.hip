@@ -78,25 +78,31 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __res
     if (threadIdx.x == 0) atomicAdd(&gw[widx], (part[0] + part[1]) + (part[2] + part[3]));
 }
 
-// ---- weight gradient of a depthwise 3x3 convolution (cin_g = cout_g = 1; any stride / dilation): one workgroup per
-//      (channel, pixel chunk); a thread walks output pixels (coalesced gy reads, the nine x taps hit L1/L2) carrying the
-//      nine tap sums in registers, so gy and x are streamed once instead of once per tap.
-__global__ __launch_bounds__(256) void dw3x3_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                               ConvGeom g, int chunks, float* __restrict__ gw) {
-    const int chunk = blockIdx.x % chunks, c = blockIdx.x / chunks;
+// ---- weight gradient of a 3x3 convolution with few input channels per group (CG = cin_g <= 5: depthwise, the
+//      stem, the pyramid merge conv; any stride / dilation): one workgroup per (output channel, pixel chunk); a thread
+//      walks output pixels (coalesced gy reads, the x taps hit L1/L2) carrying the CG*9 tap sums in registers, so gy
+//      is streamed once instead of once per tap.
+template <int CG>
+__global__ __launch_bounds__(256) void g3x3_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                              ConvGeom g, int chunks, float* __restrict__ gw) {
+    const int chunk = blockIdx.x % chunks, co = blockIdx.x / chunks;
+    const int ci0 = (co / g.cout_g) * CG;
     const int npix = g.Ho * g.Wo;
     const int64_t total = (int64_t)g.N * npix;
     const int64_t per = (total + chunks - 1) / chunks;
     const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
-    float acc[9];
+    const size_t plane = (size_t)g.H * g.W;
+    float acc[CG * 9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int t = 0; t < CG * 9; ++t) acc[t] = 0.f;
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const int n = (int)(i / npix), p = (int)(i - (int64_t)n * npix);
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
-        const float gv = gy[((size_t)n * g.Cout + c) * npix + p];
-        const float* xp = x + ((size_t)n * g.Cin + c) * g.H * (size_t)g.W;
+        const float gv = gy[((size_t)n * g.Cout + co) * npix + p];
+        const float* xp = x + ((size_t)n * g.Cin + ci0) * plane;
         const int by = oy * g.stride - g.pad, bx = ox * g.stride - g.pad;
+        int offs[9];
+        float msk[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = by + ky * g.dil;
@@ -105,23 +111,26 @@ __global__ __launch_bounds__(256) void dw3x3_bwd_weight_kernel(const float* __re
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = bx + kx * g.dil;
-                const bool okx = ix >= 0 && ix < g.W;
-                const float xv = xp[(size_t)iyc * g.W + min(max(ix, 0), g.W - 1)];
-                acc[ky * 3 + kx] = fmaf(gv, (oky && okx) ? xv : 0.f, acc[ky * 3 + kx]);
+                offs[ky * 3 + kx] = iyc * g.W + min(max(ix, 0), g.W - 1);
+                msk[ky * 3 + kx] = (oky && ix >= 0 && ix < g.W) ? gv : 0.f;
             }
         }
-    }
-    __shared__ float part[4][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+        for (int ci = 0; ci < CG; ++ci)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[ci * 9 + t] = fmaf(msk[t], xp[ci * plane + offs[t]], acc[ci * 9 + t]);
+    }
+    __shared__ float part[4][CG * 9];
+#pragma unroll
+    for (int t = 0; t < CG * 9; ++t) {
         float v = acc[t];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9)
-        atomicAdd(&gw[(size_t)c * 9 + threadIdx.x],
+    if (threadIdx.x < CG * 9)
+        atomicAdd(&gw[(size_t)co * CG * 9 + threadIdx.x],
                   (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(const float* __
             ra[r] = ga[(size_t)min(m0 + r, M - 1) * HW];
             rb[r] = xb[(size_t)min(k0 + r, K - 1) * HW];
         }
+        __builtin_amdgcn_sched_barrier(0);          // keep the 32 loads in flight together (no per-load wait)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             A[r][tid] = (ok && m0 + r < M) ? ra[r] : 0.f;
@@ -485,11 +495,18 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
         return MSPL_OK;
     }
-    if (K == 3 && g.cin_g == 1 && g.cout_g == 1) {
+    if (K == 3 && g.cin_g <= 5) {
         int chunks = 1;
         while ((int64_t)Cout * chunks < 4096 && total / (chunks * 2) >= 2048) chunks *= 2;
-        hipLaunchKernelGGL(dw3x3_bwd_weight_kernel, dim3((unsigned)(Cout * chunks)), dim3(256), 0, s, gy, x, g, chunks, gw);
-        MSPL_CHECK_LAUNCH("conv_bwd_weight(dw3x3)");
+        const dim3 grid((unsigned)(Cout * chunks)), blk(256);
+        switch (g.cin_g) {
+            case 1: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<1>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 2: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<2>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 3: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<3>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 4: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<4>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            default: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<5>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+        }
+        MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3, few input channels)");
         return MSPL_OK;
     }
     int chunks = 1;

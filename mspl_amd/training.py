@@ -21,14 +21,18 @@ from ._native import check, lib
 from .ops import _p, _stream
 
 
+def _device_class_weights(class_weights, device, ignore_idx):
+    cw = class_weights.detach().to(device, torch.float32).clone()
+    if ignore_idx is not None:
+        cw[ignore_idx] = 0.0
+    return cw
+
+
 def uest_loss(pred, aux, labels, class_weights, ignore_idx=None, ce_scale=20.0):
     """criterion(pred + 0.5*aux, labels, kld)*ce_scale + kld.mean() with kld = PixelwiseKLD(pred, aux).
     class_weights: tensor of num_classes weights; class_weights[ignore_idx] is treated as 0 (the reference zeroes it
     in place at construction, loss_fns/segmentation_loss.py:152-153)."""
-    cw = class_weights.detach().to(pred.device, torch.float32).clone()
-    if ignore_idx is not None:
-        cw[ignore_idx] = 0.0
-    return ag.uw_loss(pred, aux, labels, cw, ce_scale)
+    return ag.uw_loss(pred, aux, labels, _device_class_weights(class_weights, pred.device, ignore_idx), ce_scale)
 
 
 class FlatAdam:
@@ -93,3 +97,41 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
     optimizer.all_reduce_grads()
     optimizer.step()
     return loss.detach(), optimizer
+
+
+class GraphedTrainStep:
+    """train_step with zero_grad + forward + loss + backward replayed as ONE hipGraph (the step is ~1500 launches of
+    5-100 us; eager issue from Python is slower than the GPU executes them).  The gradient all-reduce and the Adam kernel
+    stay outside the graph, so the same object serves N = 1 and N > 1.
+
+    The first call runs one eager step (it reveals the gradient-bearing parameters and builds FlatAdam) and captures;
+    later calls copy the batch into static buffers and replay.  Shapes are fixed at construction."""
+
+    def __init__(self, model, images, labels, class_weights, ignore_idx=None, lr=5e-4, weight_decay=5e-4, ce_scale=20.0):
+        self.model = model
+        self.images = images.detach().clone()
+        self.labels = labels.detach().to(torch.int64).clone()
+        self.cw = _device_class_weights(class_weights, images.device, ignore_idx)
+        self.ce_scale = ce_scale
+        _, self.optimizer = train_step(model, self.images, self.labels, class_weights, None, ignore_idx, lr, weight_decay,
+                                       ce_scale)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.optimizer.zero_grad()
+            with torch.enable_grad():
+                pred, aux = model(self.images)
+                self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)
+                self.loss.backward()
+        self._finish()      # the capture did not execute: run the step it recorded
+
+    def _finish(self):
+        self.graph.replay()
+        self.optimizer.all_reduce_grads()
+        self.optimizer.step()
+        return self.loss.detach()
+
+    def __call__(self, images, labels):
+        self.images.copy_(images)
+        self.labels.copy_(labels)
+        return self._finish()

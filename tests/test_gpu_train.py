@@ -170,3 +170,27 @@ def test_second_step_and_train_step_helper():
         l, opt = training.train_step(m, x, y, cw, opt, ignore_idx=4)
         losses.append(float(l))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses      # same batch: the loss must go down
+
+
+def test_graphed_train_step_equals_eager():
+    """zero_grad + forward + loss + backward replayed as one hipGraph gives the same losses and weights as eager steps."""
+    from mspl_amd import models, training
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    x = synth_input((2, 3, 32, 48), 8).to(DEV)
+    y = synth_labels((2, 32, 48), 5, 8).to(DEV)
+    cw = torch.ones(5)
+    nets = []
+    for _ in range(2):
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(KEYS['espdnetue_s2.0_c5'], 3))
+        nets.append(m.to(DEV).eval())
+    l, opt = training.train_step(nets[0], x, y, cw, None, ignore_idx=4)
+    eager = [float(l)]
+    for _ in range(3):
+        l, opt = training.train_step(nets[0], x, y, cw, opt, ignore_idx=4)
+        eager.append(float(l))
+    gs = training.GraphedTrainStep(nets[1], x, y, cw, ignore_idx=4)      # eager step 1 + captured step 2
+    graphed = [float(gs(x, y)) for _ in range(2)]
+    np.testing.assert_allclose(graphed, eager[2:], rtol=2e-4, atol=1e-6)
+    for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+        np.testing.assert_allclose(q.cpu().numpy(), p.cpu().numpy(), rtol=0, atol=5e-5, err_msg=k)

@@ -36,3 +36,15 @@ for _ in range(5):
     loss, opt = training.train_step(tgt, x, y, cw, opt, ignore_idx=4)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 5
 print('train step (fwd + UW-loss + bwd + Adam), bs16 256x480: %.1f ms -> %.1f img/s, loss %.4f' % (t * 1e3, 16 / t, float(loss)))
+
+tgt2 = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+tgt2.load_state_dict(synth_state_dict(tgt2.state_dict(), 9))
+tgt2 = tgt2.to(dev).eval()
+gs = training.GraphedTrainStep(tgt2, x, y, cw, ignore_idx=4)
+for _ in range(2):
+    gs(x, y)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    loss = gs(x, y)
+torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+print('train step, hipGraph replay: %.1f ms -> %.1f img/s, loss %.4f' % (t * 1e3, 16 / t, float(loss)))

@@ -11,6 +11,6 @@ tgt = tgt.cuda().eval()
 y = torch.randint(0, 5, (16, 256, 480), device='cuda')
 cw = torch.ones(5)
 loss, opt = training.train_step(tgt, x, y, cw, None, ignore_idx=4)
-for _ in range(3):
+for _ in range(11):
     loss, opt = training.train_step(tgt, x, y, cw, opt, ignore_idx=4)
 torch.cuda.synchronize()
