@@ -356,6 +356,11 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
     }
 }
 
+int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
+                    const float* const* stage_w, const float* const* down_e, const float* br_scale,
+                    const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
+                    hipStream_t stream);       // pyrpool_sep.hip
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -370,6 +375,14 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
     MSPL_REQUIRE(N > 0 && P > 0 && h > 0 && w > 0, MSPL_ERR_BAD_SHAPE, "pyrpool_fused: bad shape N=%d P=%d %dx%d", N, P, h, w);
     MSPL_REQUIRE(nb >= 1 && nb <= PYR_MAXB, MSPL_ERR_UNSUPPORTED, "pyrpool_fused: %d branches (1..%d)", nb, PYR_MAXB);
     if (int rc = check_epi(ep, P, "pyrpool_fused")) return rc;
+    {   // stencil form first (pyrpool_sep.hip); shapes it does not cover fall through to the table-driven kernel
+        static const int force_tables = getenv("MSPL_PYR_TABLES") ? atoi(getenv("MSPL_PYR_TABLES")) : 0;
+        if (!force_tables) {
+            const int rc = pyrpool_sep_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
+                                           make_epi(ep, P, h * w), out, (hipStream_t)stream);
+            if (rc <= 0) return rc;
+        }
+    }
     PyrGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.P = P; g.h = h; g.w = w; g.nb = nb;
