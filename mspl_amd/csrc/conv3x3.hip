@@ -19,6 +19,8 @@ struct C3Geom {
     int IH, IWS;       // staged input rows / LDS row stride (floats, multiple of 4)
     int XS;            // TW / 4 strips per tile row
     int coblks;        // cout_g / COB
+    int nvec;          // 16-byte chunks per staged row
+    unsigned mag_nvec, mag_ih;   // ceil(2^32 / d): exact division of small counts by mul-hi
 };
 
 template <int STRIDE, int COB>
@@ -42,39 +44,52 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     const float* wg = w + (size_t)grp * nw;
     for (int i = tid; i < nw; i += 256) wl[i] = wg[i];
 
-    // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j).  One wave per staged row: aligned 16-byte
-    // global loads (W % 4 == 0), scalar LDS writes, zero fill outside the image.
+    // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j).  The (plane, row, 16-byte chunk) space is walked
+    // flat by all 256 threads with UL independent global loads in flight per thread before the first LDS write
+    // (aligned 16-byte loads when W % 4 == 0, scalar LDS writes since ix0 = -1 mod 4, zero fill outside the image).
     const int per_plane = g.IH * g.IWS;
     {
-        const int wave = tid >> 6, lane = tid & 63;
-        const int c_lo = (ix0 >= 0 ? ix0 : ix0 - 3) / 4 * 4;         // floor4(ix0)
-        const int nvec = (g.IWS + (ix0 - c_lo) + 3) >> 2;
+        constexpr int UL = 4;
+        const int c_lo = ix0 - 3;                    // ix0 = 4k - 1  ->  floor4(ix0) = ix0 - 3
+        const int total = g.cin_g * g.IH * g.nvec;
         const bool w4 = (g.W & 3) == 0;
-        for (int rr = wave; rr < g.cin_g * g.IH; rr += 4) {
-            const int ci = rr / g.IH, r = rr - ci * g.IH;
-            const int iy = iy0 + r;
-            const bool row_ok = iy >= 0 && iy < g.H;
-            int lc = grp * g.cin_g + ci;
-            if (g.sg > 0) lc = (lc % g.sg) * (g.Cin / g.sg) + lc / g.sg;
-            const float* src = x + (((size_t)img * g.Cin + lc) * g.H + (row_ok ? iy : 0)) * (size_t)g.W;
-            float* dst = tile + (size_t)rr * g.IWS;
-            for (int v = lane; v < nvec; v += 64) {
-                const int c0 = c_lo + 4 * v;
-                float e4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (row_ok) {
-                    if (w4 && c0 >= 0 && c0 + 3 < g.W) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(src + c0);
-                        e4[0] = t4.x; e4[1] = t4.y; e4[2] = t4.z; e4[3] = t4.w;
-                    } else {
+        for (int base = 0; base < total; base += 256 * UL) {
+            float e4[UL][4];
+            int dbase[UL], c0s[UL];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (c0 + q >= 0 && c0 + q < g.W) e4[q] = src[c0 + q];
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                e4[u][0] = e4[u][1] = e4[u][2] = e4[u][3] = 0.f;
+                dbase[u] = -1;  c0s[u] = 0;
+                if (i < total) {
+                    const int rr = (int)__umulhi((unsigned)i, g.mag_nvec), v = i - rr * g.nvec;
+                    const int ci = (int)__umulhi((unsigned)rr, g.mag_ih), r = rr - ci * g.IH;
+                    const int iy = iy0 + r;
+                    const int c0 = c_lo + 4 * v;
+                    dbase[u] = rr * g.IWS;  c0s[u] = c0;
+                    if (iy >= 0 && iy < g.H) {
+                        int lc = grp * g.cin_g + ci;
+                        if (g.sg > 0) lc = (lc % g.sg) * (g.Cin / g.sg) + lc / g.sg;
+                        const float* src = x + (((size_t)img * g.Cin + lc) * g.H + iy) * (size_t)g.W;
+                        if (w4 && c0 >= 0 && c0 + 3 < g.W) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(src + c0);
+                            e4[u][0] = t4.x; e4[u][1] = t4.y; e4[u][2] = t4.z; e4[u][3] = t4.w;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (c0 + q >= 0 && c0 + q < g.W) e4[u][q] = src[c0 + q];
+                        }
                     }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                if (dbase[u] < 0) continue;
+                float* dst = tile + dbase[u];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int j = c0 + q - ix0;
-                    if (j >= 0 && j < g.IWS) dst[j] = e4[q];
+                    const int j = c0s[u] + q - ix0;
+                    if (j >= 0 && j < g.IWS) dst[j] = e4[u][q];
                 }
             }
         }
@@ -167,6 +182,9 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
                  "conv3x3: tile (cin_g=%d, cout_g=%d) does not fit LDS", g.cin_g, g.cout_g);
     g.TH = th;
     g.IH = (th - 1) * STRIDE + 3;
+    g.nvec = (g.IWS + 3 + 3) >> 2;
+    g.mag_nvec = (unsigned)((0x100000000ull + g.nvec - 1) / g.nvec);
+    g.mag_ih = (unsigned)((0x100000000ull + g.IH - 1) / g.IH);
     g.tiles_y = ceil_div(g.Ho, th);
     const int64_t blocks = (int64_t)g.N * g.G * g.tiles_y * g.tiles_x;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv3x3: grid too large");

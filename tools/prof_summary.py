@@ -3,10 +3,10 @@
 launch-by-launch trace of the last forward pass.  Usage: python tools_prof.py gpurun_out/profN [--trace]"""
 import csv, glob, sys
 d = sys.argv[1]
-st = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+st = (glob.glob(d + '/*/*_kernel_stats.csv') + glob.glob(d + '/*_kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(st)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-tr = list(csv.DictReader(open(glob.glob(d + '/*/*_kernel_trace.csv')[0])))
+tr = list(csv.DictReader(open((glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0])))
 nfw = sum(1 for r in tr if 'label_epilogue' in r['Kernel_Name'])
 print('total %.2f ms over %d label passes -> %.3f ms/pass' % (tot / 1e6, nfw, tot / 1e6 / max(nfw, 1)))
 for r in rows[:18]:
