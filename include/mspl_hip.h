@@ -220,6 +220,24 @@ int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* tar
                          int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
                          float* gaux, float* kld_out, void* stream);
 
+/* Stand-alone loss modules (callers that compose them themselves instead of the fused K11 form):
+ *  PixelwiseKLD.forward (loss_fns/segmentation_loss.py:181-189): kld (N,HW) = sum_c softmax(d1)*(log_softmax(d1)-log_softmax(d2));
+ *  its backward: gd1/gd2 (N,C,HW) from gkld (N,HW); either output may be NULL. */
+int mspl_pixelwise_kld_fwd(const float* d1, const float* d2, int32_t N, int32_t C, int32_t HW, float* kld, void* stream);
+int mspl_pixelwise_kld_bwd(const float* d1, const float* d2, const float* gkld, int32_t N, int32_t C, int32_t HW,
+                           float* gd1, float* gd2, void* stream);
+/* Weighted cross entropy sums: sums[0] += sum_pix w[t] * -log_softmax(pred)[t] * exp(-u),  sums[1] += sum_{valid pix} w[t]
+ * (caller zeroes sums; pixels with t == ignore_index or t outside [0,C) contribute nothing; u_weight / class_weights may be
+ * NULL = 1).  UncertaintyWeightedSegmentationLoss.forward (segmentation_loss.py:155-175) = sums[0] / (N*HW);
+ * SegmentationLoss 'ce' = nn.CrossEntropyLoss(weight, ignore_index) (segmentation_loss.py:24) = sums[0] / sums[1].
+ * Backward: g = upstream gradient (1 device float); den = device pointer to sums[1] for the CrossEntropyLoss normalisation
+ * or NULL for the mean over all N*HW pixels; gpred (N,C,HW) and gu (N,HW) are overwritten (either may be NULL). */
+int mspl_weighted_ce_fwd(const float* pred, const int64_t* target, const float* u_weight, const float* class_weights,
+                         int32_t ignore_index, int32_t N, int32_t C, int32_t HW, float* sums, void* stream);
+int mspl_weighted_ce_bwd(const float* pred, const int64_t* target, const float* u_weight, const float* class_weights,
+                         int32_t ignore_index, int32_t N, int32_t C, int32_t HW, const float* g, const float* den,
+                         float* gpred, float* gu, void* stream);
+
 /* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
 int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);

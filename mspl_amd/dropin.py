@@ -47,10 +47,7 @@ def install_dropin(force=False):
     _alias('model.segmentation.espnetv2', ESPNetv2Segmentation=M.ESPNetv2Segmentation, espnetv2_seg=M.espnetv2_seg)
     _alias('data_loader.segmentation.greenhouse', id_camvid_to_greenhouse=U.id_camvid_to_greenhouse,
            id_cityscapes_to_greenhouse=U.id_cityscapes_to_greenhouse, id_forest_to_greenhouse=U.id_forest_to_greenhouse)
-    try:
-        from . import losses as S
-        _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,
-               UncertaintyWeightedSegmentationLoss=S.UncertaintyWeightedSegmentationLoss,
-               SegmentationLoss=S.SegmentationLoss)
-    except ImportError:
-        pass
+    from . import losses as S
+    _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,
+           UncertaintyWeightedSegmentationLoss=S.UncertaintyWeightedSegmentationLoss,
+           SegmentationLoss=S.SegmentationLoss, NIDLoss=S.NIDLoss)

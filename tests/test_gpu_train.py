@@ -25,6 +25,10 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+def close(a, b, atol=2e-5, rtol=1e-4):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol)
+
+
 def grads_of(fn, inputs, seed=99):
     outs = fn(*inputs)
     go = rnd(*outs.shape, seed=seed).to(outs.device)
@@ -194,3 +198,65 @@ def test_graphed_train_step_equals_eager():
     np.testing.assert_allclose(graphed, eager[2:], rtol=2e-4, atol=1e-6)
     for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
         np.testing.assert_allclose(q.cpu().numpy(), p.cpu().numpy(), rtol=0, atol=5e-5, err_msg=k)
+
+
+def _ref_losses():
+    """Torch-CPU statements of the three loss modules (loss_fns/segmentation_loss.py:11-52,146-189)."""
+    import torch.nn.functional as F
+
+    def kld(d1, d2):
+        p1 = F.softmax(d1, 1)
+        return (p1 * F.log_softmax(d1, 1) - p1 * F.log_softmax(d2, 1)).sum(1)
+
+    def uw(pred, target, u, cw):
+        n, c, h, w = pred.shape
+        lp = -F.log_softmax(pred, 1) * cw.view(1, c, 1, 1)
+        return (lp.gather(1, target.view(n, 1, h, w)) * torch.exp(-u.view(n, 1, h, w))).mean()
+    return kld, uw
+
+
+def test_loss_modules_forward_backward():
+    """PixelwiseKLD / UncertaintyWeightedSegmentationLoss / SegmentationLoss drop-ins: values and gradients vs torch CPU,
+    composed the way uest_seg_multi_os.py:1020-1023 composes them, and equal to the fused K11 form."""
+    from mspl_amd import losses, training
+    kld_ref, uw_ref = _ref_losses()
+    N, C, H, W = 2, 5, 24, 40
+    pred = rnd(N, C, H, W, seed=1) * 2
+    aux = rnd(N, C, H, W, seed=2) * 2
+    y = synth_labels((N, H, W), C, 3)
+    cw = torch.tensor([1.0, 0.5, 2.0, 1.5, 1.0])
+    # reference composition on CPU
+    pr, ar = pred.clone().requires_grad_(), aux.clone().requires_grad_()
+    cwr = cw.clone(); cwr[4] = 0.0
+    k = kld_ref(pr, ar)
+    ref = uw_ref(pr + 0.5 * ar, y, k, cwr) * 20 + k.mean()
+    ref.backward()
+    # drop-in modules on the GPU
+    pg, agd = pred.to(DEV).requires_grad_(), aux.to(DEV).requires_grad_()
+    crit = losses.UncertaintyWeightedSegmentationLoss(C, class_wts=cw.clone(), ignore_idx=4, device=DEV)
+    kg = losses.PixelwiseKLD()(pg, agd)
+    close(kg.detach(), k.detach(), atol=2e-6)
+    out = crit(pg + 0.5 * agd, y.to(DEV), kg) * 20 + kg.mean()
+    out.backward()
+    close(out.detach(), ref.detach(), atol=1e-5)
+    close(pg.grad, pr.grad, atol=2e-7, rtol=2e-4)
+    close(agd.grad, ar.grad, atol=2e-7, rtol=2e-4)
+    fused = training.uest_loss(pred.to(DEV), aux.to(DEV), y.to(DEV), cw, ignore_idx=4)
+    close(fused, ref.detach(), atol=1e-5)
+    # SegmentationLoss == nn.CrossEntropyLoss(weight, ignore_index), single tensor and (main, aux) tuple
+    y255 = y.clone(); y255[0, :3] = 255
+    ce = torch.nn.CrossEntropyLoss(ignore_index=255, weight=cw)
+    pr2, ar2 = pred.clone().requires_grad_(), aux.clone().requires_grad_()
+    r2 = ce(pr2, y255) + ce(ar2, y255)
+    r2.backward()
+    pg2, ag2 = pred.to(DEV).requires_grad_(), aux.to(DEV).requires_grad_()
+    seg = losses.SegmentationLoss(n_classes=C, device=DEV, ignore_idx=255, class_weights=cw)
+    o2 = seg((pg2, ag2), y255.to(DEV))
+    o2.backward()
+    close(o2.detach(), r2.detach(), atol=1e-5)
+    close(pg2.grad, pr2.grad, atol=2e-7, rtol=2e-4)
+    close(ag2.grad, ar2.grad, atol=2e-7, rtol=2e-4)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        losses.PixelwiseKLD()(pred, aux)
+    with pytest.raises(RuntimeError, match="only 'ce'"):
+        losses.SegmentationLoss(loss_type='bce')

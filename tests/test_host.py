@@ -132,7 +132,16 @@ def test_dropin_aliases():
     from nn_layers.efficient_pyramid_pool import EfficientPyrPool  # noqa: F401
     from model.segmentation.espdnet_ue import espdnetue_seg2  # noqa: F401
     from data_loader.segmentation.greenhouse import id_camvid_to_greenhouse  # noqa: F401
-    assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2
+    from loss_fns.segmentation_loss import (NIDLoss, PixelwiseKLD, SegmentationLoss,  # noqa: F401  (uest_seg_multi_os.py:36)
+                                            UncertaintyWeightedSegmentationLoss)
+    from mspl_amd import losses
+    assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2 and PixelwiseKLD is losses.PixelwiseKLD
+    # the callers' keyword (uest_seg_multi_os.py:509) and the in-place zeroing of the ignore class (:152-153)
+    w = torch.ones(5)
+    crit = UncertaintyWeightedSegmentationLoss(5, class_wts=w, ignore_idx=4, device='cpu')
+    assert crit.class_weights[4] == 0.0 and crit.class_weights[:4].eq(1).all()
+    with pytest.raises(RuntimeError, match='outside the hot path'):
+        NIDLoss()
 
 
 def test_product_never_imports_the_oracle():
