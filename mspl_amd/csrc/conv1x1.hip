@@ -35,6 +35,8 @@ struct PwGeom {
     int ptiles;    // pixel tiles (32 px per image, or 128 px of the flattened batch for the float4 kernel)
     int pgroups;   // ceil(ptiles / (WP * TPW))
     int vecw;      // 16-byte aligned weights: stage with float4 loads
+    unsigned long long* stamps;   // tuning aid (MSPL_PW_STAMP): 4 s_memrealtime stamps per workgroup, or null
+    int astage;    // register-weights kernel: 1 = weights go global -> LDS (coalesced) -> registers, 0 = global -> registers
 };
 
 // Per-row epilogue constants staged in LDS as six arrays of MB floats (scale, shift, alpha, rw0, rw1, rw2), so
@@ -49,7 +51,7 @@ __device__ __forceinline__ void stage_weights(float* At, float* rowc, const floa
     if (g.vecw) {
         const int kv = K32 >> 2;
         const int total = g.MB * kv;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = tid; i < total; i += 256) {
             const int m = i / kv, k = (i - m * kv) << 2;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -91,8 +93,8 @@ __device__ __forceinline__ void vec_store(void* p, const float (&v)[NSUB]) {
     else *reinterpret_cast<float*>(p) = v[0];
 }
 
-template <int NSUB>
-__global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(const float* __restrict__ x,
+template <int NSUB, int RING>
+__global__ __launch_bounds__(256, ((NSUB == 4 || RING > 4) ? 2 : 3)) void conv1x1_mfma_kernel(const float* __restrict__ x,
                                                                                const float* __restrict__ w,
                                                                                PwGeom g, Epi e,
                                                                                float* __restrict__ out) {
@@ -106,9 +108,6 @@ __global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(
     const int tid = threadIdx.x;
     const int m0 = mb * g.MB;
     const int cbase = e.coff + grp * g.M + m0;   // absolute destination channel of local row 0
-    stage_weights(At, rowc, w + ((size_t)grp * g.M + m0) * g.K, g, e, m0, cbase, tid);
-    __syncthreads();
-
     const int wave = tid >> 6, lane = tid & 63;
     const int WP = 4 / g.WM;
     const int chunk = wave % g.WM, wp = wave / g.WM;         // this wave's 32-row chunk of MB and pixel slot
@@ -116,50 +115,76 @@ __global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(
     const int mrem = g.M - m0;
     const int total_px = g.N * g.HW;
     const size_t rowbytes = (size_t)g.HW * sizeof(float);
-    if (chunk >= g.mc_total) return;                          // (no barrier follows)
+    const size_t orow = (size_t)e.hw * sizeof(float);
+    const int mlh = chunk * 32 + 4 * half;                    // local row of accumulator register 0
+    const int klast = g.K - 2;
+    const bool active = chunk < g.mc_total;
+
+    // Per-tile operand fetch: the residual rows (where registers allow) and the first RING groups of B.  The fetch
+    // for the first tile is issued BEFORE the weights are staged, so its HBM latency hides under the staging and the
+    // barrier; the fetch for tile t+1 is issued right after tile t's last MFMA.
+    // B rows kb0 + 2*kk + half, kk = 0..3.  K is even on this path; a pair beyond K is clamped to the last valid
+    // pair (finite data) and contributes nothing because A is zero padded to K32 columns.
+    float resv[16][NSUB];
+    float b[RING][4][NSUB];
+    auto tile_px = [&](int t, int& gp, bool& pok, int& img, int& p) {
+        const int ptile = (pg * g.TPW + t) * WP + wp;
+        gp = (ptile * 32 + li) * NSUB;                        // first of this lane's NSUB pixels (flattened batch)
+        pok = gp < total_px;                                  // HW % NSUB == 0: a lane's pixels share an image
+        const int gpc = pok ? gp : 0;
+        img = gpc / g.HW;  p = gpc - img * g.HW;
+        return ptile < g.ptiles;
+    };
+    auto load_group = [&](const char* xb, float (&bb)[4][NSUB], int kb0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            int kr = kb0 + 2 * kk;                            // uniform
+            kr = kr < klast ? kr : klast;
+            vec_load<NSUB>(xb + (size_t)kr * rowbytes, bb[kk]);
+        }
+    };
+    auto load_residual = [&](unsigned ooff) {
+        const char* rb = reinterpret_cast<const char*>(e.residual);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) resv[r][s] = 0.f;
+            if (mlh + dr < mrem) vec_load<NSUB>(rb + dr * orow + ooff, resv[r]);
+        }
+    };
+    auto fetch_res = [&](int t) {
+        int gp, img, p;  bool pok;
+        if (NSUB == 4 || !e.residual || !tile_px(t, gp, pok, img, p)) return;
+        load_residual((unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float)));
+    };
+    auto fetch_b = [&](int t) {
+        int gp, img, p;  bool pok;
+        if (!tile_px(t, gp, pok, img, p)) return;
+        const size_t voff = (((size_t)img * g.Cin + (size_t)grp * g.K + half) * g.HW + p) * sizeof(float);
+        const char* xb = reinterpret_cast<const char*>(x) + voff;
+#pragma unroll
+        for (int i = 0; i < RING; ++i)
+            if (i * 8 < g.K) load_group(xb, b[i], i * 8);
+    };
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (g.stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    if (active) { fetch_res(0); fetch_b(0); }
+
+    stage_weights(At, rowc, w + ((size_t)grp * g.M + m0) * g.K, g, e, m0, cbase, tid);
+    __syncthreads();
+    if (!active) return;                                      // (no barrier follows)
+    if (g.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     const float* arow0 = At + (size_t)(chunk * 32 + li) * g.KS + half;
 
     for (int t = 0; t < g.TPW; ++t) {
-        const int ptile = (pg * g.TPW + t) * WP + wp;
-        if (ptile >= g.ptiles) break;                         // wave-uniform
-        const int gp = (ptile * 32 + li) * NSUB;              // first of this lane's NSUB pixels (flattened batch)
-        const bool pok = gp < total_px;                       // HW % NSUB == 0: a lane's pixels share an image
-        const int gpc = pok ? gp : 0;
-        const int img = gpc / g.HW, p = gpc - img * g.HW;
+        int gp, img, p;  bool pok;
+        if (!tile_px(t, gp, pok, img, p)) break;              // wave-uniform
         // byte offset of X[img][grp*K + half][p] from x; k advances through a uniform (SGPR) base
         const size_t voff = (((size_t)img * g.Cin + (size_t)grp * g.K + half) * g.HW + p) * sizeof(float);
         // destination-shaped tensors (out / residual / pre_add): uniform row base + one 32-bit lane offset
-        const unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + chunk * 32 + 4 * half) * (size_t)e.hw + p) * sizeof(float));
-        const size_t orow = (size_t)e.hw * sizeof(float);
-        const int mlh = chunk * 32 + 4 * half;                // local row of accumulator register 0
-
-        // residual rows: fetched before the K loop where registers allow (latency hides under the matrix work),
-        // after it for the 4-pixel variant (its accumulators + load ring already fill the register file)
-        float resv[16][NSUB];
-        auto load_residual = [&]() {
-            const char* rb = reinterpret_cast<const char*>(e.residual);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                for (int s = 0; s < NSUB; ++s) resv[r][s] = 0.f;
-                if (mlh + dr < mrem) vec_load<NSUB>(rb + dr * orow + ooff, resv[r]);
-            }
-        };
-        if (NSUB < 4 && e.residual) load_residual();
-
-        // B rows kb0 + 2*kk + half, kk = 0..3.  K is even on this path; a pair beyond K is clamped to the last
-        // valid pair (finite data) and contributes nothing because A is zero padded to K32 columns.
+        const unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float));
         const char* xb = reinterpret_cast<const char*>(x) + voff;
-        const int klast = g.K - 2;
-        auto load_group = [&](float (&b)[4][NSUB], int kb0) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                int kr = kb0 + 2 * kk;                        // uniform
-                kr = kr < klast ? kr : klast;
-                vec_load<NSUB>(xb + (size_t)kr * rowbytes, b[kk]);
-            }
-        };
         floatx16 acc[NSUB];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
@@ -168,11 +193,6 @@ __global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(
 
         // K loop: a ring of RING groups (8 k-values each) stays in flight; slot i is refilled right after its
         // MFMAs are issued, so ~3 groups of HBM loads overlap every group of matrix work.
-        constexpr int RING = 4;
-        float b[RING][4][NSUB];
-#pragma unroll
-        for (int i = 0; i < RING; ++i)
-            if (i * 8 < g.K) load_group(b[i], i * 8);
 #pragma unroll 1
         for (int kb0 = 0; kb0 < g.K; kb0 += 8 * RING) {
 #pragma unroll
@@ -187,13 +207,15 @@ __global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(
                         for (int s = 0; s < NSUB; ++s)
                             acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i][kk][s], acc[s], 0, 0, 0);
                     }
-                    if (kb + 8 * RING < g.K) load_group(b[i], kb + 8 * RING);
+                    if (kb + 8 * RING < g.K) load_group(xb, b[i], kb + 8 * RING);
                 }
             }
         }
+        if (g.stamps && t == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0])); st2 = __builtin_amdgcn_s_memrealtime(); }
+        if (t + 1 < g.TPW) fetch_b(t + 1);                    // next tile's first groups fly during this epilogue
 
         // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
-        if (NSUB == 4 && e.residual) load_residual();
+        if (NSUB == 4 && e.residual) load_residual(ooff);
         float rr[3][NSUB];
         if (e.reinf_r) {
             const float* rp = e.reinf_r + (size_t)img * 3 * e.hw + p;
@@ -242,6 +264,210 @@ __global__ __launch_bounds__(256, (NSUB == 4 ? 2 : 3)) void conv1x1_mfma_kernel(
                         if (e.residual) t2 += resv[r][s];
                         if (e.alpha) t2 = t2 > 0.f ? t2 : alv[q] * t2;
                         v[s] = t2 * gv;
+                    }
+                    vec_store<NSUB>(ob + rowoff + ooff, v);
+                }
+            }
+            asm volatile("" ::: "memory");   // one row quad at a time: keeps hipcc from hoisting all 16 rows' work
+        }
+        if (t + 1 < g.TPW) fetch_res(t + 1);
+    }
+    if (g.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g.stamps + (size_t)blockIdx.x * 4;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memrealtime();
+        // placement: HW_REG_HW_ID (4) and HW_REG_XCC_ID (20) packed into the top bits of d[2]'s unused range
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g.stamps[(size_t)4 * 65536 + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
+
+// ------------------------------------------------------------------ MFMA kernel, weights held in registers
+// For K <= 128 per group (every EESP projection / expansion of the path) a wave's 32-row chunk of the weights is only
+// K/2 values per lane in the MFMA A layout, so it lives in VGPRs for the whole kernel: no LDS weight tile, no staging
+// barrier before the first matrix instruction, no ds_read per MFMA, and a wave walks TPW pixel tiles with the same
+// registers.  B operands stream from HBM through a ring of RING groups (4 k-steps each) exactly as above; the K loop
+// is fully unrolled (static register indices).  Only the per-row epilogue constants go through LDS.
+// NG = K / 8 (compile time: a uniform branch per group would force a full s_waitcnt at every join and serialise the
+// ring); requires 16-byte aligned weight rows.
+template <int NSUB, int NG>
+__global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              PwGeom g, Epi e, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rowc = smem;                                                    // [ROWC][MB]
+    int bid = blockIdx.x;
+    const int pg = bid % g.pgroups;  bid /= g.pgroups;
+    const int mb = bid % g.mblocks;
+    const int grp = bid / g.mblocks;
+    const int tid = threadIdx.x;
+    const int m0 = mb * g.MB;
+    const int cbase = e.coff + grp * g.M + m0;   // absolute destination channel of local row 0
+    for (int m = tid; m < g.MB; m += 256) {
+        EpiCh c = {1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+        if (m0 + m < g.M) c = epi_channel(e, cbase + m);
+        rowc[m] = c.scale; rowc[g.MB + m] = c.shift; rowc[2 * g.MB + m] = c.alpha;
+        rowc[3 * g.MB + m] = c.rw0; rowc[4 * g.MB + m] = c.rw1; rowc[5 * g.MB + m] = c.rw2;
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int WP = 4 / g.WM;
+    const int chunk = wave % g.WM, wp = wave / g.WM;         // this wave's 32-row chunk of MB and pixel slot
+    const int li = lane & 31, half = lane >> 5;
+    const int mrem = g.M - m0;
+    const int total_px = g.N * g.HW;
+    const size_t rowbytes = (size_t)g.HW * sizeof(float);
+
+    // A operand: a[ks] = W[m0 + chunk*32 + li][2*ks + half], ks < K/2.
+    constexpr int NKS = 4 * NG;
+    float a[NKS];
+    if (g.astage) {
+        // coalesced: the workgroup stages its MB x K weight tile in LDS once (odd row stride), then every wave copies
+        // its 32-row chunk into registers (conflict-free ds_read_b32); LDS is not touched again in the K loop
+        float* At = smem + (size_t)g.MB * ROWC;
+        const int kv = g.K >> 2, total = g.MB * kv;
+        const float* wg = w + ((size_t)grp * g.M + m0) * g.K;
+        constexpr int UL = 8;
+        for (int base = 0; base < total; base += 256 * UL) {
+            float4 v[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                const int m = i / kv, k = (i - m * kv) << 2;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < total && m < mrem) v[u] = *reinterpret_cast<const float4*>(wg + (size_t)m * g.K + k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                if (i < total) {
+                    const int m = i / kv, k = (i - m * kv) << 2;
+                    float* d = At + m * g.KS + k;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+        __syncthreads();
+        const float* ar = At + (size_t)(chunk * 32 + li) * g.KS + half;
+        if (chunk < g.mc_total) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) a[ks] = ar[2 * ks];
+        }
+    } else {
+        // direct: one 16-byte load covers k = 4j..4j+3 = the k-steps 2j (x | y) and 2j+1 (z | w); rows beyond M are zero
+        const int row = chunk * 32 + li;
+        const bool rok = chunk < g.mc_total && row < mrem;
+        const float* wr = w + ((size_t)grp * g.M + m0 + (rok ? row : 0)) * g.K;
+#pragma unroll
+        for (int j = 0; j < NKS / 2; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok) v = *reinterpret_cast<const float4*>(wr + 4 * j);
+            a[2 * j] = half ? v.y : v.x;
+            a[2 * j + 1] = half ? v.w : v.z;
+        }
+    }
+    __syncthreads();                                          // rowc visible (the only barrier)
+    if (chunk >= g.mc_total) return;
+
+    for (int t = 0; t < g.TPW; ++t) {
+        const int ptile = (pg * g.TPW + t) * WP + wp;
+        if (ptile >= g.ptiles) break;                         // wave-uniform
+        const int gp = (ptile * 32 + li) * NSUB;              // first of this lane's NSUB pixels (flattened batch)
+        const bool pok = gp < total_px;                       // HW % NSUB == 0: a lane's pixels share an image
+        const int gpc = pok ? gp : 0;
+        const int img = gpc / g.HW, p = gpc - img * g.HW;
+        const size_t voff = (((size_t)img * g.Cin + (size_t)grp * g.K + half) * g.HW + p) * sizeof(float);
+        const unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + chunk * 32 + 4 * half) * (size_t)e.hw + p) * sizeof(float));
+        const size_t orow = (size_t)e.hw * sizeof(float);
+        const int mlh = chunk * 32 + 4 * half;                // local row of accumulator register 0
+
+        float resv[16][NSUB];
+        if (e.residual) {
+            const char* rb = reinterpret_cast<const char*>(e.residual);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int s2 = 0; s2 < NSUB; ++s2) resv[r][s2] = 0.f;
+                if (mlh + dr < mrem) vec_load<NSUB>(rb + dr * orow + ooff, resv[r]);
+            }
+        }
+
+        const char* xb = reinterpret_cast<const char*>(x) + voff;
+        floatx16 acc[NSUB];
+#pragma unroll
+        for (int s2 = 0; s2 < NSUB; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
+
+        // K loop, fully unrolled and branch-free: group gi = k-steps 4*gi .. 4*gi+3
+        constexpr int RING = NG < 6 ? NG : 6;
+        float b[RING][4][NSUB];
+        auto load_group = [&](float (&bb)[4][NSUB], int gi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) vec_load<NSUB>(xb + (size_t)(8 * gi + 2 * kk) * rowbytes, bb[kk]);
+        };
+#pragma unroll
+        for (int i = 0; i < RING; ++i) load_group(b[i], i);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int s2 = 0; s2 < NSUB; ++s2)
+                    acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * gi + kk], b[gi % RING][kk][s2], acc[s2], 0, 0, 0);
+            if (gi + RING < NG) load_group(b[gi % RING], gi + RING);
+        }
+
+        // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
+        float rr[3][NSUB];
+        if (e.reinf_r) {
+            const float* rp = e.reinf_r + (size_t)img * 3 * e.hw + p;
+            vec_load<NSUB>(rp, rr[0]);
+            vec_load<NSUB>(rp + e.hw, rr[1]);
+            vec_load<NSUB>(rp + 2 * (size_t)e.hw, rr[2]);
+        }
+        const float* gate = e.gate ? e.gate + (size_t)img * e.ctot + cbase : nullptr;
+        char* ob = reinterpret_cast<char*>(out);
+        const char* pb = reinterpret_cast<const char*>(e.pre_add);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int mlb = mlh + 8 * rg;                                    // first of 4 consecutive local rows
+            const float4 sc4 = *reinterpret_cast<const float4*>(rowc + mlb);
+            const float4 sh4 = *reinterpret_cast<const float4*>(rowc + g.MB + mlb);
+            const float4 al4 = *reinterpret_cast<const float4*>(rowc + 2 * g.MB + mlb);
+            float4 w04 = make_float4(0.f, 0.f, 0.f, 0.f), w14 = w04, w24 = w04;
+            if (e.reinf_r) {
+                w04 = *reinterpret_cast<const float4*>(rowc + 3 * g.MB + mlb);
+                w14 = *reinterpret_cast<const float4*>(rowc + 4 * g.MB + mlb);
+                w24 = *reinterpret_cast<const float4*>(rowc + 5 * g.MB + mlb);
+            }
+            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float alv[4] = {al4.x, al4.y, al4.z, al4.w};
+            const float w0v[4] = {w04.x, w04.y, w04.z, w04.w}, w1v[4] = {w14.x, w14.y, w14.z, w14.w};
+            const float w2v[4] = {w24.x, w24.y, w24.z, w24.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q, ml = mlb + q;
+                const size_t rowoff = (size_t)(q + 8 * rg) * orow;           // uniform
+                if (ml < mrem && pok) {
+                    float v[NSUB];
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB; ++s2) v[s2] = acc[s2][r];
+                    if (pb) {
+                        float pa[NSUB];
+                        vec_load<NSUB>(pb + rowoff + ooff, pa);
+#pragma unroll
+                        for (int s2 = 0; s2 < NSUB; ++s2) v[s2] += pa[s2];
+                    }
+                    const float gv = gate ? gate[ml] : 1.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB; ++s2) {
+                        float t2 = fmaf(v[s2], scv[q], shv[q]);
+                        if (e.reinf_r) t2 += w0v[q] * rr[0][s2] + w1v[q] * rr[1][s2] + w2v[q] * rr[2][s2];
+                        if (e.residual) t2 += resv[r][s2];
+                        if (e.alpha) t2 = t2 > 0.f ? t2 : alv[q] * t2;
+                        v[s2] = t2 * gv;
                     }
                     vec_store<NSUB>(ob + rowoff + ooff, v);
                 }
@@ -318,6 +544,59 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
     }
 }
 
+// Launch of the register-resident-weights kernel (K % 8 == 0, K <= 128, aligned weights).
+static int launch_areg(const float* x, const float* w, PwGeom g, const Epi& e, const mspl_epilogue_t* ep, float* out,
+                       hipStream_t s) {
+    static const int dbg_astage = getenv("MSPL_PW_ASTAGE") ? atoi(getenv("MSPL_PW_ASTAGE")) : -1;
+    g.astage = dbg_astage >= 0 ? dbg_astage : !(g.K <= 32 && (int64_t)g.N * g.HW >= 100000);
+    g.KS = g.K | 1;
+    int mbr = ((g.M + 31) / 32) * 32;
+    if (mbr > 128) mbr = 128;
+    while (g.astage && mbr > 32 && (size_t)mbr * (g.KS + ROWC) * 4 > 40 * 1024) mbr -= 32;
+    if (mbr == 96) mbr = 64;                                   // waves along M are 1, 2 or 4
+    g.MB = mbr;
+    g.mblocks = ceil_div(g.M, mbr);
+    g.mc_total = mbr / 32;
+    g.WM = g.mc_total >= 3 ? 4 : g.mc_total;
+    const int wp = 4 / g.WM;
+    auto al = [](const void* p, int a) { return p == nullptr || (((uintptr_t)p) & (a - 1)) == 0; };
+    auto ok = [&](int ns) {
+        const int a = ns * 4;
+        return g.HW % ns == 0 && al(x, a) && al(out, a) && (!ep || (al(ep->pre_add, a) && al(ep->residual, a) && al(ep->reinf_r, a)));
+    };
+    // wave tiles = groups x 32-row chunks x pixel tiles; aim at >= 4 per SIMD (1024 SIMDs) for balance
+    auto tiles_of = [&](int ns) { return (int64_t)g.G * g.mblocks * g.mc_total * ceil_div64((int64_t)g.N * g.HW, 32 * ns); };
+    int nsub = 1;
+    if (ok(2) && tiles_of(2) >= 4096) nsub = 2;
+    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;   // tuning override
+    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    if ((dbg_nsub == 1 || dbg_nsub == 2) && ok(dbg_nsub)) nsub = dbg_nsub;
+    g.ptiles = (int)ceil_div64((int64_t)g.N * g.HW, 32 * nsub);
+    int tpw = 1;
+    while (tpw < 8 && tiles_of(nsub) / (tpw * 2) >= 4096) tpw *= 2;      // keep >= 4 waves per SIMD
+    if (dbg_tpw) tpw = dbg_tpw;
+    g.TPW = tpw;
+    g.pgroups = ceil_div(g.ptiles, wp * tpw);
+    const int64_t blocks = (int64_t)g.G * g.mblocks * g.pgroups;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
+    const dim3 grid((unsigned)blocks), blk(256);
+    const size_t lds = (size_t)g.MB * (ROWC + (g.astage ? g.KS : 0)) * sizeof(float);
+#define MSPL_AREG(NG) do { if (nsub == 2) hipLaunchKernelGGL((conv1x1_areg_kernel<2, NG>), grid, blk, lds, s, x, w, g, e, out); \
+                           else hipLaunchKernelGGL((conv1x1_areg_kernel<1, NG>), grid, blk, lds, s, x, w, g, e, out); } while (0)
+    switch (g.K >> 3) {
+        case 2: MSPL_AREG(2); break;
+        case 3: MSPL_AREG(3); break;
+        case 4: MSPL_AREG(4); break;
+        case 6: MSPL_AREG(6); break;
+        case 8: MSPL_AREG(8); break;
+        case 12: MSPL_AREG(12); break;
+        default: MSPL_AREG(16); break;
+    }
+#undef MSPL_AREG
+    MSPL_CHECK_LAUNCH("conv1x1(register weights)");
+    return MSPL_OK;
+}
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -361,6 +640,15 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     const int K32 = (g.K + 31) & ~31;
     g.KS = K32 | 1;
     g.vecw = ((g.K & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
+    static const int dbg_areg = getenv("MSPL_PW_AREG") ? atoi(getenv("MSPL_PW_AREG")) : 1;
+    const int ng8 = g.K >> 3;
+    const bool ng_ok = ng8 == 2 || ng8 == 3 || ng8 == 4 || ng8 == 6 || ng8 == 8 || ng8 == 12 || ng8 == 16;
+    // measured (tools/bench_ops.py): the register-weights kernel wins for short K on large maps (no staging, no barrier);
+    // for K >= 64 its 150-185 VGPRs leave 2 workgroups per CU and the 18x30 / 36x60 grids then need a second round
+    const bool areg_shape = dbg_areg == 2 || (g.K <= 32 && (int64_t)N * HW >= 100000);
+    if (dbg_areg && areg_shape && (g.K & 7) == 0 && ng_ok && g.vecw &&
+        (size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32))
+        return launch_areg(x, w, g, e, ep, out, s);
     const int rowf = ROWC;
     MSPL_REQUIRE((size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32),
                  MSPL_ERR_UNSUPPORTED, "conv1x1: tensor exceeds the 32-bit byte offsets of the matrix-core kernel");
@@ -381,9 +669,13 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     static bool attr_done = false;   // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
     if (!attr_done) {
         const int cap = (int)lds_cap;
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipGetLastError();
         attr_done = true;
     }
@@ -411,10 +703,44 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     g.pgroups = ceil_div(g.ptiles, wp * tpw);
     const int64_t blocks = (int64_t)groups * g.mblocks * g.pgroups;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
+    static unsigned long long* stamp_buf = nullptr;
+    static const int dbg_stamp = getenv("MSPL_PW_STAMP") ? atoi(getenv("MSPL_PW_STAMP")) : 0;
+    if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)5 * 65536 * sizeof(unsigned long long));
+    g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
     dim3 grid((unsigned)blocks), blk(256);
-    if (nsub == 4) hipLaunchKernelGGL(conv1x1_mfma_kernel<4>, grid, blk, lds, s, x, w, g, e, out);
-    else if (nsub == 2) hipLaunchKernelGGL(conv1x1_mfma_kernel<2>, grid, blk, lds, s, x, w, g, e, out);
-    else hipLaunchKernelGGL(conv1x1_mfma_kernel<1>, grid, blk, lds, s, x, w, g, e, out);
+    // ring depth = B groups (8 k-values each) in flight per wave (deeper rings measured slower: they cost occupancy)
+    int ring = 4;
+    static const int dbg_ring = getenv("MSPL_PW_RING") ? atoi(getenv("MSPL_PW_RING")) : 0;
+    if (nsub < 4 && (dbg_ring == 4 || dbg_ring == 8 || dbg_ring == 16)) ring = dbg_ring;
+#define MSPL_PW(NS, RG) hipLaunchKernelGGL((conv1x1_mfma_kernel<NS, RG>), grid, blk, lds, s, x, w, g, e, out)
+    if (nsub == 4) MSPL_PW(4, 4);
+    else if (nsub == 2) { if (ring == 16) MSPL_PW(2, 16); else if (ring == 8) MSPL_PW(2, 8); else MSPL_PW(2, 4); }
+    else { if (ring == 16) MSPL_PW(1, 16); else if (ring == 8) MSPL_PW(1, 8); else MSPL_PW(1, 4); }
+#undef MSPL_PW
+    if (g.stamps) {   // debug only: synchronous dump of the phase timeline (100 MHz ticks)
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[4 * 65536];
+        (void)hipMemcpy(host, g.stamps, (size_t)blocks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t3 = 0; double a = 0, b = 0, c = 0, late = 0;
+        for (int64_t i = 0; i < blocks; ++i) { if (host[4*i] < t0) t0 = host[4*i]; if (host[4*i+3] > t3) t3 = host[4*i+3]; a += host[4*i+1]-host[4*i]; b += host[4*i+2]-host[4*i+1]; c += host[4*i+3]-host[4*i+2]; }
+        for (int64_t i = 0; i < blocks; ++i) late += host[4*i] - t0;
+        fprintf(stderr, "[pw stamp] K=%d M=%d HW=%d blocks=%lld span=%.2fus  avg: start-delay=%.2fus fetch+stage+barrier=%.2fus kloop=%.2fus epilogue(+more tiles)=%.2fus\n",
+                g.K, g.M, g.HW, (long long)blocks, (t3-t0)/100.0, late/blocks/100.0, a/blocks/100.0, b/blocks/100.0, c/blocks/100.0);
+        static unsigned long long hwid[65536];
+        (void)hipMemcpy(hwid, g.stamps + (size_t)4 * 65536, (size_t)blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        static int cnt[8 * 4096];
+        memset(cnt, 0, sizeof(cnt));
+        int used = 0, mx = 0;
+        for (int64_t i = 0; i < blocks; ++i) {
+            const unsigned hw = (unsigned)hwid[i], xcc = (unsigned)(hwid[i] >> 32) & 7;
+            const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+            const int key = (int)(xcc * 4096 + se * 256 + sh * 16 + cu);
+            if (cnt[key]++ == 0) ++used;
+            if (cnt[key] > mx) mx = cnt[key];
+        }
+        fprintf(stderr, "[pw stamp] placement: %d distinct CUs used, max %d workgroups on one CU (hw_id sample 0x%x xcc %u)\n", used, mx,
+                (unsigned)hwid[0], (unsigned)(hwid[0] >> 32));
+    }
     MSPL_CHECK_LAUNCH("conv1x1");
     return MSPL_OK;
 }

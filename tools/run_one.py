@@ -21,6 +21,12 @@ with torch.no_grad():
         x = torch.randn(N, 24, 144, 240, device='cuda'); w4 = torch.randn(4, 24, 3, 3, device='cuda')
         for _ in range(3):
             ops.eesp_dw_hff(x, w4, [1, 2, 3, 4], 2)
+    elif what == 'pw_l4exp':
+        x = torch.randn(N, 512, 18, 30, device='cuda'); w = torch.randn(512, 128, 1, 1, device='cuda')
+        r = torch.randn(N, 512, 18, 30, device='cuda')
+        sc = torch.ones(512, device='cuda')
+        for _ in range(3):
+            ops.conv1x1(x, w, 4, Epi(sc, sc, sc, residual=r))
     elif what == 'pw_l3exp':
         x = torch.randn(N, 256, 36, 60, device='cuda'); w = torch.randn(256, 64, 1, 1, device='cuda')
         r = torch.randn(N, 256, 36, 60, device='cuda')
