@@ -29,6 +29,7 @@ BATCH = 16
 H, W = 288, 480
 CLASSES = 13
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PATH_BYTES_PER_IMAGE = 356.9e6   # whole forward, ESPDNet-UE s=2.0 C=13 at 288x480
 
 
 def k2_algorithmic_bytes(model, n_img, h, w):
@@ -179,6 +180,13 @@ def main():
             best = t if best is None or t < best else best
         k2_ms.append(best)
     k2_bytes, k2_launches = k2_algorithmic_bytes(model, BATCH, H, W)
+    # HBM bytes per K2 launch from the PMC counters (FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
+    # the MI355X guide prescribes; tools/k2_traffic.py writes the summary).  bench.py cannot run rocprofv3 on itself.
+    k2_traffic, k2_traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_k2_hbm_traffic.json')
+    if os.path.exists(tpath):
+        k2_traffic = int(json.load(open(tpath))['avg_traffic_bytes_per_launch'])
+        k2_traffic_src = 'profiles/r01_k2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
     avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
     achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
 
@@ -203,9 +211,16 @@ def main():
                        'sharding': 'image list sharded by rank, no data-path collective'},
             'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff_kernel (K2, %d launches/forward)' % k2_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': k2_traffic,
+                         'traffic_source': k2_traffic_src,
                          'algorithmic_bytes_per_launch': int(k2_bytes / k2_launches),
                          'avg_launch_us': round(avg_launch_s * 1e6, 3)},
+            # the whole hot path against SURVEY section 8(d)'s algorithmic activation traffic (356.9 MB/image at 288x480,
+            # convs as in+out, the EESP branches as one shared read, BN/PReLU/add/cat fused = 0)
+            'path_roofline': {'algorithmic_bytes_per_image': PATH_BYTES_PER_IMAGE,
+                              'achieved': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9, 1),
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, shape)
