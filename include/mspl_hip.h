@@ -125,6 +125,16 @@ int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t HW, const m
 int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
                       int32_t HW, float* mean_ws, float* gate, void* stream);
 
+/* K6 prologue: the low-resolution branches' maps for mspl_pyrpool_fused_fwd in ONE launch (one workgroup per (image,
+ *     channel) plane): out[i] (N,P,hs[i],ws[i]) = dw3x3(adaptive_avg_pool2d(x, (hs[i],ws[i]))) with stage_w[i] (P,1,3,3);
+ *     nn_layers/efficient_pyramid_pool.py:44-50 for the scales < 1.  A workgroup stages a band of input rows and the
+ *     pooled rows it yields in LDS; mspl_pyr_down_prep_lds_bytes() returns the bytes that takes for a shape, or 0 when no
+ *     band fits (very wide maps: use mspl_adaptive_avgpool_fwd + mspl_conv3x3_fwd per branch instead). */
+int64_t mspl_pyr_down_prep_lds_bytes(int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                                     const int32_t* ws);
+int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                           const int32_t* ws, const float* const* stage_w, float* const* out, void* stream);
+
 /* K6  fused EfficientPyrPool body: all branches + merge_layer.0 (BN+PReLU) + Shuffle + merge_layer.2 (grouped
  *     3x3 + BN + PReLU) in one pass over the projected tensor.  Replaces nn_layers/efficient_pyramid_pool.py:39-58
  *     (everything between projection_layer and the final 1x1) and cnn_utils.py:119-125.

@@ -59,6 +59,9 @@ SIGNATURES = {
     'mspl_weighted_ce_fwd': [c_f32p, ctypes.c_void_p, c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_weighted_ce_bwd': [c_f32p, ctypes.c_void_p, c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, c_f32p, c_f32p,
                              ctypes.c_void_p],
+    'mspl_pyr_down_prep_lds_bytes': [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)],
+    'mspl_pyr_down_prep_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],
@@ -75,6 +78,7 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
     lib.mspl_version.restype = ctypes.c_char_p
     lib.mspl_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.mspl_last_error.restype = ctypes.c_size_t

@@ -441,10 +441,16 @@ class EfficientPyrPool(nn.Module):
     def forward_fused(self, x, sizes):
         N, P, height, width = x.shape
         stage_ws, down_es = [], []
+        down = [i for i, (h_s, w_s) in enumerate(sizes) if self.scales[i] < 1.0 and (h_s, w_s) != (height, width)]
+        prepped = {}
+        if down and ops.pyr_down_prep_fits(x.shape, [sizes[i] for i in down]):        # all low-res maps in one launch
+            maps = ops.pyr_down_prep(x, [sizes[i] for i in down], [self.stages[i].weight for i in down])
+            prepped = dict(zip(down, maps))
         for i, (stage, (h_s, w_s)) in enumerate(zip(self.stages, sizes)):
-            if self.scales[i] < 1.0 and (h_s, w_s) != (height, width):   # (same-size pool/resize are identities)
+            if i in down:                                                 # (same-size pool/resize are identities)
                 stage_ws.append(None)
-                down_es.append(ops.conv3x3(ops.adaptive_avgpool(x, (h_s, w_s)), stage.weight, P))
+                down_es.append(prepped[i] if i in prepped else
+                               ops.conv3x3(ops.adaptive_avgpool(x, (h_s, w_s)), stage.weight, P))
             else:
                 stage_ws.append(stage.weight)
                 down_es.append(None)

@@ -189,6 +189,40 @@ def gap_gate(x, w):
     return gate
 
 
+def pyr_down_prep_fits(shape, sizes):
+    """True when pyr_down_prep can stage a row band of an (N,P,h,w) map with these branch sizes in LDS
+    (else: adaptive_avgpool + conv3x3 per branch)."""
+    nb = len(sizes)
+    N, P, h, w = [int(v) for v in shape]
+    if nb < 1 or nb > 4 or any(int(s[0]) > h or int(s[1]) > w for s in sizes):
+        return False
+    hs = (ctypes.c_int32 * nb)(*[int(s[0]) for s in sizes])
+    ws = (ctypes.c_int32 * nb)(*[int(s[1]) for s in sizes])
+    return lib.mspl_pyr_down_prep_lds_bytes(N, P, h, w, nb, hs, ws) > 0
+
+
+def pyr_down_prep(x, sizes, stage_ws):
+    """K6 prologue: [dw3x3(adaptive_avg_pool2d(x, size_i)) for each low-resolution branch] in one launch."""
+    x = _f32(x, 'x')
+    N, P, h, w = x.shape
+    nb = len(sizes)
+    hs = (ctypes.c_int32 * nb)(*[int(s[0]) for s in sizes])
+    ws = (ctypes.c_int32 * nb)(*[int(s[1]) for s in sizes])
+    sw, op = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+    outs, keep = [], []
+    for i in range(nb):
+        t = _f32(stage_ws[i], 'stage weight')
+        if t.numel() != P * 9:
+            raise RuntimeError('mspl_amd: pyramid stage weight %s, expected (%d,1,3,3)' % (tuple(t.shape), P))
+        keep.append(t)
+        sw[i] = t.data_ptr()
+        o = torch.empty((N, P, int(sizes[i][0]), int(sizes[i][1])), device=x.device, dtype=torch.float32)
+        outs.append(o)
+        op[i] = o.data_ptr()
+    check(lib.mspl_pyr_down_prep_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, op, _stream()))
+    return outs
+
+
 def pyrpool_fused(x, sizes, stage_ws, down_es, br_scale, br_shift, br_alpha, merge_w, ep=None, out=None):
     """K6.  x (N,P,h,w); sizes: [(hs,ws)] per branch; stage_ws / down_es: per-branch tensors or None."""
     x = _f32(x, 'x')

@@ -207,3 +207,20 @@ def test_pyrpool_fused_equals_unfused_and_oracle(cfg):
         ref = onet.pyr_pool(x, {'m.' + k: v for k, v in sd.items()}, 'm', lbr)
     close(yu, ref, atol=5e-5)
     close(yf, ref, atol=5e-5)
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 144, 240, [(72, 120), (15, 24)]), (1, 8, 18, 30, [(9, 15), (5, 5)]),
+                                 (2, 4, 33, 47, [(17, 24), (5, 5)]), (1, 3, 7, 9, [(5, 5)]), (1, 2, 36, 60, [(18, 30), (5, 6), (36, 60)])])
+def test_pyr_down_prep(cfg):
+    """One-launch low-resolution pyramid maps == adaptive_avg_pool2d + depthwise 3x3 (torch CPU), incl. overlapping and
+    ragged pooling windows, a branch as large as the map, and the LDS-size query."""
+    from mspl_amd import ops
+    N, P, h, w, sizes = cfg
+    x = rnd(N, P, h, w, seed=4)
+    ws = [rnd(P, 1, 3, 3, seed=10 + i) for i in range(len(sizes))]
+    assert ops.pyr_down_prep_fits(x.shape, sizes)
+    outs = ops.pyr_down_prep(x.to(DEV), sizes, [t.to(DEV) for t in ws])
+    for o, sz, wt in zip(outs, sizes, ws):
+        ref = F.conv2d(F.adaptive_avg_pool2d(x, sz), wt, padding=1, groups=P)
+        close(o, ref, atol=2e-5)
+    assert not ops.pyr_down_prep_fits((1, 1, 4096, 8192), [(5, 5)])     # 800-row windows: left to the per-branch kernels

@@ -112,3 +112,20 @@ if __name__ == '__main__':
         bench_k2()
     if what in ('pyr', 'all'):
         bench_pyr()
+
+
+def bench_prep():
+    from mspl_amd import ops as O
+    N, P = 16, 16
+    for h, w in [(18, 30), (36, 60), (72, 120), (144, 240)]:
+        import math
+        sizes = [(max(math.ceil(h * s), 5), max(math.ceil(w * s), 5)) for s in (0.5, 0.1)]
+        x = torch.randn(N, P, h, w, device=DEV)
+        ws = [torch.randn(P, 1, 3, 3, device=DEV) for _ in sizes]
+        t_f = timeit(lambda: O.pyr_down_prep(x, sizes, ws))
+        t_s = timeit(lambda: [O.conv3x3(O.adaptive_avgpool(x, sz), wt, P) for sz, wt in zip(sizes, ws)])
+        print('prep %3dx%3d  fused %7.1f us   separate %7.1f us' % (h, w, t_f, t_s))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'prep':
+    bench_prep()

@@ -21,6 +21,11 @@ with torch.no_grad():
         x = torch.randn(N, 24, 144, 240, device='cuda'); w4 = torch.randn(4, 24, 3, 3, device='cuda')
         for _ in range(3):
             ops.eesp_dw_hff(x, w4, [1, 2, 3, 4], 2)
+    elif what == 'prep4':
+        x = torch.randn(N, 16, 144, 240, device='cuda')
+        ws = [torch.randn(16, 1, 3, 3, device='cuda') for _ in range(2)]
+        for _ in range(3):
+            ops.pyr_down_prep(x, [(72, 120), (15, 24)], ws)
     elif what == 'pw_l4exp':
         x = torch.randn(N, 512, 18, 30, device='cuda'); w = torch.randn(512, 128, 1, 1, device='cuda')
         r = torch.randn(N, 512, 18, 30, device='cuda')
