@@ -14,16 +14,27 @@ namespace mspl {
 struct RsGeom {
     int N, C, Hi, Wi, Ho, Wo;
     int XS;           // ceil(Wo / 4)
+    unsigned mag_xs;  // ceil(2^32 / XS): s / XS == __umulhi(s, mag_xs) for s * XS < 2^32
     float sh, sw;     // bilinear scales
 };
 
-// Decode a flat strip index into (n, c, y, x0).
-__device__ __forceinline__ void strip_decode(int64_t idx, const RsGeom& g, int& n, int& c, int& y, int& x0) {
-    const int xs = (int)(idx % g.XS);  idx /= g.XS;
-    y = (int)(idx % g.Ho);  idx /= g.Ho;
-    c = (int)(idx % g.C);
-    n = (int)(idx / g.C);
-    x0 = xs * 4;
+// Grid layout of the strip kernels: blockIdx.x walks the Ho x XS strips of one plane, (blockIdx.y, blockIdx.z) the
+// N*C planes.  The plane split is uniform (scalar unit); the strip split is one mul-hi -- the 64-bit div/mod chains of
+// a flat index were a large share of these kernels' instructions.
+__device__ __forceinline__ bool strip_decode(const RsGeom& g, int& n, int& c, int& y, int& x0) {
+    const int plane = blockIdx.z * gridDim.y + blockIdx.y;
+    const unsigned s = blockIdx.x * 256u + threadIdx.x;
+    if (plane >= g.N * g.C || s >= (unsigned)(g.Ho * g.XS)) return false;
+    n = plane / g.C;  c = plane - n * g.C;
+    y = g.XS == 1 ? (int)s : (int)__umulhi(s, g.mag_xs);       // (ceil(2^32 / 1) does not fit the 32-bit magic)
+    x0 = ((int)s - y * g.XS) * 4;
+    return true;
+}
+
+static inline dim3 strip_grid(const RsGeom& g) {
+    const int planes = g.N * g.C;
+    const int gy = planes < 65535 ? planes : 65535;
+    return dim3((unsigned)ceil_div(g.Ho * g.XS, 256), (unsigned)gy, (unsigned)ceil_div(planes, gy));
 }
 
 __device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n, int c, int y, int x0,
@@ -47,36 +58,51 @@ __device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n
 }
 
 __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restrict__ x, RsGeom g, Epi e,
-                                                           float* __restrict__ out, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+                                                           float* __restrict__ out) {
     int n, c, y, x0;
-    strip_decode(idx, g, n, c, y, x0);
+    if (!strip_decode(g, n, c, y, x0)) return;
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // input columns 2*x0-1 .. 2*x0+7; 2*x0 is a multiple of 8, so with Wi % 4 == 0 the 8 interior columns are
-    // two aligned 16-byte loads and only the left neighbour is a scalar load
+    // two aligned 16-byte loads and only the left neighbour is a scalar load.  The three rows are read branch-free
+    // (clamped row index, zero weight outside the image) so that all nine loads are in flight together.
     const bool vec = ((g.Wi & 3) == 0) && (2 * x0 + 7 < g.Wi);
+    if (vec) {
+        float4 a[3], b[3];
+        float l[3], m[3];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * y - 1 + ky;
-        if (iy < 0 || iy >= g.Hi) continue;
-        const float* row = src + (size_t)iy * g.Wi;
-        float rv[9];
-        if (vec) {
-            const float4 a = *reinterpret_cast<const float4*>(row + 2 * x0);
-            const float4 b = *reinterpret_cast<const float4*>(row + 2 * x0 + 4);
-            rv[0] = x0 > 0 ? row[2 * x0 - 1] : 0.f;
-            rv[1] = a.x; rv[2] = a.y; rv[3] = a.z; rv[4] = a.w; rv[5] = b.x; rv[6] = b.y; rv[7] = b.z; rv[8] = b.w;
-        } else {
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * y - 1 + ky;
+            m[ky] = (iy >= 0 && iy < g.Hi) ? 1.f : 0.f;
+            const float* row = src + (size_t)min(max(iy, 0), g.Hi - 1) * g.Wi + 2 * x0;
+            a[ky] = *reinterpret_cast<const float4*>(row);
+            b[ky] = *reinterpret_cast<const float4*>(row + 4);
+            l[ky] = row[x0 > 0 ? -1 : 0];
+        }
+        const float lm = x0 > 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float w = m[ky];
+            acc[0] += w * ((lm * l[ky] + a[ky].x) + a[ky].y);
+            acc[1] += w * ((a[ky].y + a[ky].z) + a[ky].w);
+            acc[2] += w * ((a[ky].w + b[ky].x) + b[ky].y);
+            acc[3] += w * ((b[ky].y + b[ky].z) + b[ky].w);
+        }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * y - 1 + ky;
+            if (iy < 0 || iy >= g.Hi) continue;
+            const float* row = src + (size_t)iy * g.Wi;
+            float rv[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int ix = 2 * x0 - 1 + i;
                 rv[i] = (ix >= 0 && ix < g.Wi) ? row[ix] : 0.f;
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += rv[2 * j] + rv[2 * j + 1] + rv[2 * j + 2];
+            for (int j = 0; j < 4; ++j) acc[j] += rv[2 * j] + rv[2 * j + 1] + rv[2 * j + 2];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] *= (1.0f / 9.0f);   // count_include_pad=True: divisor is always 9
@@ -84,11 +110,9 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, RsGeom g, Epi e,
-                                                       float* __restrict__ out, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+                                                       float* __restrict__ out) {
     int n, c, y, x0;
-    strip_decode(idx, g, n, c, y, x0);
+    if (!strip_decode(g, n, c, y, x0)) return;
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     int y0i, y1i;  float wy0, wy1;
     bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
@@ -111,11 +135,9 @@ __device__ __forceinline__ int ada_start(int o, int I, int O) { return (int)(((i
 __device__ __forceinline__ int ada_end(int o, int I, int O) { return (int)((((int64_t)(o + 1)) * I + O - 1) / O); }
 
 __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ x, RsGeom g, Epi e,
-                                                               float* __restrict__ out, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+                                                               float* __restrict__ out) {
     int n, c, y, x0;
-    strip_decode(idx, g, n, c, y, x0);
+    if (!strip_decode(g, n, c, y, x0)) return;
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     const int ys = ada_start(y, g.Hi, g.Ho), ye = ada_end(y, g.Hi, g.Ho);
     float acc[4];
@@ -164,16 +186,13 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_wave_kernel(const float*
     }
 }
 
-// x and out share the destination geometry (N, ctot, HW); 4 pixels per thread.
+// x and out share the destination geometry (N, ctot, HW); 4 pixels per thread; blockIdx.y/z = plane (n, c).
 __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ x, int N, int C, Epi e,
-                                                        float* __restrict__ out, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int qs = (e.hw + 3) >> 2;
-    const int q = (int)(idx % qs);
-    int64_t r = idx / qs;
-    const int c = (int)(r % C);
-    const int n = (int)(r / C);
+                                                        float* __restrict__ out) {
+    const int plane = blockIdx.z * gridDim.y + blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (plane >= N * C || q >= ((e.hw + 3) >> 2)) return;
+    const int n = plane / C, c = plane - n * C;
     const int cabs = e.coff + c;
     const EpiCh ec = epi_channel(e, cabs);
     const int p0 = q * 4;
@@ -233,6 +252,8 @@ static int resample_common(const char* who, const float* x, float* out, int N, i
     if (int rc = check_epi(ep, C, who)) return rc;
     g.N = N; g.C = C; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo;
     g.XS = ceil_div(Wo, 4);
+    g.mag_xs = (unsigned)((0x100000000ull + g.XS - 1) / g.XS);
+    MSPL_REQUIRE((int64_t)Ho * g.XS * g.XS < (1ll << 32), MSPL_ERR_BAD_SHAPE, "%s: plane too large", who);
     g.sh = bilinear_scale(Hi, Ho);
     g.sw = bilinear_scale(Wi, Wo);
     e = make_epi(ep, C, Ho * Wo);
@@ -250,8 +271,7 @@ extern "C" int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32
     RsGeom g; Epi e; int64_t total;
     const int Ho = H > 0 ? (H - 1) / 2 + 1 : 0, Wo = W > 0 ? (W - 1) / 2 + 1 : 0;
     if (int rc = resample_common("avgpool3x3s2", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
-    hipLaunchKernelGGL(avgpool3x3s2_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, g, e, out, total);
+    hipLaunchKernelGGL(avgpool3x3s2_kernel, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out);
     MSPL_CHECK_LAUNCH("avgpool3x3s2");
     return MSPL_OK;
 }
@@ -260,8 +280,7 @@ extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t H
                                  int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream) {
     RsGeom g; Epi e; int64_t total;
     if (int rc = resample_common("bilinear", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
-    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, g, e, out, total);
+    hipLaunchKernelGGL(bilinear_kernel, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out);
     MSPL_CHECK_LAUNCH("bilinear");
     return MSPL_OK;
 }
@@ -279,8 +298,7 @@ extern "C" int mspl_adaptive_avgpool_fwd(const float* x, int32_t N, int32_t C, i
         MSPL_CHECK_LAUNCH("adaptive_avgpool(wave)");
         return MSPL_OK;
     }
-    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, g, e, out, total);
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out);
     MSPL_CHECK_LAUNCH("adaptive_avgpool");
     return MSPL_OK;
 }
@@ -291,10 +309,9 @@ extern "C" int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t 
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "pointwise: bad shape N=%d C=%d HW=%d", N, C, HW);
     if (int rc = check_epi(ep, C, "pointwise")) return rc;
     const Epi e = make_epi(ep, C, HW);
-    const int64_t total = (int64_t)N * C * ((HW + 3) / 4);
-    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "pointwise: grid too large");
-    hipLaunchKernelGGL(pointwise_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, N, C, e, out, total);
+    const int planes = N * C, gy = planes < 65535 ? planes : 65535;
+    const dim3 grid((unsigned)ceil_div((HW + 3) / 4, 256), (unsigned)gy, (unsigned)ceil_div(planes, gy));
+    hipLaunchKernelGGL(pointwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, N, C, e, out);
     MSPL_CHECK_LAUNCH("pointwise");
     return MSPL_OK;
 }
