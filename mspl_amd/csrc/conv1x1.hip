@@ -490,13 +490,13 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
     const int nw = g.G * g.M * g.K;
     for (int i = threadIdx.x; i < nw; i += 256) wl[i] = w[i];
     __syncthreads();
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)g.N * g.G * g.mtiles * g.Q;
-    if (idx >= total) return;
-    const int q = (int)(idx % g.Q);  idx /= g.Q;
-    const int mt = (int)(idx % g.mtiles);  idx /= g.mtiles;
-    const int grp = (int)(idx % g.G);
-    const int img = (int)(idx / g.G);
+    // blockIdx.y/z = (image, group, row tile) -- uniform splits on the scalar unit; blockIdx.x = pixel quads
+    int slab = blockIdx.z * gridDim.y + blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (slab >= g.N * g.G * g.mtiles || q >= g.Q) return;
+    const int mt = slab % g.mtiles;  slab /= g.mtiles;
+    const int grp = slab % g.G;
+    const int img = slab / g.G;
     const int p0 = q * 4;
     const bool v4 = (g.HW & 3) == 0;
     const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.K) * (size_t)g.HW + p0;
@@ -610,9 +610,10 @@ static int launch_small(const float* x, const float* w, int N, int Cin, int Cout
     g.mtiles = ceil_div(g.M, mt);
     const size_t lds = (size_t)Cout * g.K * sizeof(float);
     MSPL_REQUIRE(lds <= 48 * 1024, MSPL_ERR_UNSUPPORTED, "conv1x1(small-K): weight block %zu B exceeds LDS", lds);
-    const int64_t total = (int64_t)N * groups * g.mtiles * g.Q;
-    MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
-    dim3 grid((unsigned)ceil_div64(total, 256)), blk(256);
+    const int64_t slabs = (int64_t)N * groups * g.mtiles;
+    MSPL_REQUIRE(slabs < 65535ll * 65535ll, MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
+    const int gy = slabs < 65535 ? (int)slabs : 65535;
+    dim3 grid((unsigned)ceil_div(g.Q, 256), (unsigned)gy, (unsigned)ceil_div64(slabs, gy)), blk(256);
     if (mt == 2) hipLaunchKernelGGL(conv1x1_valu_kernel<2>, grid, blk, lds, s, x, w, g, e, out);
     else if (mt == 4) hipLaunchKernelGGL(conv1x1_valu_kernel<4>, grid, blk, lds, s, x, w, g, e, out);
     else hipLaunchKernelGGL(conv1x1_valu_kernel<8>, grid, blk, lds, s, x, w, g, e, out);

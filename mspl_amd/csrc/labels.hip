@@ -98,6 +98,84 @@ __global__ __launch_bounds__(256) void label_epilogue_kernel(const float* __rest
     }
 }
 
+// Label pass form (labels and / or the KL map only, C <= CMAX): one thread per output pixel, a workgroup per piece of
+// one output row, so the row interpolation is uniform; the 2*C interpolated logits are kept in registers (all their loads
+// are independent and issue together), then max / exp-sum passes run on registers: one exp per class and head instead of
+// the online form's rescaling exps, and no 64-bit index arithmetic.
+template <int CMAX>
+__global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
+                                                                 LeGeom g, const uint8_t* __restrict__ lut,
+                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, n = blockIdx.z;
+    if (x >= g.W) return;
+    int my0, my1, mx0, mx1;  float mwy0, mwy1, mwx0, mwx1;
+    bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);                      // uniform
+    bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
+    const int mplane = g.Hm * g.Wm;
+    const float* mr0 = mainp + (size_t)n * g.C * mplane + my0 * g.Wm;
+    const float* mr1 = mainp + (size_t)n * g.C * mplane + my1 * g.Wm;
+    float m[CMAX], a[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        m[c] = -INFINITY;
+        if (c < g.C) {
+            const float top = mwx0 * mr0[c * mplane + mx0] + mwx1 * mr0[c * mplane + mx1];
+            const float bot = mwx0 * mr1[c * mplane + mx0] + mwx1 * mr1[c * mplane + mx1];
+            m[c] = mwy0 * top + mwy1 * bot;
+        }
+    }
+    if (auxp) {
+        int ay0, ay1, ax0, ax1;  float awy0, awy1, awx0, awx1;
+        bilinear_src(g.sha, y, g.Ha, ay0, ay1, awy0, awy1);                  // uniform
+        bilinear_src(g.swa, x, g.Wa, ax0, ax1, awx0, awx1);
+        const int aplane = g.Ha * g.Wa;
+        const float* ar0 = auxp + (size_t)n * g.C * aplane + ay0 * g.Wa;
+        const float* ar1 = auxp + (size_t)n * g.C * aplane + ay1 * g.Wa;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            a[c] = -INFINITY;
+            if (c < g.C) {
+                const float top = awx0 * ar0[c * aplane + ax0] + awx1 * ar0[c * aplane + ax1];
+                const float bot = awx0 * ar1[c * aplane + ax0] + awx1 * ar1[c * aplane + ax1];
+                a[c] = awy0 * top + awy1 * bot;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) a[c] = c < g.C ? 0.f : -INFINITY;
+    }
+    const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+    if (labels) {
+        float omax = -INFINITY;  int best = 0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
+        }
+        labels[pix] = lut ? lut[best] : (uint8_t)best;
+    }
+    if (kld) {
+        float k = 0.f;
+        if (auxp) {
+            float M1 = -INFINITY, M2 = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) { M1 = fmaxf(M1, m[c]); M2 = fmaxf(M2, a[c]); }
+            float S1 = 0.f, T1 = 0.f, S2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c < g.C) {
+                    const float e1 = expf(m[c] - M1);
+                    S1 += e1;
+                    T1 = fmaf(e1, m[c] - a[c], T1);
+                    S2 += expf(a[c] - M2);
+                }
+            }
+            k = T1 / S1 - (M1 + logf(S1)) + (M2 + logf(S2));
+        }
+        kld[pix] = k;
+    }
+}
+
 struct MergeSrc {
     const uint8_t* p[8];
 };
@@ -216,6 +294,15 @@ extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int
     g.sha = aux ? bilinear_scale(Ha, H) : 0.f; g.swa = aux ? bilinear_scale(Wa, W) : 0.f;
     const int64_t total = (int64_t)N * H * W;
     MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "label_epilogue: grid too large");
+    if (!prob && !main_up && !aux_up && C <= 24 && H <= 65535 && N <= 65535 &&
+        (int64_t)N * C * Hm * Wm < (1ll << 31) && (int64_t)N * C * (int64_t)Ha * Wa < (1ll << 31)) {
+        const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)H, (unsigned)N);
+        if (C <= 8) hipLaunchKernelGGL(label_epilogue_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
+        else if (C <= 16) hipLaunchKernelGGL(label_epilogue_reg_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
+        else hipLaunchKernelGGL(label_epilogue_reg_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
+        MSPL_CHECK_LAUNCH("label_epilogue");
+        return MSPL_OK;
+    }
     hipLaunchKernelGGL(label_epilogue_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        mainp, aux, g, lut, labels, prob, kld, main_up, aux_up, total);
     MSPL_CHECK_LAUNCH("label_epilogue");
