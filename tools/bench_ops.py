@@ -129,3 +129,32 @@ def bench_prep():
 
 if len(sys.argv) > 1 and sys.argv[1] == 'prep':
     bench_prep()
+
+
+def bench_stream():
+    from mspl_amd import ops as O
+    N = 16
+    x = torch.randn(N, 32, 144, 240, device=DEV)
+    t = timeit(lambda: O.avgpool3x3s2(x))
+    print('avgpool 32x144x240 -> 72x120: %.1f us (%.0f GB/s of in+out)' % (t, (x.numel() * 4 * 1.25) / t / 1e3))
+    y = torch.randn(N, 32, 72, 120, device=DEV)
+    pre = torch.randn(N, 32, 144, 240, device=DEV)
+    sc = torch.ones(32, device=DEV)
+    t = timeit(lambda: O.bilinear(y, (144, 240), Epi(sc, sc, sc, pre_add=pre)))
+    print('bilinear 32x72x120 -> 144x240 (+pre_add, BN, PReLU): %.1f us (%.0f GB/s)' % (t, (y.numel() * 4 + 2 * pre.numel() * 4) / t / 1e3))
+    t = timeit(lambda: O.pointwise(pre, Epi(sc, sc, sc)))
+    print('pointwise 32x144x240: %.1f us (%.0f GB/s)' % (t, 2 * pre.numel() * 4 / t / 1e3))
+    img = torch.randn(N, 3, 288, 480, device=DEV)
+    w = torch.randn(32, 3, 3, 3, device=DEV)
+    sc32 = torch.ones(32, device=DEV)
+    t = timeit(lambda: O.conv3x3(img, w, 1, 2, ep=Epi(sc32, sc32, sc32)))
+    print('stem conv3x3 s2 3->32: %.1f us (%.0f GB/s)' % (t, (img.numel() * 4 + N * 32 * 144 * 240 * 4) / t / 1e3))
+    xe = torch.randn(N, 32, 144, 240, device=DEV)
+    we = torch.randn(16, 2, 3, 3, device=DEV)
+    sc16 = torch.ones(16, device=DEV)
+    t = timeit(lambda: O.conv3x3(xe, we, 16, 1, ep=Epi(sc16, sc16, sc16)))
+    print('pwconv expand 3x3 g16 32->16 @144x240: %.1f us (%.0f GB/s)' % (t, (xe.numel() * 4 * 1.5) / t / 1e3))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'stream':
+    bench_stream()
