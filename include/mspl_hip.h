@@ -230,6 +230,13 @@ int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* tar
                          int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
                          float* gaux, float* kld_out, void* stream);
 
+/* MIOU.get_iou (utilities/metrics/segmentation_miou.py:13-44) on the device: argmax (first maximum) of logits (N,C,HW), or
+ * ready labels (N,HW) uint8 (pass exactly one of the two), against int64 targets, in the reference's uint8 arithmetic (+1,
+ * 255 wraps to 0 = ignored).  hist: 3*num_classes counters [area_inter | area_pred | area_mask], accumulated into (caller
+ * zeroes); area_union = pred + mask - inter + 1e-6 is the caller's. */
+int mspl_miou_areas_fwd(const float* logits, const uint8_t* labels, const int64_t* target, int32_t N, int32_t C, int32_t HW,
+                        int32_t num_classes, unsigned long long* hist, void* stream);
+
 /* Stand-alone loss modules (callers that compose them themselves instead of the fused K11 form):
  *  PixelwiseKLD.forward (loss_fns/segmentation_loss.py:181-189): kld (N,HW) = sum_c softmax(d1)*(log_softmax(d1)-log_softmax(d2));
  *  its backward: gd1/gd2 (N,C,HW) from gkld (N,HW); either output may be NULL. */

@@ -274,6 +274,40 @@ static void launch_merge(int ncls, dim3 grid, hipStream_t st, const MergeSrc& ms
         hipLaunchKernelGGL((merge_labels_kernel<S, 16>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
 }
 
+// MIOU.get_iou (utilities/metrics/segmentation_miou.py:13-44) without the host round trip: per pixel
+//   p = uint8(argmax_c logits) + 1,  t = uint8(target) + 1   (uint8 arithmetic: 255 wraps to 0 = ignored)
+//   p = t > 0 ? p : 0;  i = (p == t) ? p : 0;  three K-bin histograms over the values 1..K (torch.histc(min=1, max=K)).
+// Integer work: LDS histograms per workgroup, one 64-bit atomic per bin and workgroup.  hist = [inter | pred | mask].
+__global__ __launch_bounds__(256) void miou_areas_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ labels,
+                                                         const int64_t* __restrict__ target, int C, int HW, int K,
+                                                         int64_t total, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[3 * 64];
+    for (int i = threadIdx.x; i < 3 * K; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        unsigned p;
+        if (logits) {
+            const int64_t n = idx / HW;
+            const float* lp = logits + (size_t)n * C * HW + (idx - n * HW);
+            float best = lp[0];  int bi = 0;
+            for (int c = 1; c < C; ++c) { const float v = lp[(size_t)c * HW]; if (v > best) { best = v; bi = c; } }
+            p = (unsigned)bi;
+        } else {
+            p = labels[idx];
+        }
+        p = (p + 1u) & 255u;
+        const unsigned t = ((unsigned)(target[idx] & 255) + 1u) & 255u;
+        if (t == 0) p = 0;
+        const unsigned in = (p == t) ? p : 0u;
+        if (in >= 1 && in <= (unsigned)K) atomicAdd(&h[in - 1], 1u);
+        if (p >= 1 && p <= (unsigned)K) atomicAdd(&h[K + p - 1], 1u);
+        if (t >= 1 && t <= (unsigned)K) atomicAdd(&h[2 * K + t - 1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * K; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -343,5 +377,21 @@ extern "C" int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64
         default: launch_merge<8>(num_classes, grid, st, ms, npix, thresh, fill, out, hist, vec_ok); break;
     }
     MSPL_CHECK_LAUNCH("merge_labels");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_miou_areas_fwd(const float* logits, const uint8_t* labels, const int64_t* target, int32_t N, int32_t C,
+                                   int32_t HW, int32_t num_classes, unsigned long long* hist, void* stream) {
+    MSPL_REQUIRE((logits != nullptr) != (labels != nullptr), MSPL_ERR_NULL_POINTER, "miou_areas: pass logits OR labels");
+    MSPL_REQUIRE(target && hist, MSPL_ERR_NULL_POINTER, "miou_areas: null pointer");
+    MSPL_REQUIRE(N > 0 && HW > 0 && (!logits || C > 0), MSPL_ERR_BAD_SHAPE, "miou_areas: bad shape N=%d C=%d HW=%d", N, C, HW);
+    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 64, MSPL_ERR_UNSUPPORTED, "miou_areas: %d classes (1..64)", num_classes);
+    const int64_t total = (int64_t)N * HW;
+    int64_t blocks = ceil_div64(total, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(miou_areas_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, labels, target, C, HW,
+                       num_classes, total, hist);
+    MSPL_CHECK_LAUNCH("miou_areas");
     return MSPL_OK;
 }

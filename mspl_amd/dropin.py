@@ -5,6 +5,7 @@ uest_seg_multi_os.py:31-46,402-409, utilities/utils.py:278-298 and train_segment
 from `data_loader.segmentation.greenhouse`.  install_dropin() registers alias modules under those names so
 the existing scripts pick up the HIP-backed classes without edits (call it before their imports run).
 """
+import os
 import sys
 import types
 
@@ -13,6 +14,11 @@ def _alias(name, **attrs):
     mod = types.ModuleType(name)
     mod.__dict__.update(attrs)
     mod.__dict__['__mspl_dropin__'] = True
+    if not attrs:
+        # a parent package created on the way: keep the reference's other sub-modules importable through it
+        # (utilities.utils, data_loader.segmentation.camvid, ...) by pointing __path__ at the real directories
+        rel = os.path.join(*name.split('.'))
+        mod.__path__ = [os.path.join(p or '.', rel) for p in sys.path if os.path.isdir(os.path.join(p or '.', rel))]
     sys.modules[name] = mod
     parent, _, leaf = name.rpartition('.')
     if parent:
@@ -48,6 +54,8 @@ def install_dropin(force=False):
     _alias('data_loader.segmentation.greenhouse', id_camvid_to_greenhouse=U.id_camvid_to_greenhouse,
            id_cityscapes_to_greenhouse=U.id_cityscapes_to_greenhouse, id_forest_to_greenhouse=U.id_forest_to_greenhouse)
     from . import losses as S
+    from . import metrics as Q
+    _alias('utilities.metrics.segmentation_miou', MIOU=Q.MIOU)
     _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,
            UncertaintyWeightedSegmentationLoss=S.UncertaintyWeightedSegmentationLoss,
            SegmentationLoss=S.SegmentationLoss, NIDLoss=S.NIDLoss)

@@ -224,3 +224,23 @@ def test_pyr_down_prep(cfg):
         ref = F.conv2d(F.adaptive_avg_pool2d(x, sz), wt, padding=1, groups=P)
         close(o, ref, atol=2e-5)
     assert not ops.pyr_down_prep_fits((1, 1, 4096, 8192), [(5, 5)])     # 800-row windows: left to the per-branch kernels
+
+
+@pytest.mark.parametrize('K,C', [(4, 5), (21, 21), (5, 13)])
+def test_miou_areas(K, C):
+    """Device MIOU.get_iou == the reference's uint8 + torch.histc arithmetic (oracle), incl. the 255 -> ignored wrap, classes
+    beyond num_classes, logits and ready-made argmax maps."""
+    from mspl_amd.metrics import MIOU
+    from oracle import labels as olab
+    N, H, W = 3, 37, 53
+    logits = rnd(N, C, H, W, seed=11)
+    tgt = torch.randint(0, C, (N, H, W), generator=torch.Generator().manual_seed(5))
+    tgt[0, :5] = 255
+    ri, ru = olab.miou_areas(logits, tgt, K)
+    m = MIOU(K)
+    gi, gu = m.get_iou(logits.to(DEV), tgt.to(DEV))
+    assert np.array_equal(gi, ri) and np.allclose(gu, ru, rtol=0, atol=1e-3)
+    gi2, gu2 = m.get_iou(logits.argmax(1).to(DEV), tgt.to(DEV))
+    assert np.array_equal(gi2, ri) and np.allclose(gu2, ru, rtol=0, atol=1e-3)
+    gi3, _ = m.get_iou((logits.to(DEV), logits.to(DEV)), tgt.to(DEV))       # (main, aux) tuple: first element
+    assert np.array_equal(gi3, ri)

@@ -125,7 +125,7 @@ def test_class_weights_rule():
 
 def test_dropin_aliases():
     import sys
-    for n in [k for k in sys.modules if k.split('.')[0] in ('nn_layers', 'model', 'loss_fns', 'data_loader')]:
+    for n in [k for k in sys.modules if k.split('.')[0] in ('nn_layers', 'model', 'loss_fns', 'data_loader', 'utilities')]:
         del sys.modules[n]
     mspl_amd.install_dropin()
     from nn_layers.eesp import EESP, DownSampler  # noqa: F401
@@ -134,6 +134,7 @@ def test_dropin_aliases():
     from data_loader.segmentation.greenhouse import id_camvid_to_greenhouse  # noqa: F401
     from loss_fns.segmentation_loss import (NIDLoss, PixelwiseKLD, SegmentationLoss,  # noqa: F401  (uest_seg_multi_os.py:36)
                                             UncertaintyWeightedSegmentationLoss)
+    from utilities.metrics.segmentation_miou import MIOU  # noqa: F401  (uest_seg_multi_os.py:33)
     from mspl_amd import losses
     assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2 and PixelwiseKLD is losses.PixelwiseKLD
     # the callers' keyword (uest_seg_multi_os.py:509) and the in-place zeroing of the ignore class (:152-153)
