@@ -15,6 +15,7 @@ self-training loop use (uest_seg_multi_os.py:605-608); it is folded into per-cha
 vectors that are cached until a parameter changes.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -68,6 +69,60 @@ def bn_fold(bn):
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
     return cached(bn, 'fold', [bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+
+# ------------------------------------------------------------------ independent branches on side streams
+# The forward has branches that do not depend on each other (the image-reinforcement chain of a DownSampler vs its
+# EESP; the three EfficientPWConv skip connections and the auxiliary decoder vs the main decoder).  Most kernels of
+# the path are single-round launches whose ramp, latency chains and tail leave CUs idle, so these branches are issued
+# on side HIP streams (fork: side waits for the current stream; join: the current stream waits for the side).  Under
+# hipGraph capture the fork/join become parallel graph branches.  Inference path only; MSPL_SIDE_STREAMS=0 disables.
+_SIDE_ENABLED = os.environ.get('MSPL_SIDE_STREAMS', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(idx, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), idx)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+    return st
+
+
+class fork(object):
+    """with fork(idx, inputs): ...   -- the body is issued on side stream idx; `inputs` are tensors produced on the
+    current stream that the body reads (their memory must not be recycled while the side stream still uses them)."""
+
+    def __init__(self, idx, inputs=()):
+        self.idx, self.inputs, self.ctx = idx, inputs, None
+
+    def __enter__(self):
+        if not _SIDE_ENABLED or _training_path() or not self.inputs:
+            return self
+        cur = torch.cuda.current_stream(self.inputs[0].device)
+        side = _side_stream(self.idx, self.inputs[0].device)
+        side.wait_stream(cur)
+        for t in self.inputs:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join(idx, outputs=()):
+    """The current stream waits for side stream idx; `outputs` were produced there and are consumed here."""
+    outs = [t for t in outputs if t is not None]
+    if not _SIDE_ENABLED or _training_path() or not outs:
+        return
+    cur = torch.cuda.current_stream(outs[0].device)
+    cur.wait_stream(_side_stream(idx, outs[0].device))
+    for t in outs:
+        t.record_stream(cur)
 
 
 def _training_path():
@@ -361,14 +416,16 @@ class DownSampler(nn.Module):
         r = None
         if input2 is not None:
             pyr = input2 if isinstance(input2, ImagePyramid) else ImagePyramid(input2)
-            r = self.inp_reinf[0](pyr.at_height(Ho))
+            with fork(0, (pyr.levels[0],)):                      # image pyramid + 3x3: independent of the EESP branch
+                r = self.inp_reinf[0](pyr.at_height(Ho))
             if r.shape[3] != Wo:
                 raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton '
                                    'dimension 3' % (Wo, r.shape[3]))
+        cat = self.eesp.reduce_transform(input)             # projection + K2 (do not need the reinforcement)
+        join(0, (r,))
         scale, shift, rw = self._epilogue_vectors(r is not None)
         ep = Epi(scale, shift, self.act.weight, reinf_r=r, reinf_w=rw)
         ops.avgpool3x3s2(input, ep, out=(out, 0))
-        cat = self.eesp.reduce_transform(input)
         ops.conv1x1(cat, self.eesp.conv_1x1_exp.conv.weight, self.eesp.k, ep, out=(out, self.nin))
         return out
 

@@ -21,7 +21,7 @@ from torch.nn import init
 from . import ops
 from . import autograd as ag
 from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path,
-                     decoder_merge)
+                     decoder_merge, fork, join)
 
 sc_ch_dict = {
     0.5: [16, 32, 64, 128, 256, 1024],
@@ -140,19 +140,28 @@ class _SegBase(nn.Module):
 
     def _decode(self, l1, l2, l3, l4, aux_layer):
         aux = None
+        # the three skip connections depend on the encoder only, the auxiliary head on one decoder stage only: both
+        # are issued on side streams (layers.fork / join) and overlap the main decoder chain
+        with fork(1, (l1, l2, l3)):
+            pw2, pw3, pw4 = self.merge_enc_dec_l2(l3), self.merge_enc_dec_l3(l2), self.merge_enc_dec_l4(l1)
         bu = self.bu_dec_l1(l4)
         if aux_layer == 0:
-            aux = self.aux_decoder(bu)
-        bu = decoder_merge(self.merge_enc_dec_l2(l3), bu, self.bu_br_l2)
+            with fork(2, (bu,)):
+                aux = self.aux_decoder(bu)
+        join(1, (pw2, pw3, pw4))
+        bu = decoder_merge(pw2, bu, self.bu_br_l2)
         bu = self.bu_dec_l2(bu)
         if aux_layer == 1:
-            aux = self.aux_decoder(bu)
-        bu = decoder_merge(self.merge_enc_dec_l3(l2), bu, self.bu_br_l3)
+            with fork(2, (bu,)):
+                aux = self.aux_decoder(bu)
+        bu = decoder_merge(pw3, bu, self.bu_br_l3)
         bu = self.bu_dec_l3(bu)
         if aux_layer == 2:
-            aux = self.aux_decoder(bu)
-        bu = decoder_merge(self.merge_enc_dec_l4(l1), bu, self.bu_br_l4)
+            with fork(2, (bu,)):
+                aux = self.aux_decoder(bu)
+        bu = decoder_merge(pw4, bu, self.bu_br_l4)
         bu = self.bu_dec_l4(bu)
+        join(2, (aux,))
         return bu, aux
 
     def get_basenet_params(self):

@@ -17,6 +17,10 @@ with torch.no_grad():
         x = torch.randn(N, 64, 36, 60, device='cuda'); w4 = torch.randn(4, 64, 3, 3, device='cuda')
         for _ in range(3):
             ops.eesp_dw_hff(x, w4, [1, 2, 3, 4], 1)
+    elif what == 'k2_l4':
+        x = torch.randn(N, 128, 18, 30, device='cuda'); w4 = torch.randn(4, 128, 3, 3, device='cuda')
+        for _ in range(3):
+            ops.eesp_dw_hff(x, w4, [1, 1, 2, 3], 1)
     elif what == 'k2_l2':
         x = torch.randn(N, 24, 144, 240, device='cuda'); w4 = torch.randn(4, 24, 3, 3, device='cuda')
         for _ in range(3):
