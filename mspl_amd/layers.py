@@ -81,11 +81,13 @@ _SIDE_ENABLED = os.environ.get('MSPL_SIDE_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
 
 
-def _side_stream(idx, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), idx)
+def _side_stream(idx, device, parent):
+    """Side stream idx of the stream `parent` (keyed by parent so that concurrent source models do not share one)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, idx, parent.cuda_stream)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -100,7 +102,7 @@ class fork(object):
         if not _SIDE_ENABLED or _training_path() or not self.inputs:
             return self
         cur = torch.cuda.current_stream(self.inputs[0].device)
-        side = _side_stream(self.idx, self.inputs[0].device)
+        side = _side_stream(self.idx, self.inputs[0].device, cur)
         side.wait_stream(cur)
         for t in self.inputs:
             t.record_stream(side)
@@ -120,7 +122,7 @@ def join(idx, outputs=()):
     if not _SIDE_ENABLED or _training_path() or not outs:
         return
     cur = torch.cuda.current_stream(outs[0].device)
-    cur.wait_stream(_side_stream(idx, outs[0].device))
+    cur.wait_stream(_side_stream(idx, outs[0].device, cur))
     for t in outs:
         t.record_stream(cur)
 

@@ -111,6 +111,8 @@ class PseudoLabelPass:
     def _run(self, images):
         maps = []
         for m, lut in zip(self.models, self.luts):
+            # (sources run one after the other: forking one HIP stream per source model on top of the models' own side
+            # streams crashed hipStreamEndCapture on ROCm 7.2 -- nested fork/join graphs are avoided)
             main, aux = _lowres(m, images)
             maps.append(ops.label_epilogue(main, aux, images.shape[2:], lut=lut)['labels'])
         return ops.merge_labels(maps, self.classes, self.thresh, NO_AGREEMENT_CLASS, self.hist), maps
