@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const float* __res
                 for (int s2 = 0; s2 < NSUB; ++s2)
                     acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * gi + kk], b[gi % RING][kk][s2], acc[s2], 0, 0, 0);
             if (gi + RING < NG) load_group(b[gi % RING], gi + RING);
+            __builtin_amdgcn_sched_barrier(0);          // keep the refill here (the scheduler would sink it to its use)
         }
 
         // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
@@ -474,6 +475,203 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const float* __res
             }
             asm volatile("" ::: "memory");   // one row quad at a time: keeps hipcc from hoisting all 16 rows' work
         }
+    }
+}
+
+// ------------------------------------------------------------------ MFMA kernel, tile-pipelined (small feature maps)
+// At 18x30 / 36x60 a launch is a single round of workgroups that all stage, all multiply and all store at the same
+// time, and a wave's time is a chain of memory round trips.  This form removes round trips instead of hiding them:
+// K / 8 is a compile-time constant, so the K loop is straight-line code and the s_waitcnt counters the compiler emits
+// are exact (a ring of B groups really stays in flight); the ring runs ACROSS pixel tiles -- the last groups of tile t
+// are refilled with the first groups of tile t+1, which then land during tile t's epilogue -- and a workgroup walks
+// several tiles with one weight staging.  Weights are read from LDS per MFMA (immediate offsets).
+template <int NSUB, int NG>
+__global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              PwGeom g, Epi e, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rowc = smem;                                                    // [ROWC][MB]
+    float* At = smem + (size_t)g.MB * ROWC;                                // [MB][KS]
+    int bid = blockIdx.x;
+    const int pg = bid % g.pgroups;  bid /= g.pgroups;
+    const int mb = bid % g.mblocks;
+    const int grp = bid / g.mblocks;
+    const int tid = threadIdx.x;
+    const int m0 = mb * g.MB;
+    const int cbase = e.coff + grp * g.M + m0;   // absolute destination channel of local row 0
+    const int wave = tid >> 6, lane = tid & 63;
+    const int WP = 4 / g.WM;
+    const int chunk = wave % g.WM, wp = wave / g.WM;
+    const int li = lane & 31, half = lane >> 5;
+    const int mrem = g.M - m0;
+    const int total_px = g.N * g.HW;
+    const size_t rowbytes = (size_t)g.HW * sizeof(float);
+    const size_t orow = (size_t)e.hw * sizeof(float);
+    const int mlh = chunk * 32 + 4 * half;
+    const bool active = chunk < g.mc_total;
+
+    constexpr int RING = (NG % 4 == 0) ? 4 : ((NG % 3 == 0) ? 3 : (NG < 4 ? NG : 2));
+    static_assert(NG % RING == 0, "ring slots must map onto the same groups in every tile");
+    float b[RING][4][NSUB];
+    float resv[16][NSUB];
+    auto tile_px = [&](int t, int& gp, bool& pok, int& img, int& p) {
+        const int ptile = (pg * g.TPW + t) * WP + wp;
+        gp = (ptile * 32 + li) * NSUB;
+        pok = gp < total_px;
+        const int gpc = pok ? gp : 0;
+        img = gpc / g.HW;  p = gpc - img * g.HW;
+        return t < g.TPW && ptile < g.ptiles;
+    };
+    auto x_base = [&](int img, int p) {
+        return reinterpret_cast<const char*>(x) + (((size_t)img * g.Cin + (size_t)grp * g.K + half) * g.HW + p) * sizeof(float);
+    };
+    auto load_group = [&](const char* xb, float (&bb)[4][NSUB], int gi) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vec_load<NSUB>(xb + (size_t)(8 * gi + 2 * kk) * rowbytes, bb[kk]);
+    };
+    auto load_residual = [&](unsigned ooff) {
+        const char* rb = reinterpret_cast<const char*>(e.residual);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int s2 = 0; s2 < NSUB; ++s2) resv[r][s2] = 0.f;
+            if (mlh + dr < mrem) vec_load<NSUB>(rb + dr * orow + ooff, resv[r]);
+        }
+    };
+
+    // first tile's operands go out before the weights are staged
+    int gp = 0, img = 0, p = 0;  bool pok = false;
+    bool have = active && tile_px(0, gp, pok, img, p);
+    const char* xb = x_base(img, p);
+    unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float));
+    if (have) {
+        if (e.residual) load_residual(ooff);
+#pragma unroll
+        for (int i = 0; i < RING; ++i) load_group(xb, b[i], i);
+    }
+    {   // weights (coalesced 16-byte loads, all in flight) and per-row constants -> LDS
+        const int kv = g.K >> 2, total = g.MB * kv;
+        const float* wg = w + ((size_t)grp * g.M + m0) * g.K;
+        constexpr int UL = 8;
+        for (int base = 0; base < total; base += 256 * UL) {
+            float4 v[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                const int m = i / kv, k = (i - m * kv) << 2;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < total && m < mrem) v[u] = *reinterpret_cast<const float4*>(wg + (size_t)m * g.K + k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = base + u * 256 + tid;
+                if (i < total) {
+                    const int m = i / kv, k = (i - m * kv) << 2;
+                    float* d = At + m * g.KS + k;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+        for (int m = tid; m < g.MB; m += 256) {
+            EpiCh c = {1.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+            if (m0 + m < g.M) c = epi_channel(e, cbase + m);
+            rowc[m] = c.scale; rowc[g.MB + m] = c.shift; rowc[2 * g.MB + m] = c.alpha;
+            rowc[3 * g.MB + m] = c.rw0; rowc[4 * g.MB + m] = c.rw1; rowc[5 * g.MB + m] = c.rw2;
+        }
+    }
+    __syncthreads();
+    if (!have) return;                                        // (no barrier follows)
+    const float* ar = At + (size_t)(chunk * 32 + li) * g.KS + half;
+
+    for (int t = 0; have; ++t) {
+        // the tile after this one (its first RING groups replace this tile's last ones in the ring); when there is
+        // none the same addresses are loaded again and dropped, so the loop body stays branch-free
+        int gpn, imgn, pn;  bool pokn;
+        const bool have_next = tile_px(t + 1, gpn, pokn, imgn, pn);
+        const char* xbn = have_next ? x_base(imgn, pn) : xb;
+
+        floatx16 acc[NSUB];
+#pragma unroll
+        for (int s2 = 0; s2 < NSUB; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float a = ar[2 * (4 * gi + kk)];
+#pragma unroll
+                for (int s2 = 0; s2 < NSUB; ++s2)
+                    acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[gi % RING][kk][s2], acc[s2], 0, 0, 0);
+            }
+            if (gi + RING < NG) load_group(xb, b[gi % RING], gi + RING);
+            else load_group(xbn, b[gi % RING], gi + RING - NG);
+            // without this the machine scheduler sinks every refill down to its first use (shorter live ranges) and
+            // the ring degenerates into load -> s_waitcnt vmcnt(0) -> mfma
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
+        float rr[3][NSUB];
+        if (e.reinf_r) {
+            const float* rp = e.reinf_r + (size_t)img * 3 * e.hw + p;
+            vec_load<NSUB>(rp, rr[0]);
+            vec_load<NSUB>(rp + e.hw, rr[1]);
+            vec_load<NSUB>(rp + 2 * (size_t)e.hw, rr[2]);
+        }
+        const float* gate = e.gate ? e.gate + (size_t)img * e.ctot + cbase : nullptr;
+        char* ob = reinterpret_cast<char*>(out);
+        const char* pb = reinterpret_cast<const char*>(e.pre_add);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int mlb = mlh + 8 * rg;
+            const float4 sc4 = *reinterpret_cast<const float4*>(rowc + mlb);
+            const float4 sh4 = *reinterpret_cast<const float4*>(rowc + g.MB + mlb);
+            const float4 al4 = *reinterpret_cast<const float4*>(rowc + 2 * g.MB + mlb);
+            float4 w04 = make_float4(0.f, 0.f, 0.f, 0.f), w14 = w04, w24 = w04;
+            if (e.reinf_r) {
+                w04 = *reinterpret_cast<const float4*>(rowc + 3 * g.MB + mlb);
+                w14 = *reinterpret_cast<const float4*>(rowc + 4 * g.MB + mlb);
+                w24 = *reinterpret_cast<const float4*>(rowc + 5 * g.MB + mlb);
+            }
+            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const float alv[4] = {al4.x, al4.y, al4.z, al4.w};
+            const float w0v[4] = {w04.x, w04.y, w04.z, w04.w}, w1v[4] = {w14.x, w14.y, w14.z, w14.w};
+            const float w2v[4] = {w24.x, w24.y, w24.z, w24.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q, ml = mlb + q;
+                const size_t rowoff = (size_t)(q + 8 * rg) * orow;
+                if (ml < mrem && pok) {
+                    float v[NSUB];
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB; ++s2) v[s2] = acc[s2][r];
+                    if (pb) {
+                        float pa[NSUB];
+                        vec_load<NSUB>(pb + rowoff + ooff, pa);
+#pragma unroll
+                        for (int s2 = 0; s2 < NSUB; ++s2) v[s2] += pa[s2];
+                    }
+                    const float gv = gate ? gate[ml] : 1.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NSUB; ++s2) {
+                        float t2 = fmaf(v[s2], scv[q], shv[q]);
+                        if (e.reinf_r) t2 += w0v[q] * rr[0][s2] + w1v[q] * rr[1][s2] + w2v[q] * rr[2][s2];
+                        if (e.residual) t2 += resv[r][s2];
+                        if (e.alpha) t2 = t2 > 0.f ? t2 : alv[q] * t2;
+                        v[s2] = t2 * gv;
+                    }
+                    vec_store<NSUB>(ob + rowoff + ooff, v);
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        // advance to the next tile (its B groups are already in flight); its residual rows are requested now
+        have = have_next;
+        gp = gpn; pok = pokn; img = imgn; p = pn; xb = xbn;
+        ooff = (unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float));
+        if (have && e.residual) load_residual(ooff);
     }
 }
 
@@ -542,6 +740,55 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
                 if (p0 + j < g.HW) dst[j] = epi_apply(e, ec, acc[m][j], img, cabs, p0 + j);
         }
     }
+}
+
+// Launch of the tile-pipelined kernel (K % 32 == 0 or K in {16, 24}, aligned weights, small feature maps).
+static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, const mspl_epilogue_t* ep, float* out,
+                       hipStream_t s) {
+    g.KS = g.K | 1;
+    int mbr = ((g.M + 31) / 32) * 32;
+    if (mbr > 128) mbr = 128;
+    while (mbr > 32 && (size_t)mbr * (g.KS + ROWC) * 4 > 40 * 1024) mbr -= 32;
+    if (mbr == 96) mbr = 64;
+    g.MB = mbr;
+    g.mblocks = ceil_div(g.M, mbr);
+    g.mc_total = mbr / 32;
+    g.WM = g.mc_total >= 3 ? 4 : g.mc_total;
+    const int wp = 4 / g.WM;
+    auto al = [](const void* p, int a) { return p == nullptr || (((uintptr_t)p) & (a - 1)) == 0; };
+    auto ok = [&](int ns) {
+        const int a = ns * 4;
+        return g.HW % ns == 0 && al(x, a) && al(out, a) && (!ep || (al(ep->pre_add, a) && al(ep->residual, a) && al(ep->reinf_r, a)));
+    };
+    int nsub = ok(2) ? 2 : 1;
+    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;
+    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    if ((dbg_nsub == 1 || dbg_nsub == 2) && ok(dbg_nsub)) nsub = dbg_nsub;
+    g.ptiles = (int)ceil_div64((int64_t)g.N * g.HW, 32 * nsub);
+    // workgroups: at most one resident round (3 per CU), each walking TPW tiles per wave
+    int tpw = 1;
+    while ((int64_t)g.G * g.mblocks * ceil_div(g.ptiles, wp * tpw) > 768) ++tpw;
+    if (dbg_tpw) tpw = dbg_tpw;
+    g.TPW = tpw;
+    g.pgroups = ceil_div(g.ptiles, wp * tpw);
+    const int64_t blocks = (int64_t)g.G * g.mblocks * g.pgroups;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
+    const dim3 grid((unsigned)blocks), blk(256);
+    const size_t lds = (size_t)g.MB * (ROWC + g.KS) * sizeof(float);
+#define MSPL_PIPE(NG) do { if (nsub == 2) hipLaunchKernelGGL((conv1x1_pipe_kernel<2, NG>), grid, blk, lds, s, x, w, g, e, out); \
+                           else hipLaunchKernelGGL((conv1x1_pipe_kernel<1, NG>), grid, blk, lds, s, x, w, g, e, out); } while (0)
+    switch (g.K >> 3) {
+        case 2: MSPL_PIPE(2); break;
+        case 3: MSPL_PIPE(3); break;
+        case 4: MSPL_PIPE(4); break;
+        case 6: MSPL_PIPE(6); break;
+        case 8: MSPL_PIPE(8); break;
+        case 12: MSPL_PIPE(12); break;
+        default: MSPL_PIPE(16); break;
+    }
+#undef MSPL_PIPE
+    MSPL_CHECK_LAUNCH("conv1x1(tile-pipelined)");
+    return MSPL_OK;
 }
 
 // Launch of the register-resident-weights kernel (K % 8 == 0, K <= 128, aligned weights).
@@ -647,6 +894,11 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     // measured (tools/bench_ops.py): the register-weights kernel wins for short K on large maps (no staging, no barrier);
     // for K >= 64 its 150-185 VGPRs leave 2 workgroups per CU and the 18x30 / 36x60 grids then need a second round
     const bool areg_shape = dbg_areg == 2 || (g.K <= 32 && (int64_t)N * HW >= 100000);
+    static const int dbg_pipe = getenv("MSPL_PW_PIPE") ? atoi(getenv("MSPL_PW_PIPE")) : 1;
+    const bool pipe_shape = true;      // measured faster than the LDS-ring and register-weights forms on every eligible shape
+    if (dbg_pipe && pipe_shape && (g.K & 7) == 0 && ng_ok && g.vecw &&
+        (size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32))
+        return launch_pipe(x, w, g, e, ep, out, s);
     if (dbg_areg && areg_shape && (g.K & 7) == 0 && ng_ok && g.vecw &&
         (size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32))
         return launch_areg(x, w, g, e, ep, out, s);
