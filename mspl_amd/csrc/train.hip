@@ -484,7 +484,7 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_REQUIRE(e == hipSuccess, MSPL_ERR_HIP, "conv_bwd_weight: memset failed: %s", hipGetErrorString(e));
     }
     const int64_t total = (int64_t)N * g.Ho * g.Wo;
-    if (K == 1 && g.cin_g >= 4 && g.cout_g >= 4) {
+    if (K == 1) {       // (the 16x16 tile is zero padded for groups with fewer channels, e.g. the 3-channel image reinforcement)
         const int tiles_m = ceil_div(g.cout_g, 16), tiles_k = ceil_div(g.cin_g, 16);
         int64_t base = (int64_t)groups * tiles_m * tiles_k;
         int chunks = 1;
