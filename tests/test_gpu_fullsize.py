@@ -1,0 +1,112 @@
+"""BASELINE.json's full sizes (bs=16, 288x480 / 256x480) through size-independent properties, plus spot checks of single
+images against the CPU oracle.  Needs a real MI355X: run with `-m gpu`.
+
+Properties used: an image's labels / KL map do not depend on its batch-mates (batch 16 == batch 1, bit for bit: every
+kernel works per image plane or per pixel); hipGraph replay == eager launches; the class histogram counts every pixel
+once; merging is a pure function of the per-source maps (bit-exact against the oracle's merge of the SAME maps); merging S
+copies of a map returns the map wherever its class is a valid greenhouse class; a graphed train step equals an eager one.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels as olab
+from oracle import net as onet
+from tests.conftest import GOLDEN
+from tests.synth import synth_input, synth_labels, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+DEV = 'cuda'
+
+
+def _net(C, ds, seed):
+    from mspl_amd import models as M
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = M.ESPDNetwithUncertaintyEstimation(a, classes=C, dataset=ds, fix_pyr_plane_proj=True)
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % C], seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def test_config2_self_label_pass_bs16_288x480():
+    """BASELINE configs[1]: ESPDNet-UE s=2.0 C=13 single-source label pass, 16x3x288x480."""
+    from mspl_amd import uest
+    m, sd = _net(13, 'camvid', 0)
+    x = synth_input((16, 3, 288, 480), 77)
+    eager = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=False)
+    lab, kld = eager(x.to(DEV))
+    lab, kld = lab.clone(), kld.clone()
+    assert lab.shape == (16, 288, 480) and lab.dtype == torch.uint8 and kld.shape == (16, 288, 480)
+    assert int(eager.hist.sum()) == 16 * 288 * 480                       # every pixel counted once
+    np.testing.assert_array_equal(eager.hist.cpu().numpy(), np.bincount(lab.cpu().numpy().ravel(), minlength=13))
+    assert torch.isfinite(kld).all() and float(kld.min()) > -1e-5        # a KL divergence
+    # hipGraph replay == eager, twice (static buffers are reused)
+    graphed = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=True)
+    for _ in range(2):
+        lg, kg = graphed(x.to(DEV))
+        assert torch.equal(lg, lab) and torch.equal(kg, kld)
+    # batch independence: image i alone gives the same bits
+    solo = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=False)
+    for i in (0, 7, 15):
+        li, ki = solo(x[i:i + 1].to(DEV))
+        assert torch.equal(li[0], lab[i]) and torch.equal(ki[0], kld[i])
+    # one image against the CPU oracle at full size
+    with torch.no_grad():
+        main, aux = onet.espdnet_ue_forward(sd, x[3:4])
+        prob, kref = olab.get_output(main, aux)
+    ref = olab.argmax_labels(prob)[0]
+    top2 = np.sort(prob.numpy()[0], axis=0)[-2:]
+    clear = (top2[1] - top2[0]) > 1e-4                                   # away from fp32 ties of the reference itself
+    got = lab[3].cpu().numpy()
+    assert (got == ref)[clear].all() and clear.mean() > 0.99
+    np.testing.assert_allclose(kld[3].cpu().numpy(), kref.numpy()[0], rtol=0, atol=2e-4)
+
+
+def test_config3_three_source_pass_bs16_256x480():
+    """BASELINE configs[2]: CamVid(13) + Cityscapes(20) + Forest(5) -> LUT -> merge('all') -> histogram, 16x3x256x480."""
+    from mspl_amd import ops, uest
+    specs = [(13, 'camvid', 'camvid'), (20, 'city', 'cityscapes'), (5, 'forest', 'forest')]
+    nets = [_net(C, ds, 60 + i)[0] for i, (C, ds, _) in enumerate(specs)]
+    x = synth_input((16, 3, 256, 480), 5)
+    p = uest.PseudoLabelPass(nets, [s[2] for s in specs], merge_label_policy='all', device=DEV, use_graph=True)
+    merged = p(x.to(DEV)).clone()
+    maps = [t.clone() for t in p.source_maps(x.to(DEV))]
+    np_maps = np.stack([t.cpu().numpy() for t in maps])
+    ref = olab.merge_outputs(np_maps.reshape(3, -1, 480), 5, 'all').reshape(16, 256, 480)     # integer stage: bit-exact
+    np.testing.assert_array_equal(merged.cpu().numpy(), ref.astype(np.uint8))
+    p.reset()
+    again = p(x.to(DEV))
+    assert torch.equal(again, merged)
+    np.testing.assert_array_equal(p.hist.cpu().numpy(), np.bincount(ref.ravel(), minlength=5)[:5])
+    assert int(p.hist.sum()) == 16 * 256 * 480
+    # merging S copies of one map is the identity on valid classes (and 4 elsewhere)
+    same = ops.merge_labels([maps[0]] * 3, 5, 3, 4).cpu().numpy()
+    m0 = maps[0].cpu().numpy()
+    np.testing.assert_array_equal(same, np.where(m0 < 5, m0, 4).astype(np.uint8))
+    # batch independence of the whole multi-source pass
+    p1 = uest.PseudoLabelPass(nets, [s[2] for s in specs], merge_label_policy='all', device=DEV, use_graph=False)
+    assert torch.equal(p1(x[9:10].to(DEV))[0], merged[9])
+
+
+def test_config3_train_step_bs16_256x480():
+    """The uest train step at the benchmark size: finite loss and gradients, graphed == eager, loss goes down."""
+    from mspl_amd import training
+    x = synth_input((16, 3, 256, 480), 8).to(DEV)
+    y = synth_labels((16, 256, 480), 5, 8).to(DEV)
+    cw = torch.ones(5)
+    nets = [_net(5, 'greenhouse', 3)[0].to(DEV).eval() for _ in range(2)]
+    l0, opt = training.train_step(nets[0], x, y, cw, None, ignore_idx=4)
+    assert all(torch.isfinite(p.grad).all() for p in opt.params)
+    eager = [float(l0)]
+    for _ in range(3):
+        l, opt = training.train_step(nets[0], x, y, cw, opt, ignore_idx=4)
+        eager.append(float(l))
+    gs = training.GraphedTrainStep(nets[1], x, y, cw, ignore_idx=4)
+    graphed = [float(gs(x, y)) for _ in range(2)]
+    assert np.isfinite(eager).all() and eager[-1] < eager[0]
+    np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4)
