@@ -114,6 +114,43 @@ __device__ __forceinline__ float epi_apply(const Epi& e, const EpiCh& c, float v
     return v;
 }
 
+// Four consecutive pixels p .. p+3 of one row (hw % 4 == 0 and p % 4 == 0: every per-pixel operand is one 16-byte
+// load instead of four 4-byte loads with their own 64-bit address arithmetic).  Same operation order as epi_apply.
+__device__ __forceinline__ float4 epi_apply4(const Epi& e, const EpiCh& c, const float (&a)[4], int n, int cabs, int p) {
+    const size_t off = ((size_t)n * e.ctot + cabs) * (size_t)e.hw + p;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (e.pre_add) {
+        const float4 t = *reinterpret_cast<const float4*>(e.pre_add + off);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], c.scale, c.shift);
+    if (e.reinf_r) {
+        const float* r = e.reinf_r + (size_t)n * 3 * e.hw + p;
+        const float4 r0 = *reinterpret_cast<const float4*>(r);
+        const float4 r1 = *reinterpret_cast<const float4*>(r + e.hw);
+        const float4 r2 = *reinterpret_cast<const float4*>(r + 2 * (size_t)e.hw);
+        v[0] += c.rw0 * r0.x + c.rw1 * r1.x + c.rw2 * r2.x;
+        v[1] += c.rw0 * r0.y + c.rw1 * r1.y + c.rw2 * r2.y;
+        v[2] += c.rw0 * r0.z + c.rw1 * r1.z + c.rw2 * r2.z;
+        v[3] += c.rw0 * r0.w + c.rw1 * r1.w + c.rw2 * r2.w;
+    }
+    if (e.residual) {
+        const float4 t = *reinterpret_cast<const float4*>(e.residual + off);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    if (e.alpha) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : c.alpha * v[j];
+    }
+    if (e.gate) {
+        const float gv = e.gate[(size_t)n * e.ctot + cabs];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gv;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ size_t epi_offset(const Epi& e, int n, int cabs, int p) {
     return ((size_t)n * e.ctot + cabs) * (size_t)e.hw + p;
 }

@@ -728,12 +728,7 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
         const EpiCh ec = epi_channel(e, cabs);
         float* dst = out + epi_offset(e, img, cabs, p0);
         if (v4) {
-            float4 o;
-            o.x = epi_apply(e, ec, acc[m][0], img, cabs, p0);
-            o.y = epi_apply(e, ec, acc[m][1], img, cabs, p0 + 1);
-            o.z = epi_apply(e, ec, acc[m][2], img, cabs, p0 + 2);
-            o.w = epi_apply(e, ec, acc[m][3], img, cabs, p0 + 3);
-            *reinterpret_cast<float4*>(dst) = o;
+            *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc[m], img, cabs, p0);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

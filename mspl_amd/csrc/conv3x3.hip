@@ -143,12 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             const EpiCh ec = epi_channel(e, cabs);
             float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
             if (((g.Wo & 3) == 0)) {
-                float4 v;
-                v.x = epi_apply(e, ec, acc[c][0], img, cabs, pix);
-                v.y = epi_apply(e, ec, acc[c][1], img, cabs, pix + 1);
-                v.z = epi_apply(e, ec, acc[c][2], img, cabs, pix + 2);
-                v.w = epi_apply(e, ec, acc[c][3], img, cabs, pix + 3);
-                *reinterpret_cast<float4*>(dst) = v;
+                *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc[c], img, cabs, pix);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)

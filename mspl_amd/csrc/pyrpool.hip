@@ -340,12 +340,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
         const int pix = y * wl_ + xb;
         float* dst = out + epi_offset(e, n, cabs, pix);
         if ((wl_ & 3) == 0) {
-            float4 v;
-            v.x = epi_apply(e, ec, acc[0], n, cabs, pix);
-            v.y = epi_apply(e, ec, acc[1], n, cabs, pix + 1);
-            v.z = epi_apply(e, ec, acc[2], n, cabs, pix + 2);
-            v.w = epi_apply(e, ec, acc[3], n, cabs, pix + 3);
-            *reinterpret_cast<float4*>(dst) = v;
+            *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc, n, cabs, pix);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

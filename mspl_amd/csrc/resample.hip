@@ -44,12 +44,7 @@ __device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n
     const int pix = y * g.Wo + x0;
     float* dst = out + epi_offset(e, n, cabs, pix);
     if ((g.Wo & 3) == 0) {
-        float4 v;
-        v.x = epi_apply(e, ec, acc[0], n, cabs, pix);
-        v.y = epi_apply(e, ec, acc[1], n, cabs, pix + 1);
-        v.z = epi_apply(e, ec, acc[2], n, cabs, pix + 2);
-        v.w = epi_apply(e, ec, acc[3], n, cabs, pix + 3);
-        *reinterpret_cast<float4*>(dst) = v;
+        *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc, n, cabs, pix);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -109,23 +104,32 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
     strip_store(e, g, n, c, y, x0, acc, out);
 }
 
+// The column sources / weights depend on the output column only: a workgroup computes the table of the columns it
+// touches once into LDS (4 floats per column) instead of four bilinear_src evaluations per thread; source reads use
+// 32-bit offsets from the plane base.
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, RsGeom g, Epi e,
                                                        float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float xtab[];      // [4 * XS][4] = {xa, xb, wx0, wx1}
+    const int ncol = 4 * g.XS;
+    for (int c = threadIdx.x; c < ncol; c += 256) {
+        int xa, xb;  float wx0, wx1;
+        bilinear_src(g.sw, min(c, g.Wo - 1), g.Wi, xa, xb, wx0, wx1);
+        xtab[4 * c] = __int_as_float(xa); xtab[4 * c + 1] = __int_as_float(xb); xtab[4 * c + 2] = wx0; xtab[4 * c + 3] = wx1;
+    }
+    __syncthreads();
     int n, c, y, x0;
     if (!strip_decode(g, n, c, y, x0)) return;
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     int y0i, y1i;  float wy0, wy1;
     bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
-    const float* r0 = src + (size_t)y0i * g.Wi;
-    const float* r1 = src + (size_t)y1i * g.Wi;
+    const int r0 = y0i * g.Wi, r1 = y1i * g.Wi;
     float acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int xx = min(x0 + j, g.Wo - 1);
-        int xa, xb;  float wx0, wx1;
-        bilinear_src(g.sw, xx, g.Wi, xa, xb, wx0, wx1);
-        const float top = wx0 * r0[xa] + wx1 * r0[xb];
-        const float bot = wx0 * r1[xa] + wx1 * r1[xb];
+        const float4 t = *reinterpret_cast<const float4*>(xtab + 4 * (x0 + j));
+        const int xa = __float_as_int(t.x), xb = __float_as_int(t.y);
+        const float top = t.z * src[r0 + xa] + t.w * src[r0 + xb];
+        const float bot = t.z * src[r1 + xa] + t.w * src[r1 + xb];
         acc[j] = wy0 * top + wy1 * bot;
     }
     strip_store(e, g, n, c, y, x0, acc, out);
@@ -199,12 +203,8 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict_
     const size_t off = epi_offset(e, n, cabs, p0);
     if ((e.hw & 3) == 0) {
         const float4 v = *reinterpret_cast<const float4*>(x + off);
-        float4 o;
-        o.x = epi_apply(e, ec, v.x, n, cabs, p0);
-        o.y = epi_apply(e, ec, v.y, n, cabs, p0 + 1);
-        o.z = epi_apply(e, ec, v.z, n, cabs, p0 + 2);
-        o.w = epi_apply(e, ec, v.w, n, cabs, p0 + 3);
-        *reinterpret_cast<float4*>(out + off) = o;
+        const float a4[4] = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<float4*>(out + off) = epi_apply4(e, ec, a4, n, cabs, p0);
     } else {
         for (int j = 0; j < 4 && p0 + j < e.hw; ++j) out[off + j] = epi_apply(e, ec, x[off + j], n, cabs, p0 + j);
     }
@@ -280,7 +280,9 @@ extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t H
                                  int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream) {
     RsGeom g; Epi e; int64_t total;
     if (int rc = resample_common("bilinear", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
-    hipLaunchKernelGGL(bilinear_kernel, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out);
+    const size_t lds = (size_t)16 * g.XS * sizeof(float);
+    MSPL_REQUIRE(lds <= 64 * 1024 && (int64_t)Hi * Wi < (1ll << 31), MSPL_ERR_UNSUPPORTED, "bilinear: output rows of %d pixels do not fit the column table", Wo);
+    hipLaunchKernelGGL(bilinear_kernel, strip_grid(g), dim3(256), lds, (hipStream_t)stream, x, g, e, out);
     MSPL_CHECK_LAUNCH("bilinear");
     return MSPL_OK;
 }
