@@ -162,7 +162,15 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     else if (g.cout_g % 2 == 0) cob = 2;
     g.coblks = g.cout_g / cob;
     const int wo4 = (g.Wo + 3) & ~3;
-    g.TW = wo4 <= 128 ? wo4 : 64;
+    g.TW = wo4;
+    if (wo4 > 128) {          // widest tile <= 128 columns that wastes the fewest columns in the last tile of a row
+        int best = 64, best_waste = 1 << 30;
+        for (int tw = 128; tw >= 64; tw -= 4) {
+            const int waste = ceil_div(g.Wo, tw) * tw - g.Wo;
+            if (waste < best_waste) { best_waste = waste; best = tw; }
+        }
+        g.TW = best;
+    }
     g.XS = g.TW / 4;
     g.tiles_x = ceil_div(g.Wo, g.TW);
     g.IWS = (((g.TW - 1) * STRIDE + 3 + 3) & ~3) + 4;
@@ -173,6 +181,9 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     while (th > 1 && lds_of(th) > 40 * 1024) th = (th + 1) / 2;
     // keep 256 threads busy: shrink the tile only while it still holds >= 256 strips
     while (th > 2 && (int64_t)g.coblks * (th / 2) * g.XS >= 512) th = th / 2;
+    // ... and shrink it further while the grid would not even give every CU a few workgroups (a lone workgroup per CU
+    // is one wave per SIMD: nothing hides its LDS latency -- the 3->32 stem ran at a third of its speed that way)
+    while (th > 2 && (int64_t)g.N * g.G * ceil_div(g.Ho, th) * ceil_div(g.Wo, g.TW) < 1536) th = th / 2;
     MSPL_REQUIRE(lds_of(th) <= 64 * 1024, MSPL_ERR_UNSUPPORTED,
                  "conv3x3: tile (cin_g=%d, cout_g=%d) does not fit LDS", g.cin_g, g.cout_g);
     g.TH = th;
