@@ -83,12 +83,41 @@ def cpu_baseline(sd, shape, seconds_budget=20.0):
             'sample': '%d images (batches of %d, %dx%d), torch-CPU oracle, %d threads' % (n, nb, shape[2], shape[3], cores)}
 
 
+def train_step_rate(dev, iters=10):
+    """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
+    KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as one hipGraph replay
+    (+ the Adam kernel) per step.  Extra field; `value` stays the label-pass metric."""
+    import torch
+    from mspl_amd import models, training
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 9))
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((BATCH, 3, 256, 480), generator=g).to(dev)
+    y = torch.randint(0, 5, (BATCH, 256, 480), generator=g).to(dev)
+    step = training.GraphedTrainStep(m, x, y, torch.ones(5), ignore_idx=4)
+    for _ in range(2):
+        step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
+            'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16 x 3 x 256 x 480 fp32, hipGraph replay + Adam kernel',
+            'loss_finite': bool(torch.isfinite(loss))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train', action='store_true', help='skip the extra train-step field')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     args = ap.parse_args()
 
@@ -251,6 +280,8 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if world == 1 and not args.no_train:
+            out['train_step'] = train_step_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, shape)
         print(json.dumps(out))
