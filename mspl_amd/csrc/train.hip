@@ -207,20 +207,53 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
     const bool act = alpha != nullptr;
     const float al = act ? alpha[ch] : 1.f;
     const size_t base = ((size_t)n * C + ch) * (size_t)HW;
-    const int per = (HW + chunks - 1) / chunks;
-    const int p0 = chunk * per, p1 = min(HW, p0 + per);
     float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        const size_t o = base + p;
-        const float u = c[o] + (pre ? pre[o] : 0.f);
-        const float z = u * sc + sh + (res ? res[o] : 0.f);
-        const float g = gy[o];
-        const float gz = (!act || z > 0.f) ? g : al * g;
+    auto one = [&](float cv, float pv, float rv, float g, float& gz, float& gcv) {
+        const float u = cv + pv;
+        const float z = u * sc + sh + rv;
+        gz = (!act || z > 0.f) ? g : al * g;
         if (act && z <= 0.f) s_alpha += g * z;
         s_scale += gz * u;
         s_shift += gz;
-        if (gz_out) gz_out[o] = gz;
-        if (gc_out) gc_out[o] = gz * sc;
+        gcv = gz * sc;
+    };
+    if ((HW & 3) == 0) {                       // 16-byte operands, two independent quads in flight per iteration
+        const int q4 = HW >> 2, per = (q4 + chunks - 1) / chunks;
+        const int q0 = chunk * per, q1 = min(q4, q0 + per);
+        const float4* c4 = reinterpret_cast<const float4*>(c + base);
+        const float4* p4 = pre ? reinterpret_cast<const float4*>(pre + base) : nullptr;
+        const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+        const float4* g4 = reinterpret_cast<const float4*>(gy + base);
+        float4* z4 = gz_out ? reinterpret_cast<float4*>(gz_out + base) : nullptr;
+        float4* o4 = gc_out ? reinterpret_cast<float4*>(gc_out + base) : nullptr;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = q0 + threadIdx.x; q < q1; q += 512) {
+            const int qb = q + 256;
+            const bool hb = qb < q1;
+            const float4 ca = c4[q], ga = g4[q], pa = p4 ? p4[q] : zero, ra = r4 ? r4[q] : zero;
+            const float4 cb = hb ? c4[qb] : zero, gb = hb ? g4[qb] : zero, pb = (hb && p4) ? p4[qb] : zero, rb = (hb && r4) ? r4[qb] : zero;
+            float4 gz, gc;
+            one(ca.x, pa.x, ra.x, ga.x, gz.x, gc.x); one(ca.y, pa.y, ra.y, ga.y, gz.y, gc.y);
+            one(ca.z, pa.z, ra.z, ga.z, gz.z, gc.z); one(ca.w, pa.w, ra.w, ga.w, gz.w, gc.w);
+            if (z4) z4[q] = gz;
+            if (o4) o4[q] = gc;
+            if (hb) {
+                one(cb.x, pb.x, rb.x, gb.x, gz.x, gc.x); one(cb.y, pb.y, rb.y, gb.y, gz.y, gc.y);
+                one(cb.z, pb.z, rb.z, gb.z, gz.z, gc.z); one(cb.w, pb.w, rb.w, gb.w, gz.w, gc.w);
+                if (z4) z4[qb] = gz;
+                if (o4) o4[qb] = gc;
+            }
+        }
+    } else {
+        const int per = (HW + chunks - 1) / chunks;
+        const int p0 = chunk * per, p1 = min(HW, p0 + per);
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const size_t o = base + p;
+            float gz, gc;
+            one(c[o], pre ? pre[o] : 0.f, res ? res[o] : 0.f, gy[o], gz, gc);
+            if (gz_out) gz_out[o] = gz;
+            if (gc_out) gc_out[o] = gc;
+        }
     }
     float v[3] = {s_scale, s_shift, s_alpha};
     __shared__ float part[3][4];
@@ -262,10 +295,11 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __re
 // two bilinear sources include it.  Output y uses source rows floor(y*sh) and +1, so the candidates for input row iy
 // are y in [ceil((iy-1)/sh), floor((iy+1)/sh)] (clamped); same along x.
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int ix = (int)(idx % g.Wi);  int64_t t = idx / g.Wi;
-    const int iy = (int)(t % g.Hi);  t /= g.Hi;            // t = n*C + c
+    const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.N * g.C || pi >= g.Hi * g.Wi) return;
+    const int iy = pi / g.Wi, ix = pi - iy * g.Wi;
+    const int64_t idx = (int64_t)t * g.Hi * g.Wi + pi;
     const float* gp = gy + (size_t)t * g.Ho * g.Wo;
     int ylo = 0, yhi = g.Ho - 1, xlo = 0, xhi = g.Wo - 1;
     if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
@@ -525,7 +559,7 @@ extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const
     MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
     int chunks = 1;
-    while ((int64_t)N * C * chunks < 2048 && HW / (chunks * 2) >= 1024) chunks *= 2;
+    while ((int64_t)N * C * chunks < 4096 && HW / (chunks * 2) >= 2048) chunks *= 2;
     const int64_t blocks = (int64_t)N * C * chunks;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: grid too large");
     hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, pre_add, residual, gy,
@@ -557,7 +591,9 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
     RsG g;
     if (int rc = rs_geom("bilinear_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
     const int64_t total = (int64_t)N * C * Hi * Wi;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)), dim3(256), 0,
+                       (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("bilinear_bwd");
     return MSPL_OK;
 }
