@@ -115,6 +115,26 @@ class fork(object):
             self.ctx.__exit__(*exc)
         return False
 
+    def mark(self):
+        """An event after the work issued so far in this branch (None when the branch runs inline): lets the main stream
+        wait for an early result (`wait_mark`) without waiting for everything the side stream was given."""
+        if self.ctx is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+
+def wait_mark(ev, outputs=()):
+    """The current stream waits for a fork.mark() event; `outputs` were produced before it on the side stream."""
+    if ev is None:
+        return
+    cur = torch.cuda.current_stream()
+    cur.wait_event(ev)
+    for t in outputs:
+        if t is not None:
+            t.record_stream(cur)
+
 
 def join(idx, outputs=()):
     """The current stream waits for side stream idx; `outputs` were produced there and are consumed here."""

@@ -21,7 +21,7 @@ from torch.nn import init
 from . import ops
 from . import autograd as ag
 from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path,
-                     decoder_merge, fork, join)
+                     decoder_merge, fork, join, wait_mark)
 
 sc_ch_dict = {
     0.5: [16, 32, 64, 128, 256, 1024],
@@ -142,23 +142,27 @@ class _SegBase(nn.Module):
         aux = None
         # the three skip connections depend on the encoder only, the auxiliary head on one decoder stage only: both
         # are issued on side streams (layers.fork / join) and overlap the main decoder chain
-        with fork(1, (l1, l2, l3)):
-            pw2, pw3, pw4 = self.merge_enc_dec_l2(l3), self.merge_enc_dec_l3(l2), self.merge_enc_dec_l4(l1)
+        with fork(1, (l1, l2, l3)) as f:
+            pw2 = self.merge_enc_dec_l2(l3);  e2 = f.mark()      # each skip connection is awaited on its own event:
+            pw3 = self.merge_enc_dec_l3(l2);  e3 = f.mark()      # stage k of the decoder starts when pw_k is ready, not
+            pw4 = self.merge_enc_dec_l4(l1);  e4 = f.mark()      # when the whole side stream has drained
         bu = self.bu_dec_l1(l4)
         if aux_layer == 0:
             with fork(2, (bu,)):
                 aux = self.aux_decoder(bu)
-        join(1, (pw2, pw3, pw4))
+        wait_mark(e2, (pw2,))
         bu = decoder_merge(pw2, bu, self.bu_br_l2)
         bu = self.bu_dec_l2(bu)
         if aux_layer == 1:
             with fork(2, (bu,)):
                 aux = self.aux_decoder(bu)
+        wait_mark(e3, (pw3,))
         bu = decoder_merge(pw3, bu, self.bu_br_l3)
         bu = self.bu_dec_l3(bu)
         if aux_layer == 2:
             with fork(2, (bu,)):
                 aux = self.aux_decoder(bu)
+        wait_mark(e4, (pw4,))                                     # the side stream's last work: it is joined here
         bu = decoder_merge(pw4, bu, self.bu_br_l4)
         bu = self.bu_dec_l4(bu)
         join(2, (aux,))
