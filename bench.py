@@ -118,6 +118,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the extra train-step field')
+    ap.add_argument('--no-bs64', action='store_true', help='skip the extra batch-64 K2 field (use for rocprofv3 --stats runs: '
+                    'its launches would mix into the per-kernel averages)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     args = ap.parse_args()
 
@@ -213,7 +215,7 @@ def main():
     # The same 13 K2 launches at 4x the batch ("report K2 at bs=16 and bs=64"): at bs=16 seven of the
     # thirteen launches move 22 MB each and are bounded by launch ramp + two memory round trips, not by bandwidth.
     k2_ms64 = []
-    if rank == 0:
+    if rank == 0 and not args.no_bs64:
         for a_, kw in calls:
             xin64 = torch.cat([a_[0]] * 4, 0)
             kw64 = {k: v for k, v in kw.items() if k != 'out'}
