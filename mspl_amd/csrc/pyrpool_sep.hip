@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
             const int r = i / NCH, m = i - r * NCH;
             const int iy = y0 - 3 + r, ix = x0 - 4 + 4 * m;
             if (iy >= 0 && iy < hl && ix >= 0 && ix < wl_ && !(g.stop_after & 1024)) goff = iy * wl_ + ix;
-            dst = (r * XWl + 4 * m) | (m > 0 ? (1 << 30) : 0) | (4 * m < XWl ? (1 << 29) : 0);     // +1: see store_x
+            const int nvalid = min(4, wl_ - ix);            // (only the row's last chunk is partial, when w % 4 != 0)
+            dst = (r * XWl + 4 * m) | (m > 0 ? (1 << 30) : 0) | (4 * m < XWl ? (1 << 29) : 0) | ((nvalid & 7) << 25);     // +1: see store_x
         };
         mk(tid, xg0, xd0);
         mk(tid + 256, xg1, xd1);
@@ -279,15 +280,25 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
 
     const size_t plane = (size_t)hl * wl_;
     const float* xpl = x + ((size_t)n * g.P + c_first) * plane;
-    auto load_x = [&](int goff) -> float4 {
-        return goff >= 0 ? *reinterpret_cast<const float4*>(xpl + goff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool w4 = (wl_ & 3) == 0;                 // rows 16-byte aligned: whole chunks, vector loads / stores
+    auto load_x = [&](int goff, int dst) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (goff < 0) return v;
+        if (w4) return *reinterpret_cast<const float4*>(xpl + goff);
+        const int nvalid = (dst >> 25) & 7;
+        const float* q = xpl + goff;
+        v.x = q[0];
+        if (nvalid > 1) v.y = q[1];
+        if (nvalid > 2) v.z = q[2];
+        if (nvalid > 3) v.w = q[3];
+        return v;
     };
     auto store_x = [&](int dst, const float4& v) {
-        float* d = xs + (dst & 0xffffff) - 1;          // chunk m covers tile cols 4m-1 .. 4m+2
+        float* d = xs + (dst & 0x1ffffff) - 1;         // chunk m covers tile cols 4m-1 .. 4m+2
         if (dst & (1 << 30)) d[0] = v.x;
         if (dst & (1 << 29)) { d[1] = v.y; d[2] = v.z; d[3] = v.w; }
     };
-    float4 xr0 = load_x(xg0), xr1 = load_x(xg1);
+    float4 xr0 = load_x(xg0, xd0), xr1 = load_x(xg1, xd1);
     float er0 = ed0 >= 0 ? *ep0 : 0.f, er1 = ed1 >= 0 ? *ep1 : 0.f;
     float cr = cp ? *cp : 0.f;
 
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
         if (ed1 >= 0) smem[ed1] = er1;
         if (ci + 1 < g.CPB) {
             xpl += plane;
-            xr0 = load_x(xg0);  xr1 = load_x(xg1);
+            xr0 = load_x(xg0, xd0);  xr1 = load_x(xg1, xd1);
             if (ed0 >= 0) { ep0 += es0; er0 = *ep0; }
             if (ed1 >= 0) { ep1 += es1; er1 = *ep1; }
             if (cp) { cp += cstride; cr = *cp; }
@@ -424,7 +435,14 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
                 v.y = fmaf(acc[1], esc, esh);  v.y = (ep_alpha && v.y <= 0.f) ? eal * v.y : v.y;
                 v.z = fmaf(acc[2], esc, esh);  v.z = (ep_alpha && v.z <= 0.f) ? eal * v.z : v.z;
                 v.w = fmaf(acc[3], esc, esh);  v.w = (ep_alpha && v.w <= 0.f) ? eal * v.w : v.w;
-                *reinterpret_cast<float4*>(dst) = v;      // w % 4 == 0 (launcher)
+                if (w4) {
+                    *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    dst[0] = v.x;
+                    if (xb + 1 < wl_) dst[1] = v.y;
+                    if (xb + 2 < wl_) dst[2] = v.z;
+                    if (xb + 3 < wl_) dst[3] = v.w;
+                }
             }
         }
         __syncthreads();   // the next plane overwrites xs / wl / E / C / B
@@ -460,13 +478,12 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
                     const float* const* stage_w, const float* const* down_e, const float* br_scale,
                     const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
                     hipStream_t stream) {
-    if ((w & 3) != 0) return 1;                                      // 16-byte rows throughout
     if (e.pre_add || e.residual || e.reinf_r || e.gate) return 1;    // only the scale/shift/PReLU epilogue
     Pyr2Geom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.P = P; g.h = h; g.w = w; g.nb = nb;
     g.br_scale = br_scale; g.br_shift = br_shift; g.br_alpha = br_alpha; g.merge_w = merge_w;
-    g.TW = w >= 32 ? 32 : w;
+    g.TW = w >= 32 ? 32 : ((w + 3) & ~3);
     g.NS = (g.TW + 2 + 3) / 4;
     g.BW = 4 * g.NS;
     g.XW = g.BW + 4;
