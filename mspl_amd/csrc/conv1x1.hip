@@ -37,6 +37,7 @@ struct PwGeom {
     int vecw;      // 16-byte aligned weights: stage with float4 loads
     unsigned long long* stamps;   // tuning aid (MSPL_PW_STAMP): 4 s_memrealtime stamps per workgroup, or null
     int astage;    // register-weights kernel: 1 = weights go global -> LDS (coalesced) -> registers, 0 = global -> registers
+    int AR;        // tile-pipelined kernel: weight rows actually staged (min(MB, M)); lanes of absent rows re-read row AR-1
 };
 
 // Per-row epilogue constants staged in LDS as six arrays of MB floats (scale, shift, alpha, rw0, rw1, rw2), so
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
         for (int i = 0; i < RING; ++i) load_group(xb, b[i], i);
     }
     {   // weights (coalesced 16-byte loads, all in flight) and per-row constants -> LDS
-        const int kv = g.K >> 2, total = g.MB * kv;
+        const int kv = g.K >> 2, total = g.AR * kv;
         const float* wg = w + ((size_t)grp * g.M + m0) * g.K;
         constexpr int UL = 8;
         for (int base = 0; base < total; base += 256 * UL) {
@@ -582,7 +583,9 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
     }
     __syncthreads();
     if (!have) return;                                        // (no barrier follows)
-    const float* ar = At + (size_t)(chunk * 32 + li) * g.KS + half;
+    // rows beyond the staged ones (M < 32: the 16-row decoder projections) read the last staged row; their results are
+    // computed and dropped (stores are masked by ml < mrem)
+    const float* ar = At + (size_t)min(chunk * 32 + li, g.AR - 1) * g.KS + half;
 
     for (int t = 0; have; ++t) {
         // the tile after this one (its first RING groups replace this tile's last ones in the ring); when there is
@@ -769,7 +772,9 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     const int64_t blocks = (int64_t)g.G * g.mblocks * g.pgroups;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
     const dim3 grid((unsigned)blocks), blk(256);
-    const size_t lds = (size_t)g.MB * (ROWC + g.KS) * sizeof(float);
+    g.AR = g.M < g.MB ? g.M : g.MB;
+    const size_t lds = ((size_t)g.MB * ROWC + (size_t)g.AR * g.KS) * sizeof(float);
+    MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "conv1x1: weight tile of %zu B exceeds LDS", lds);
 #define MSPL_PIPE(NG) do { if (nsub == 2) hipLaunchKernelGGL((conv1x1_pipe_kernel<2, NG>), grid, blk, lds, s, x, w, g, e, out); \
                            else hipLaunchKernelGGL((conv1x1_pipe_kernel<1, NG>), grid, blk, lds, s, x, w, g, e, out); } while (0)
     switch (g.K >> 3) {
@@ -779,7 +784,9 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
         case 6: MSPL_PIPE(6); break;
         case 8: MSPL_PIPE(8); break;
         case 12: MSPL_PIPE(12); break;
-        default: MSPL_PIPE(16); break;
+        case 16: MSPL_PIPE(16); break;
+        case 32: MSPL_PIPE(32); break;
+        default: MSPL_PIPE(64); break;
     }
 #undef MSPL_PIPE
     MSPL_CHECK_LAUNCH("conv1x1(tile-pipelined)");
@@ -886,12 +893,14 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     static const int dbg_areg = getenv("MSPL_PW_AREG") ? atoi(getenv("MSPL_PW_AREG")) : 1;
     const int ng8 = g.K >> 3;
     const bool ng_ok = ng8 == 2 || ng8 == 3 || ng8 == 4 || ng8 == 6 || ng8 == 8 || ng8 == 12 || ng8 == 16;
+    // K = 256 / 512 (the decoder's first projection) only when the staged rows fit LDS (few output channels)
+    const bool ng_big = (ng8 == 32 || ng8 == 64) && (size_t)((g.M < 32 ? g.M : 32) * ((g.K | 1)) + 32 * ROWC) * 4 <= 64 * 1024 && g.M <= 32;
     // measured (tools/bench_ops.py): the register-weights kernel wins for short K on large maps (no staging, no barrier);
     // for K >= 64 its 150-185 VGPRs leave 2 workgroups per CU and the 18x30 / 36x60 grids then need a second round
     const bool areg_shape = dbg_areg == 2 || (g.K <= 32 && (int64_t)N * HW >= 100000);
     static const int dbg_pipe = getenv("MSPL_PW_PIPE") ? atoi(getenv("MSPL_PW_PIPE")) : 1;
     const bool pipe_shape = true;      // measured faster than the LDS-ring and register-weights forms on every eligible shape
-    if (dbg_pipe && pipe_shape && (g.K & 7) == 0 && ng_ok && g.vecw &&
+    if (dbg_pipe && pipe_shape && (g.K & 7) == 0 && (ng_ok || ng_big) && g.vecw &&
         (size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32))
         return launch_pipe(x, w, g, e, ep, out, s);
     if (dbg_areg && areg_shape && (g.K & 7) == 0 && ng_ok && g.vecw &&
