@@ -40,9 +40,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;   // input coords of LDS (0,0)
     const int tid = threadIdx.x;
 
+    // the group's weights: the first 1024 are requested into registers NOW and written to LDS after the tile (their
+    // latency then hides under the tile's HBM round trip instead of preceding it); any rest goes the plain way
     const int nw = g.cout_g * g.cin_g * 9;
     const float* wg = w + (size_t)grp * nw;
-    for (int i = tid; i < nw; i += 256) wl[i] = wg[i];
+    float wreg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wreg[u] = (tid + 256 * u < nw) ? wg[tid + 256 * u] : 0.f;
 
     // stage input planes; LDS (r, j) <-> input (iy0 + r, ix0 + j).  The (plane, row, 16-byte chunk) space is walked
     // flat by all 256 threads with UL independent global loads in flight per thread before the first LDS write
@@ -94,6 +98,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             }
         }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (tid + 256 * u < nw) wl[tid + 256 * u] = wreg[u];
+    for (int i = tid + 1024; i < nw; i += 256) wl[i] = wg[i];
     __syncthreads();
 
     const int rows_here = min(g.TH, g.Ho - oy0);
