@@ -102,6 +102,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     for (int u = 0; u < 4; ++u)
         if (tid + 256 * u < nw) wl[tid + 256 * u] = wreg[u];
     for (int i = tid + 1024; i < nw; i += 256) wl[i] = wg[i];
+    // per-channel epilogue constants of the group -> LDS (read from global inside the item loop they were one dependent
+    // round trip per output channel and item)
+    float* cl = wl + nw;                                         // [cout_g][6] = scale, shift, alpha, rw0, rw1, rw2
+    for (int c = tid; c < g.cout_g; c += 256) {
+        const EpiCh ec = epi_channel(e, e.coff + grp * g.cout_g + c);
+        float* d = cl + c * 6;
+        d[0] = ec.scale; d[1] = ec.shift; d[2] = ec.alpha; d[3] = ec.rw0; d[4] = ec.rw1; d[5] = ec.rw2;
+    }
     __syncthreads();
 
     const int rows_here = min(g.TH, g.Ho - oy0);
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < COB; ++c) {
             const int cabs = e.coff + grp * g.cout_g + cb * COB + c;
-            const EpiCh ec = epi_channel(e, cabs);
+            const float* cc = cl + (cb * COB + c) * 6;
+            const EpiCh ec = {cc[0], cc[1], cc[2], cc[3], cc[4], cc[5]};
             float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
             if (((g.Wo & 3) == 0)) {
                 *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc[c], img, cabs, pix);
@@ -183,7 +192,7 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     g.tiles_x = ceil_div(g.Wo, g.TW);
     g.IWS = (((g.TW - 1) * STRIDE + 3 + 3) & ~3) + 4;
     auto lds_of = [&](int th) {
-        return ((size_t)g.cin_g * ((th - 1) * STRIDE + 3) * g.IWS + (size_t)g.cout_g * g.cin_g * 9) * sizeof(float);
+        return ((size_t)g.cin_g * ((th - 1) * STRIDE + 3) * g.IWS + (size_t)g.cout_g * g.cin_g * 9 + (size_t)g.cout_g * 6) * sizeof(float);
     };
     int th = g.Ho < 16 ? g.Ho : 16;
     while (th > 1 && lds_of(th) > 40 * 1024) th = (th + 1) / 2;
