@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __rest
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const float4 q = *reinterpret_cast<const float4*>(row + 4 * i);
+                        // all four elements count as used: keeps this one ds_read_b128 (hipcc otherwise narrows the
+                        // read to the elements this dilation touches and emits ~2x as many ds_read2_b32)
+                        asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
                         rv[4 * i] = q.x; rv[4 * i + 1] = q.y; rv[4 * i + 2] = q.z; rv[4 * i + 3] = q.w;
                     }
                     const float w0 = wp[k * 9 + ky * 3], w1 = wp[k * 9 + ky * 3 + 1], w2 = wp[k * 9 + ky * 3 + 2];
