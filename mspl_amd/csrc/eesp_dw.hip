@@ -165,11 +165,18 @@ __global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __rest
         for (int j = 0; j < OW; ++j) prev[j] = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            constexpr int dummy = 0; (void)dummy;
             const int d = DS::d(k);
-            float a[OW];
+            if (k > 0 && DS::d(k - 1) == d) continue;       // evaluated together with the first branch of its run
+            // branches with the same dilation read the same three rows: the run k .. k+R-1 shares one set of row reads
+            // (level 4 uses d = 1,1,2,3: 27 instead of 36 ds_read_b128 per item)
+            int R = 1;
 #pragma unroll
-            for (int j = 0; j < OW; ++j) a[j] = 0.f;
+            for (int q = k + 1; q < 4; ++q) if (DS::d(q) == d && q == k + R) ++R;
+            float a[4][OW];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < OW; ++j) a[r][j] = 0.f;
             if (!g.nocompute) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
@@ -183,35 +190,44 @@ __global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __rest
                         asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
                         rv[4 * i] = q.x; rv[4 * i + 1] = q.y; rv[4 * i + 2] = q.z; rv[4 * i + 3] = q.w;
                     }
-                    const float w0 = wp[k * 9 + ky * 3], w1 = wp[k * 9 + ky * 3 + 1], w2 = wp[k * 9 + ky * 3 + 2];
 #pragma unroll
-                    for (int j = 0; j < OW; ++j) {
-                        const int ci = 4 + j * STRIDE;
-                        a[j] = fmaf(w0, rv[ci - d], a[j]);
-                        a[j] = fmaf(w1, rv[ci], a[j]);
-                        a[j] = fmaf(w2, rv[ci + d], a[j]);
+                    for (int r = 0; r < 4; ++r) {
+                        if (r >= R) break;
+                        const float w0 = wp[(k + r) * 9 + ky * 3], w1 = wp[(k + r) * 9 + ky * 3 + 1], w2 = wp[(k + r) * 9 + ky * 3 + 2];
+#pragma unroll
+                        for (int j = 0; j < OW; ++j) {
+                            const int ci = 4 + j * STRIDE;
+                            a[r][j] = fmaf(w0, rv[ci - d], a[r][j]);
+                            a[r][j] = fmaf(w1, rv[ci], a[r][j]);
+                            a[r][j] = fmaf(w2, rv[ci + d], a[r][j]);
+                        }
                     }
                 }
             }
-            // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
-            const float sc = ep[k * 3], sh = ep[k * 3 + 1], al = ep[k * 3 + 2];
-            float v[OW];
 #pragma unroll
-            for (int j = 0; j < OW; ++j) {
-                a[j] += prev[j];
-                prev[j] = a[j];
-                float q = fmaf(a[j], sc, sh);
-                if (has_act) q = q > 0.f ? q : al * q;
-                v[j] = q;
-            }
-            float* dst = reinterpret_cast<float*>(ob + k * kstride + voff);
-            if (ovec) {
-                if constexpr (OW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-            } else {
+            for (int r = 0; r < 4; ++r) {
+                if (r >= R) break;
+                const int kk = k + r;
+                // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
+                const float sc = ep[kk * 3], sh = ep[kk * 3 + 1], al = ep[kk * 3 + 2];
+                float v[OW];
 #pragma unroll
-                for (int j = 0; j < OW; ++j)
-                    if (xb + j < g.Wo) dst[j] = v[j];
+                for (int j = 0; j < OW; ++j) {
+                    a[r][j] += prev[j];
+                    prev[j] = a[r][j];
+                    float q = fmaf(a[r][j], sc, sh);
+                    if (has_act) q = q > 0.f ? q : al * q;
+                    v[j] = q;
+                }
+                float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
+                if (ovec) {
+                    if constexpr (OW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < OW; ++j)
+                        if (xb + j < g.Wo) dst[j] = v[j];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // one branch at a time (keeps the register footprint small)
         }
