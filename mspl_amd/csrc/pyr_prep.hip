@@ -202,9 +202,13 @@ using namespace mspl;
 // Chooses the band count and the LDS layout; returns the dynamic LDS bytes, or 0 when no band count fits.
 static size_t prep_plan(PrepGeom& g, int64_t planes) {
     g.WS = (g.w + 3) & ~3;
-    int S = (int)ceil_div64(2048, planes);        // enough workgroups to fill the chip ...
+    // two bands per plane measured best for the 18x30 .. 72x120 stages (more bands = more halo rows and more tiny
+    // workgroups; the chain of phases, not the grid size, sets the time) ...
+    int S = planes >= 128 ? 2 : (int)ceil_div64(256, planes);
     if (S < 1) S = 1;
     if (S > 16) S = 16;
+    static const int dbg_s = getenv("MSPL_PREP_S") ? atoi(getenv("MSPL_PREP_S")) : 0;
+    if (dbg_s > 0) S = dbg_s;
     for (;; S *= 2) {                             // ... and few enough input rows per band to fit LDS
         g.S = S;
         int off = 0;
