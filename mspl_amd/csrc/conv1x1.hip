@@ -540,6 +540,8 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
         }
     };
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (g.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     // first tile's operands go out before the weights are staged
     int gp = 0, img = 0, p = 0;  bool pok = false;
     bool have = active && tile_px(0, gp, pok, img, p);
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
     }
     __syncthreads();
     if (!have) return;                                        // (no barrier follows)
+    if (g.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     // rows beyond the staged ones (M < 32: the 16-row decoder projections) read the last staged row; their results are
     // computed and dropped (stores are masked by ml < mrem)
     const float* ar = At + (size_t)min(chunk * 32 + li, g.AR - 1) * g.KS + half;
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        if (g.stamps && t == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0])); st2 = __builtin_amdgcn_s_memrealtime(); }
         // ---- epilogue.  Sub-tile s, register r: row = (r & 3) + 8 * (r >> 2) + 4 * half, pixel gp + s.
         float rr[3][NSUB];
         if (e.reinf_r) {
@@ -675,6 +679,11 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
         gp = gpn; pok = pokn; img = imgn; p = pn; xb = xbn;
         ooff = (unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float));
         if (have && e.residual) load_residual(ooff);
+    }
+    if (g.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g.stamps + (size_t)blockIdx.x * 4;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -772,6 +781,12 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     const int64_t blocks = (int64_t)g.G * g.mblocks * g.pgroups;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
     const dim3 grid((unsigned)blocks), blk(256);
+    {
+        static unsigned long long* stamp_buf = nullptr;
+        static const int dbg_stamp = getenv("MSPL_PW_STAMP") ? atoi(getenv("MSPL_PW_STAMP")) : 0;
+        if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)5 * 65536 * sizeof(unsigned long long));
+        g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
+    }
     g.AR = g.M < g.MB ? g.M : g.MB;
     const size_t lds = ((size_t)g.MB * ROWC + (size_t)g.AR * g.KS) * sizeof(float);
     MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "conv1x1: weight tile of %zu B exceeds LDS", lds);
@@ -790,6 +805,16 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     }
 #undef MSPL_PIPE
     MSPL_CHECK_LAUNCH("conv1x1(tile-pipelined)");
+    if (g.stamps) {   // debug only: synchronous dump of the phase timeline (100 MHz ticks)
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[4 * 65536];
+        (void)hipMemcpy(host, g.stamps, (size_t)blocks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t3 = 0; double a = 0, b = 0, c = 0, late = 0;
+        for (int64_t i = 0; i < blocks; ++i) { if (host[4*i] < t0) t0 = host[4*i]; if (host[4*i+3] > t3) t3 = host[4*i+3]; a += host[4*i+1]-host[4*i]; b += host[4*i+2]-host[4*i+1]; c += host[4*i+3]-host[4*i+2]; }
+        for (int64_t i = 0; i < blocks; ++i) late += host[4*i] - t0;
+        fprintf(stderr, "[pw-pipe stamp] K=%d M=%d HW=%d blocks=%lld tpw=%d span=%.2fus  avg: start-delay=%.2fus fetch+stage+barrier=%.2fus kloop=%.2fus epilogue(+more tiles)=%.2fus\n",
+                g.K, g.M, g.HW, (long long)blocks, g.TPW, (t3-t0)/100.0, late/blocks/100.0, a/blocks/100.0, b/blocks/100.0, c/blocks/100.0);
+    }
     return MSPL_OK;
 }
 
