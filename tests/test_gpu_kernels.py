@@ -50,7 +50,9 @@ def test_eesp_dw_unsupported_dilation_raises():
     # (N, Cin, Cout, groups, H, W)
     (2, 32, 24, 4, 16, 30), (1, 512, 512, 4, 16, 30), (2, 256, 64, 4, 9, 13), (1, 512, 16, 1, 16, 30),
     (2, 96, 96, 4, 8, 12), (1, 16, 13, 1, 17, 23), (1, 48, 16, 1, 20, 20), (2, 16, 4, 4, 10, 10),
-    (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 512, 64, 1, 4, 8)])
+    (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 512, 64, 1, 4, 8),
+    # many pixel tiles: several tiles per wave (the ring runs across tiles), 48 rows in a 64-row weight tile, odd pixel count
+    (1, 32, 16, 1, 288, 720), (1, 64, 96, 2, 160, 320), (3, 24, 8, 1, 191, 201)])
 def test_conv1x1_epilogues(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
