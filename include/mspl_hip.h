@@ -230,6 +230,13 @@ int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* tar
                          int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
                          float* gaux, float* kld_out, void* stream);
 
+/* K13  dense (groups = 1) 1x1 / dilated 3x3 convolution on the fp32 matrix cores: the ASPP heads of nn_layers/aspp.py:7-99
+ *      (Conv2d(Cin, Cout, k, padding = dilation, dilation) + BatchNorm + ReLU).  x: (N,Cin,H,W); w_packed: the conv weight
+ *      re-laid as (k*k, Cout, Cin) (tap-major, 16-byte aligned; Cin % 32 == 0); output (N,Cout,H,W) slice with the
+ *      scale / shift / alpha epilogue (fold the conv bias into shift; alpha = 0 is ReLU). */
+int mspl_dense_conv_fwd(const float* x, const float* w_packed, int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                        int32_t ksize, int32_t dilation, const mspl_epilogue_t* ep, float* out, void* stream);
+
 /* MIOU.get_iou (utilities/metrics/segmentation_miou.py:13-44) on the device: argmax (first maximum) of logits (N,C,HW), or
  * ready labels (N,HW) uint8 (pass exactly one of the two), against int64 targets, in the reference's uint8 arithmetic (+1,
  * 255 wraps to 0 = ignored).  hist: 3*num_classes counters [area_inter | area_pred | area_mask], accumulated into (caller

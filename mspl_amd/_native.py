@@ -62,6 +62,8 @@ SIGNATURES = {
     'mspl_pyr_down_prep_lds_bytes': [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)],
     'mspl_pyr_down_prep_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
+    'mspl_dense_conv_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
+                            ctypes.c_void_p],
     'mspl_miou_areas_fwd': [c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32, c_i32, c_i32, ctypes.c_void_p, ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,

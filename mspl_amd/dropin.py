@@ -53,6 +53,8 @@ def install_dropin(force=False):
     _alias('model.segmentation.espnetv2', ESPNetv2Segmentation=M.ESPNetv2Segmentation, espnetv2_seg=M.espnetv2_seg)
     _alias('data_loader.segmentation.greenhouse', id_camvid_to_greenhouse=U.id_camvid_to_greenhouse,
            id_cityscapes_to_greenhouse=U.id_cityscapes_to_greenhouse, id_forest_to_greenhouse=U.id_forest_to_greenhouse)
+    from . import aspp as A
+    _alias('nn_layers.aspp', ASPP=A.ASPP, ASPP_Bottleneck=A.ASPP_Bottleneck)
     from . import losses as S
     from . import metrics as Q
     _alias('utilities.metrics.segmentation_miou', MIOU=Q.MIOU)

@@ -134,6 +134,28 @@ def conv3x3(x, w, groups=1, stride=1, shuffle_groups=0, ep=None, out=None):
     return dst
 
 
+def pack_dense_weight(w):
+    """(Cout, Cin, k, k) conv weight -> the tap-major (k*k, Cout, Cin) layout dense_conv reads (a permute copy)."""
+    w = _f32(w, 'w')
+    Cout, Cin, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, Cout, Cin).contiguous()
+
+
+def dense_conv(x, w_packed, ksize, dilation=1, ep=None, out=None):
+    """K13.  Dense 1x1 / dilated 3x3 convolution (padding = dilation) on the matrix cores; w_packed from pack_dense_weight."""
+    x, w_packed = _f32(x, 'x'), _f32(w_packed, 'w_packed')
+    N, Cin, H, W = x.shape
+    taps = ksize * ksize
+    if w_packed.dim() != 3 or w_packed.shape[0] != taps or w_packed.shape[2] != Cin:
+        raise RuntimeError('mspl_amd: dense_conv packed weight %s does not match k=%d Cin=%d' % (tuple(w_packed.shape), ksize, Cin))
+    Cout = w_packed.shape[1]
+    dst, coff = _dest(out, (N, Cout, H, W), x)
+    s, keep = _build(ep, dst, coff, N, Cout, H * W)
+    check(lib.mspl_dense_conv_fwd(_p(x), _p(w_packed), N, Cin, Cout, H, W, ksize, int(dilation), ctypes.byref(s), _p(dst),
+                                  _stream()))
+    return dst
+
+
 def avgpool3x3s2(x, ep=None, out=None):
     x = _f32(x, 'x')
     N, C, H, W = x.shape

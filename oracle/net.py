@@ -226,3 +226,26 @@ def espnetv2_forward(sd, x):
     l1, l2, l3, l4 = _encoder(x, sd, None, 'base_net')
     bu, _ = _decoder(sd, l1, l2, l3, l4, False)
     return F.interpolate(bu, size=size, mode='bilinear', align_corners=True)
+
+
+def aspp_forward(sd, x, p=''):
+    """ASPP.forward / ASPP_Bottleneck.forward, nn_layers/aspp.py:34-52 / :80-99 (the two differ in input width only).
+
+    Biased convolutions + eval-mode BatchNorm + ReLU; the image-pooling branch is interpolated with the DEFAULT
+    align_corners=False (from a 1x1 map, i.e. a constant).  sd: reference-format state dict, p: key prefix ('' or 'head.').
+    """
+    def k(name):
+        return sd[p + name]
+
+    def cbr(t, conv, bn, **kw):
+        t = F.conv2d(t, k(conv + '.weight'), k(conv + '.bias'), **kw)
+        t = F.batch_norm(t, k(bn + '.running_mean'), k(bn + '.running_var'), k(bn + '.weight'), k(bn + '.bias'), False, 0.0, 1e-5)
+        return F.relu(t)
+    h, w = x.shape[2:]
+    outs = [cbr(x, 'conv_1x1_1', 'bn_conv_1x1_1')]
+    for i, d in enumerate((6, 12, 18)):
+        outs.append(cbr(x, 'conv_3x3_%d' % (i + 1), 'bn_conv_3x3_%d' % (i + 1), padding=d, dilation=d))
+    img = cbr(F.adaptive_avg_pool2d(x, 1), 'conv_1x1_2', 'bn_conv_1x1_2')
+    outs.append(F.interpolate(img, size=(h, w), mode='bilinear'))
+    out = cbr(torch.cat(outs, 1), 'conv_1x1_3', 'bn_conv_1x1_3')
+    return F.conv2d(out, k('conv_1x1_4.weight'), k('conv_1x1_4.bias'))

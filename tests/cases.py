@@ -34,3 +34,11 @@ MODEL_CASES = {
 
 TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), sd_seed=21, in_seed=5,
                   lr=5e-4, weight_decay=5e-4, ignore_idx=4)
+
+
+# ASPP heads (nn_layers/aspp.py, BASELINE configs[4]): name -> (class name, num_classes, input shape, sd seed, input seed).
+# Small maps on purpose: the dilations (6 / 12 / 18) then reach past every border.
+ASPP_CASES = {
+    'aspp_bottleneck_c20': ('ASPP_Bottleneck', 20, (2, 2048, 10, 14), 400, 401),
+    'aspp_c13': ('ASPP', 13, (1, 512, 20, 33), 402, 403),
+}

@@ -24,13 +24,14 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import LAYER_CASES, MODEL_CASES, TRAIN_CASE  # noqa: E402
+from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES, TRAIN_CASE  # noqa: E402
 from tests.synth import synth_input, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
 from nn_layers.efficient_pyramid_pool import EfficientPyrPool  # noqa: E402
 from nn_layers.efficient_pt import EfficientPWConv  # noqa: E402
+from nn_layers import aspp as ref_aspp  # noqa: E402
 from model.segmentation.espdnet_ue import ESPDNetwithUncertaintyEstimation  # noqa: E402
 from model.segmentation.espnetv2 import ESPNetv2Segmentation  # noqa: E402
 from loss_fns.segmentation_loss import PixelwiseKLD, UncertaintyWeightedSegmentationLoss  # noqa: E402
@@ -213,7 +214,21 @@ def gen_train():
          keep=np.array(keep), **{'after_%d' % i: pd[k].detach() for i, k in enumerate(keep)})
 
 
+def gen_aspp():
+    """ASPP / ASPP_Bottleneck logits (eval mode, randomised BN statistics and biases) + their state-dict key tables."""
+    out, keys = {}, {}
+    for name, (cls, ncls, shp, sd_seed, x_seed) in sorted(ASPP_CASES.items()):
+        m = getattr(ref_aspp, cls)(num_classes=ncls).eval()
+        keys[name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synth_state_dict(m.state_dict(), sd_seed))
+        with torch.no_grad():
+            out[name] = m(synth_input(shp, x_seed))
+    save('aspp', **out)
+    with open(os.path.join(HERE, 'aspp_keys.json'), 'w') as f:
+        json.dump(keys, f, sort_keys=True)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp']
     for w in which:
         globals()['gen_' + w]()

@@ -15,7 +15,7 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import LAYER_CASES, MODEL_CASES
+from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES
 from tests.conftest import GOLDEN
 from tests.synth import synth_input, synth_state_dict
 
@@ -227,3 +227,49 @@ def test_input_not_multiple_of_16_raises_like_reference():
     m = _build_model('espdnetue', 2.0, 5, 'greenhouse').to(DEV).eval()
     with torch.no_grad(), pytest.raises(RuntimeError, match='must match'):
         m(torch.randn(1, 3, 360, 480, device=DEV))
+
+
+@pytest.mark.parametrize('name', sorted(ASPP_CASES))
+def test_aspp_heads_vs_reference_golden(name, golden):
+    """BASELINE configs[4]: the DeepLabv3 ASPP heads (dense dilated 3x3 on the matrix cores, K13) against the reference's own
+    output and the oracle; same state_dict keys as nn_layers/aspp.py."""
+    from mspl_amd import aspp
+    cls, ncls, shp, sd_seed, x_seed = ASPP_CASES[name]
+    keys = json.load(open(os.path.join(GOLDEN, 'aspp_keys.json')))[name]
+    m = getattr(aspp, cls)(num_classes=ncls)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys
+    sd = synth_state_dict(keys, sd_seed)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = synth_input(shp, x_seed)
+    with torch.no_grad():
+        y = m(x.to(DEV)).cpu()
+        ref_o = onet.aspp_forward(sd, x)
+    ref = torch.from_numpy(golden('aspp')[name])
+    assert y.shape == ref.shape
+    # 2048 (x9) products per output: fp32 summation order differs from ATen's; logits stay well inside north_star's 1e-3
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(y, ref_o, rtol=1e-4, atol=5e-4)
+    with pytest.raises(RuntimeError, match='inference-only'):
+        m(x.to(DEV))
+
+
+def test_dense_conv_shapes():
+    """K13 alone on awkward shapes: pixel counts that are not tile multiples, fewer than 128 output channels, a channel-slice
+    destination, dilation larger than the map."""
+    import torch.nn.functional as F
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    g = torch.Generator().manual_seed(3)
+    for (N, Cin, Cout, H, W, k, d) in [(1, 64, 40, 7, 9, 3, 2), (2, 96, 130, 5, 13, 1, 1), (1, 32, 256, 11, 6, 3, 12), (3, 128, 16, 9, 9, 3, 3)]:
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+        sc, sh = torch.rand(Cout + 7, generator=g) + 0.5, torch.randn(Cout + 7, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x, w, None, 1, d * (k // 2), d) * sc[3:3 + Cout].view(1, -1, 1, 1) + sh[3:3 + Cout].view(1, -1, 1, 1))
+        dst = torch.full((N, Cout + 7, H, W), -3.0, device=DEV)
+        ops.dense_conv(x.to(DEV), ops.pack_dense_weight(w.to(DEV)), k, d, Epi(sc.to(DEV), sh.to(DEV), torch.zeros(Cout + 7, device=DEV)),
+                       out=(dst, 3))
+        torch.testing.assert_close(dst[:, 3:3 + Cout].cpu(), ref, rtol=1e-4, atol=2e-4)
+        assert torch.all(dst[:, :3] == -3.0) and torch.all(dst[:, 3 + Cout:] == -3.0)
+    with pytest.raises(RuntimeError, match='multiple of 32'):
+        ops.dense_conv(torch.zeros(1, 24, 4, 4, device=DEV), torch.zeros(1, 8, 24, device=DEV), 1)

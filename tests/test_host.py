@@ -135,6 +135,7 @@ def test_dropin_aliases():
     from loss_fns.segmentation_loss import (NIDLoss, PixelwiseKLD, SegmentationLoss,  # noqa: F401  (uest_seg_multi_os.py:36)
                                             UncertaintyWeightedSegmentationLoss)
     from utilities.metrics.segmentation_miou import MIOU  # noqa: F401  (uest_seg_multi_os.py:33)
+    from nn_layers.aspp import ASPP, ASPP_Bottleneck  # noqa: F401  (model/segmentation/deeplabv3.py)
     from mspl_amd import losses
     assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2 and PixelwiseKLD is losses.PixelwiseKLD
     # the callers' keyword (uest_seg_multi_os.py:509) and the in-place zeroing of the ignore class (:152-153)
@@ -166,3 +167,13 @@ def test_training_mode_bn_fails_loudly():
     m = layers.CBR(3, 8, 3, 2)   # fresh modules are in training mode
     with torch.no_grad(), pytest.raises(RuntimeError, match='training mode'):
         m(torch.randn(1, 3, 8, 8))
+
+
+def test_aspp_state_dict_matches_reference_tables():
+    """ASPP / ASPP_Bottleneck containers: same keys and shapes as nn_layers/aspp.py (tables written by make_golden.py)."""
+    from mspl_amd import aspp
+    from tests.cases import ASPP_CASES
+    tables = json.load(open(os.path.join(GOLDEN, 'aspp_keys.json')))
+    for name, (cls, ncls, _, _, _) in ASPP_CASES.items():
+        m = getattr(aspp, cls)(num_classes=ncls)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == tables[name]

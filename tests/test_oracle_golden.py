@@ -12,7 +12,7 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import LAYER_CASES, MODEL_CASES, TRAIN_CASE
+from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES, TRAIN_CASE
 from tests.conftest import GOLDEN
 from tests.synth import synth_input, synth_labels, synth_state_dict
 
@@ -159,3 +159,16 @@ def test_train_step(golden):
     assert sum(1 for v in g['gnorm'] if v >= 0) == 340
     for i, k in enumerate(str(s) for s in g['keep']):
         torch.testing.assert_close(new[k], torch.from_numpy(g['after_%d' % i]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', sorted(ASPP_CASES))
+def test_aspp(name, golden):
+    """Oracle restatement of nn_layers/aspp.py vs the reference's own output (BASELINE configs[4] head)."""
+    cls, ncls, shp, sd_seed, x_seed = ASPP_CASES[name]
+    keys = json.load(open(os.path.join(GOLDEN, 'aspp_keys.json')))[name]
+    sd = synth_state_dict(keys, sd_seed)
+    with torch.no_grad():
+        y = onet.aspp_forward(sd, synth_input(shp, x_seed))
+    ref = torch.from_numpy(golden('aspp')[name])
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=5e-5)
