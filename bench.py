@@ -83,6 +83,38 @@ def cpu_baseline(sd, shape, seconds_budget=20.0):
             'sample': '%d images (batches of %d, %dx%d), torch-CPU oracle, %d threads' % (n, nb, shape[2], shape[3], cores)}
 
 
+def aspp_head_rate(dev, iters=10):
+    """BASELINE configs[4]: the DeepLabv3 ASPP_Bottleneck head (three dense dilated 3x3 convolutions 2048 -> 256, K13) on
+    16 x 2048 x 32 x 64 (1024x512 at output stride 16), hipGraph replay; the MFMA-bound piece of the path.  Extra field."""
+    import torch
+    from mspl_amd import aspp
+    from tests.synth import synth_state_dict
+    m = aspp.ASPP_Bottleneck(num_classes=20)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    m = m.to(dev).eval()
+    x = torch.randn(BATCH, 2048, 32, 64, device=dev)
+    with torch.no_grad():
+        for _ in range(2):
+            m(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            m(x)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    macs = BATCH * 32 * 64 * (2048 * 256 * 28 + 1280 * 256 + 256 * 20) + BATCH * 2048 * 256
+    tf = 2 * macs / dt / 1e12
+    return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_batch': round(dt * 1e3, 3),
+            'workload': 'ASPP_Bottleneck(num_classes=20), 16 x 2048 x 32 x 64 fp32 (1024x512 @ OS16), hipGraph replay',
+            'roofline': {'bound': 'mfma', 'kernel': 'dense_conv_mfma_kernel (K13)', 'achieved': round(tf, 1), 'peak': 157.3,
+                         'unit': 'TFLOP/s', 'frac': round(tf / 157.3, 4)}}
+
+
 def train_step_rate(dev, iters=10):
     """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
     KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as one hipGraph replay
@@ -118,6 +150,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the extra train-step field')
+    ap.add_argument('--no-aspp', action='store_true', help='skip the extra ASPP-head field (BASELINE configs[4])')
     ap.add_argument('--no-bs64', action='store_true', help='skip the extra batch-64 K2 field (use for rocprofv3 --stats runs: '
                     'its launches would mix into the per-kernel averages)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
@@ -284,6 +317,8 @@ def main():
         }
         if world == 1 and not args.no_train:
             out['train_step'] = train_step_rate(dev)
+        if world == 1 and not args.no_aspp:
+            out['aspp_head'] = aspp_head_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, shape)
         print(json.dumps(out))
