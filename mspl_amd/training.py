@@ -61,8 +61,18 @@ class FlatAdam:
                 p.data = pv
                 p.grad = gv
                 off += k
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        # torch.optim spelling: the reference's adjust_learning_rate writes optimizer.param_groups[0]['lr'] (:1325-1328)
+        self.param_groups = [{'lr': lr, 'params': self.params}]
         self.step_count = 0
+
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]['lr'] = value
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -80,6 +90,18 @@ class FlatAdam:
                                  float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                  float(self.weight_decay), self.step_count, _stream()))
         layers.bump_param_epoch()       # the kernel wrote through raw pointers: invalidate folded-BN / packed-weight caches
+
+
+def lr_poly(base_lr, iter_n, max_iter, power):
+    """uest_seg_multi_os.py:1317-1321."""
+    return base_lr * ((1 - float(iter_n) / max_iter) ** power)
+
+
+def adjust_learning_rate(optimizer, i_iter, tot_iter, base_lr, power=0.0):
+    """uest_seg_multi_os.py:1325-1328 (base_lr / power are script globals there: args.learning_rate, args.power)."""
+    lr = lr_poly(base_lr, i_iter, tot_iter, power)
+    optimizer.param_groups[0]['lr'] = lr
+    return lr
 
 
 def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=None, lr=5e-4, weight_decay=5e-4,

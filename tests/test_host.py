@@ -177,3 +177,15 @@ def test_aspp_state_dict_matches_reference_tables():
     for name, (cls, ncls, _, _, _) in ASPP_CASES.items():
         m = getattr(aspp, cls)(num_classes=ncls)
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == tables[name]
+
+
+def test_lr_schedule_helpers():
+    """lr_poly / adjust_learning_rate (uest_seg_multi_os.py:1317-1328) against the formula, through the param_groups spelling."""
+    from mspl_amd import training
+
+    class Opt:
+        param_groups = [{'lr': 0.0}]
+    o = Opt()
+    assert training.lr_poly(5e-4, 10, 100, 0.0) == 5e-4
+    assert abs(training.lr_poly(1e-3, 25, 100, 0.9) - 1e-3 * 0.75 ** 0.9) < 1e-15
+    assert training.adjust_learning_rate(o, 50, 100, 2e-3, 2.0) == o.param_groups[0]['lr'] == 2e-3 * 0.25
