@@ -101,11 +101,12 @@ int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int
 int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
                           const mspl_epilogue_t* ep, float* out, void* stream);
 
-/* Bilinear resize, align_corners=True (ATen index rule) + epilogue.
- *     Replaces F.interpolate at efficient_pyramid_pool.py:48,50 and espdnet_ue.py:110,301-302.
+/* Bilinear resize (ATen index rules) + epilogue.  align_corners != 0: F.interpolate(align_corners=True) at
+ *     efficient_pyramid_pool.py:48,50 and espdnet_ue.py:110,301-302; align_corners == 0: the default rule the DeepLab-style
+ *     heads use (nn_layers/aspp.py:93, model/segmentation/deeplabv3.py:40).
  */
 int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
-                      int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream);
+                      int32_t Wo, int32_t align_corners, const mspl_epilogue_t* ep, float* out, void* stream);
 
 /* adaptive_avg_pool2d (window [floor(i*I/O), ceil((i+1)*I/O)) ) + epilogue.
  *     Replaces efficient_pyramid_pool.py:46,52.

@@ -73,6 +73,12 @@ class _ASPPBase(nn.Module):
         return ops.conv1x1(out, c4.weight, 1, Epi(shift=c4.bias))
 
 
+def upsample_logits(logits, size):
+    """The head's caller: F.upsample(output, size=(h, w), mode='bilinear') with the default align_corners=False
+    (model/segmentation/deeplabv3.py:40)."""
+    return ops.bilinear(logits, size, align_corners=False)
+
+
 class ASPP(_ASPPBase):
     def __init__(self, num_classes):
         super().__init__(512, num_classes)

@@ -169,6 +169,21 @@ __device__ __forceinline__ void bilinear_src(float scale, int dst, int in_size, 
     w0 = 1.0f - lam;
 }
 
+// ATen's align_corners=False source rule (area_pixel_compute_source_index, not cubic): src = scale*(dst+0.5)-0.5, clamped at 0;
+// scale = in/out.  Used by the DeepLab-style heads (nn_layers/aspp.py:93, model/segmentation/deeplabv3.py:40).
+__device__ __forceinline__ void bilinear_src_hp(float scale, int dst, int in_size, int& i0, int& i1, float& w0, float& w1) {
+    float real = scale * ((float)dst + 0.5f) - 0.5f;
+    real = real < 0.f ? 0.f : real;
+    int idx = (int)floorf(real);
+    if (idx > in_size - 1) idx = in_size - 1;
+    float lam = real - (float)idx;
+    lam = fminf(fmaxf(lam, 0.0f), 1.0f);
+    i0 = idx;
+    i1 = idx + ((idx < in_size - 1) ? 1 : 0);
+    w1 = lam;
+    w0 = 1.0f - lam;
+}
+
 static inline float bilinear_scale(int in_size, int out_size) {
     return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
 }

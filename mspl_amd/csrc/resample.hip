@@ -16,6 +16,7 @@ struct RsGeom {
     int XS;           // ceil(Wo / 4)
     unsigned mag_xs;  // ceil(2^32 / XS): s / XS == __umulhi(s, mag_xs) for s * XS < 2^32
     float sh, sw;     // bilinear scales
+    int half_pixel;   // bilinear: 0 = align_corners=True, 1 = ATen's align_corners=False rule (src = scale*(dst+0.5)-0.5, >= 0)
 };
 
 // Grid layout of the strip kernels: blockIdx.x walks the Ho x XS strips of one plane, (blockIdx.y, blockIdx.z) the
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     const int ncol = 4 * g.XS;
     for (int c = threadIdx.x; c < ncol; c += 256) {
         int xa, xb;  float wx0, wx1;
-        bilinear_src(g.sw, min(c, g.Wo - 1), g.Wi, xa, xb, wx0, wx1);
+        if (g.half_pixel) bilinear_src_hp(g.sw, min(c, g.Wo - 1), g.Wi, xa, xb, wx0, wx1);
+        else bilinear_src(g.sw, min(c, g.Wo - 1), g.Wi, xa, xb, wx0, wx1);
         xtab[4 * c] = __int_as_float(xa); xtab[4 * c + 1] = __int_as_float(xb); xtab[4 * c + 2] = wx0; xtab[4 * c + 3] = wx1;
     }
     __syncthreads();
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
     if (!strip_decode(g, n, c, y, x0)) return;
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     int y0i, y1i;  float wy0, wy1;
-    bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
+    if (g.half_pixel) bilinear_src_hp(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
+    else bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
     const int r0 = y0i * g.Wi, r1 = y1i * g.Wi;
     float acc[4];
 #pragma unroll
@@ -256,6 +259,7 @@ static int resample_common(const char* who, const float* x, float* out, int N, i
     MSPL_REQUIRE((int64_t)Ho * g.XS * g.XS < (1ll << 32), MSPL_ERR_BAD_SHAPE, "%s: plane too large", who);
     g.sh = bilinear_scale(Hi, Ho);
     g.sw = bilinear_scale(Wi, Wo);
+    g.half_pixel = 0;
     e = make_epi(ep, C, Ho * Wo);
     total = (int64_t)N * C * Ho * g.XS;
     MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "%s: grid too large", who);
@@ -277,9 +281,14 @@ extern "C" int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32
 }
 
 extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho,
-                                 int32_t Wo, const mspl_epilogue_t* ep, float* out, void* stream) {
+                                 int32_t Wo, int32_t align_corners, const mspl_epilogue_t* ep, float* out, void* stream) {
     RsGeom g; Epi e; int64_t total;
     if (int rc = resample_common("bilinear", x, out, N, C, Hi, Wi, Ho, Wo, ep, g, e, total)) return rc;
+    g.half_pixel = align_corners ? 0 : 1;
+    if (g.half_pixel) {        // ATen area_pixel_compute_scale(align_corners=False, no scale factor): in / out
+        g.sh = (float)Hi / (float)Ho;
+        g.sw = (float)Wi / (float)Wo;
+    }
     const size_t lds = (size_t)16 * g.XS * sizeof(float);
     MSPL_REQUIRE(lds <= 64 * 1024 && (int64_t)Hi * Wi < (1ll << 31), MSPL_ERR_UNSUPPORTED, "bilinear: output rows of %d pixels do not fit the column table", Wo);
     hipLaunchKernelGGL(bilinear_kernel, strip_grid(g), dim3(256), lds, (hipStream_t)stream, x, g, e, out);

@@ -166,14 +166,14 @@ def avgpool3x3s2(x, ep=None, out=None):
     return dst
 
 
-def bilinear(x, size, ep=None, out=None):
-    """align_corners=True bilinear resize to size=(Ho,Wo)."""
+def bilinear(x, size, ep=None, out=None, align_corners=True):
+    """Bilinear resize to size=(Ho,Wo); align_corners=True is the ESPNet decoders' rule, False F.interpolate's default."""
     x = _f32(x, 'x')
     N, C, H, W = x.shape
     Ho, Wo = int(size[0]), int(size[1])
     dst, coff = _dest(out, (N, C, Ho, Wo), x)
     s, keep = _build(ep, dst, coff, N, C, Ho * Wo)
-    check(lib.mspl_bilinear_fwd(_p(x), N, C, H, W, Ho, Wo, ctypes.byref(s), _p(dst), _stream()))
+    check(lib.mspl_bilinear_fwd(_p(x), N, C, H, W, Ho, Wo, 1 if align_corners else 0, ctypes.byref(s), _p(dst), _stream()))
     return dst
 
 

@@ -246,3 +246,13 @@ def test_miou_areas(K, C):
     assert np.array_equal(gi2, ri) and np.allclose(gu2, ru, rtol=0, atol=1e-3)
     gi3, _ = m.get_iou((logits.to(DEV), logits.to(DEV)), tgt.to(DEV))       # (main, aux) tuple: first element
     assert np.array_equal(gi3, ri)
+
+
+@pytest.mark.parametrize('cfg', [(2, 3, 8, 16, 128, 256), (1, 5, 7, 9, 20, 31), (1, 2, 12, 10, 5, 4), (1, 1, 1, 1, 6, 3)])
+def test_bilinear_align_corners_false(cfg):
+    """The default F.interpolate rule (half-pixel centres) of the DeepLab heads, incl. down-scaling and a 1x1 source."""
+    from mspl_amd import ops
+    N, C, Hi, Wi, Ho, Wo = cfg
+    x = rnd(N, C, Hi, Wi, seed=8)
+    close(ops.bilinear(x.to(DEV), (Ho, Wo), align_corners=False), F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False),
+          atol=1e-5)
