@@ -529,7 +529,7 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
         return MSPL_OK;
     }
-    if (K == 3 && g.cin_g <= 5) {
+    if (K == 3 && (g.cin_g <= 5 || g.cin_g == 8)) {
         int chunks = 1;
         while ((int64_t)Cout * chunks < 4096 && total / (chunks * 2) >= 2048) chunks *= 2;
         const dim3 grid((unsigned)(Cout * chunks)), blk(256);
@@ -538,7 +538,8 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
             case 2: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<2>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
             case 3: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<3>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
             case 4: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<4>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
-            default: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<5>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 5: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<5>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            default: hipLaunchKernelGGL(g3x3_bwd_weight_kernel<8>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
         }
         MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3, few input channels)");
         return MSPL_OK;
