@@ -261,7 +261,8 @@ def test_dense_conv_shapes():
     from mspl_amd import ops
     from mspl_amd.ops import Epi
     g = torch.Generator().manual_seed(3)
-    for (N, Cin, Cout, H, W, k, d) in [(1, 64, 40, 7, 9, 3, 2), (2, 96, 130, 5, 13, 1, 1), (1, 32, 256, 11, 6, 3, 12), (3, 128, 16, 9, 9, 3, 3)]:
+    for (N, Cin, Cout, H, W, k, d) in [(1, 64, 40, 7, 9, 3, 2), (2, 96, 130, 5, 13, 1, 1), (1, 32, 256, 11, 6, 3, 12), (3, 128, 16, 9, 9, 3, 3),
+                                       (1, 64, 130, 250, 263, 3, 2)]:          # >= 512 tiles of 128 pixels: the wide-tile form
         x = torch.randn(N, Cin, H, W, generator=g)
         w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
         sc, sh = torch.rand(Cout + 7, generator=g) + 0.5, torch.randn(Cout + 7, generator=g) * 0.1
