@@ -126,6 +126,17 @@ int mspl_pointwise_fwd(const float* x, int32_t N, int32_t C, int32_t HW, const m
 int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int32_t Cout,
                       int32_t HW, float* mean_ws, float* gate, void* stream);
 
+/* RGB-D fusion gate blend.  Replaces nn_layers/fusion_gate.py:26-47 after its 1x1 convolution (which runs through
+ * mspl_conv1x1_fwd on the two halves of the weight, no concatenated copy):
+ *     z != NULL:  w = sigmoid(z); out = rgb*w + depth*(1-w)          (is_trainable=True,  :27-41)
+ *     z == NULL:  out = rgb + depth                                  (is_trainable=False, :43-44)
+ * All operands `count` fp32 elements, 16-byte aligned.  The reference's `torch.ones(size).to('cuda')` temporary
+ * (:38) is not materialised. */
+int mspl_fusion_gate_fwd(const float* z, const float* rgb, const float* depth, int64_t count, float* out, void* stream);
+/* Its backward: grgb = gy*w, gdepth = gy*(1-w), gz = gy*(rgb-depth)*w*(1-w)   (z == NULL: grgb = gdepth = gy). */
+int mspl_fusion_gate_bwd(const float* z, const float* rgb, const float* depth, const float* gy, int64_t count,
+                         float* gz, float* grgb, float* gdepth, void* stream);
+
 /* K6 prologue: the low-resolution branches' maps for mspl_pyrpool_fused_fwd in ONE launch (one workgroup per (image,
  *     channel) plane): out[i] (N,P,hs[i],ws[i]) = dw3x3(adaptive_avg_pool2d(x, (hs[i],ws[i]))) with stage_w[i] (P,1,3,3);
  *     nn_layers/efficient_pyramid_pool.py:44-50 for the scales < 1.  A workgroup stages a band of input rows and the

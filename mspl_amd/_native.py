@@ -37,6 +37,8 @@ SIGNATURES = {
     'mspl_adaptive_avgpool_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_pointwise_fwd': [c_f32p, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_gap_gate_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_fusion_gate_fwd': [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p],
+    'mspl_fusion_gate_bwd': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_pyrpool_fused_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f32p, c_f32p, c_f32p,
                                c_f32p, _EP, c_f32p, ctypes.c_void_p],

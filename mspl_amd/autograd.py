@@ -193,6 +193,33 @@ class GapGateFn(torch.autograd.Function):
         return gx, gw
 
 
+class FusionGateFn(torch.autograd.Function):
+    """FusionGate blend (nn_layers/fusion_gate.py:36-44); z is None for the non-trainable gate (rgb + depth)."""
+
+    @staticmethod
+    def forward(ctx, z, rgb, depth):
+        rgb, depth = _c(rgb), _c(depth)
+        z = None if z is None else _c(z)
+        out = torch.empty_like(rgb)
+        check(lib.mspl_fusion_gate_fwd(None if z is None else _p(z), _p(rgb), _p(depth), rgb.numel(), _p(out), _stream()))
+        ctx.gated = z is not None
+        ctx.save_for_backward(*((z, rgb, depth) if ctx.gated else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _c(gy)
+        grgb, gdepth = torch.empty_like(gy), torch.empty_like(gy)
+        if ctx.gated:
+            z, rgb, depth = ctx.saved_tensors
+            gz = torch.empty_like(gy)
+            check(lib.mspl_fusion_gate_bwd(_p(z), _p(rgb), _p(depth), _p(gy), gy.numel(), _p(gz), _p(grgb), _p(gdepth),
+                                           _stream()))
+            return gz, grgb, gdepth
+        check(lib.mspl_fusion_gate_bwd(None, None, None, _p(gy), gy.numel(), None, _p(grgb), _p(gdepth), _stream()))
+        return None, grgb, gdepth
+
+
 class ChannelScaleFn(torch.autograd.Function):
     """y[n,c,:,:] * gate[n,c]."""
 

@@ -50,6 +50,8 @@ def install_dropin(force=False):
            input_reinforcement=M.input_reinforcement)
     _alias('model.segmentation.espdnet_ue', ESPDNetwithUncertaintyEstimation=M.ESPDNetwithUncertaintyEstimation,
            espdnetue_seg2=M.espdnetue_seg2)
+    _alias('model.segmentation.espdnet', ESPDNetSegmentation=M.ESPDNetSegmentation, espdnet_seg=M.espdnet_seg,
+           espdnet_seg_with_pre_rgbd=M.espdnet_seg_with_pre_rgbd)
     _alias('model.segmentation.espnetv2', ESPNetv2Segmentation=M.ESPNetv2Segmentation, espnetv2_seg=M.espnetv2_seg)
     _alias('data_loader.segmentation.greenhouse', id_camvid_to_greenhouse=U.id_camvid_to_greenhouse,
            id_cityscapes_to_greenhouse=U.id_cityscapes_to_greenhouse, id_forest_to_greenhouse=U.id_forest_to_greenhouse)

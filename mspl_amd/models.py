@@ -5,7 +5,8 @@ Reference surface mirrored (paths relative to the reference root):
   model/classification/espnetv2_config.py:6-23    channel tables, repetition counts, receptive-field limits
   model/segmentation/espdnet_ue.py:18-302         ESPDNetwithUncertaintyEstimation, :304-382 espdnetue_seg2
   model/segmentation/espnetv2.py:16-198           ESPNetv2Segmentation, espnetv2_seg
-  nn_layers/fusion_gate.py:11-47                  FusionGate (parameters only: RGB-D fusion is out of scope)
+  model/segmentation/espdnet.py:18-417            ESPDNetSegmentation, espdnet_seg, espdnet_seg_with_pre_rgbd
+  nn_layers/fusion_gate.py:11-47                  FusionGate (RGB-D fusion, x_d path of espdnet_ue.py:186-270)
 
 Beyond the reference API each network offers `forward_lowres(x)` -- the decoder outputs before the final
 bilinear upsample -- which the pseudo-label pass feeds to the fused label epilogue so that full-resolution
@@ -20,7 +21,7 @@ from torch.nn import init
 
 from . import ops
 from . import autograd as ag
-from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path,
+from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path, cached,
                      decoder_merge, fork, join, wait_mark)
 
 sc_ch_dict = {
@@ -90,8 +91,10 @@ class EESPNet(nn.Module):
 
 
 class FusionGate(nn.Module):
-    """RGB-D fusion gate parameters (nn_layers/fusion_gate.py:11-47).  Present in every checkpoint, unused
-    when x_d is None (all multi-source scripts)."""
+    """RGB-D fusion gate (nn_layers/fusion_gate.py:11-47): out = rgb*w + depth*(1-w), w = sigmoid(conv_1x1(cat(rgb, depth))),
+    or rgb + depth when not trainable.  The concatenation is never materialised on the inference path: the 1x1 runs as two
+    matrix-core launches over the two halves of the weight (the second accumulates onto the first), then one blend kernel.
+    The reference's hard-coded `.to('cuda')` (:38) has no counterpart: everything stays on the inputs' device."""
 
     def __init__(self, nchannel, is_trainable=True):
         super().__init__()
@@ -101,7 +104,20 @@ class FusionGate(nn.Module):
         self.is_trainable = is_trainable
 
     def forward(self, rgb, depth):
-        raise NotImplementedError('mspl_amd: RGB-D fusion (x_d) is outside the hot path (SURVEY.md section 8f rank 3)')
+        if rgb.shape != depth.shape or rgb.shape[1] != self.nchannel:
+            raise RuntimeError('mspl_amd: FusionGate(%d) got rgb %s and depth %s'
+                               % (self.nchannel, tuple(rgb.shape), tuple(depth.shape)))
+        w = self.conv_1x1.conv.weight
+        if _training_path():
+            z = ag.conv(torch.cat((rgb, depth), 1), w) if self.is_trainable else None
+            return ag.FusionGateFn.apply(z, rgb, depth)
+        if not self.is_trainable:
+            return ops.fusion_gate(None, rgb, depth)
+        c = self.nchannel
+        w_rgb, w_d = cached(self, 'halves', [w], lambda: (w[:, :c].contiguous(), w[:, c:].contiguous()))
+        z = ops.conv1x1(rgb, w_rgb)
+        z = ops.conv1x1(depth, w_d, ep=ops.Epi(pre_add=z))
+        return ops.fusion_gate(z, rgb, depth)
 
 
 class _SegBase(nn.Module):
@@ -136,6 +152,39 @@ class _SegBase(nn.Module):
         l4 = b.level4_0(l3, pyr)
         for layer in b.level4:
             l4 = layer(l4)
+        return l1, l2, l3, l4
+
+    def _encode_rgbd(self, x, x_d):
+        """Encoder with the depth branch (espdnet_ue.py:186-270 == espdnet.py:200-284): depth features from depth_base_net
+        (DownSamplers without image reinforcement), a FusionGate after level1, level2 and after the level3 / level4
+        stacks (after every block with dense_fuse); the RGB branch's level3[1:] run through depth_base_net's blocks."""
+        if x_d.dim() != 4 or x_d.shape[0] != x.shape[0] or x_d.shape[1] != 1 or x_d.shape[2:] != x.shape[2:]:
+            raise RuntimeError('mspl_amd: depth input %s does not match image %s (expected (N,1,H,W))'
+                               % (tuple(x_d.shape), tuple(x.shape)))
+        b, d = self.base_net, self.depth_base_net
+        pyr = ImagePyramid(x.detach()) if b.input_reinforcement else None
+        dl1 = d.level1(x_d)                                                     # :187
+        l1 = self.fusion_gate_level1(b.level1(x), dl1)                          # :191
+        dl2 = d.level2_0(dl1)                                                   # :198 (no image reinforcement)
+        l2 = self.fusion_gate_level2(b.level2_0(l1, pyr), dl2)                  # :196,:202
+        l3 = b.level3_0(l2, pyr)                                                # :207
+        dl3 = d.level3_0(dl2)                                                   # :209
+        for i, (layer, dlayer) in enumerate(zip(b.level3, d.level3)):           # :213-228
+            l3 = (layer if i == 0 else dlayer)(l3)
+            dl3 = dlayer(dl3)
+            if self.dense_fuse:
+                l3 = self.fusion_gate_level3(l3, dl3)
+        if not self.dense_fuse:
+            l3 = self.fusion_gate_level3(l3, dl3)                               # :230-233
+        l4 = b.level4_0(l3, pyr)                                                # :238
+        dl4 = d.level4_0(dl3)                                                   # :240
+        for layer, dlayer in zip(b.level4, d.level4):                           # :244-259
+            l4 = layer(l4)
+            dl4 = dlayer(dl4)
+            if self.dense_fuse:
+                l4 = self.fusion_gate_level4(l4, dl4)
+        if not self.dense_fuse:
+            l4 = self.fusion_gate_level4(l4, dl4)                               # :261-264
         return l1, l2, l3, l4
 
     def _decode(self, l1, l2, l3, l4, aux_layer):
@@ -215,13 +264,16 @@ class ESPDNetwithUncertaintyEstimation(_SegBase):
         return self.get_segment_params()
 
     def forward_lowres(self, x, x_d=None):
-        """(main at H/2 x W/2, aux at H/4 x W/4 for aux_layer=2): decoder outputs before espdnet_ue.py:301-302."""
-        if x_d is not None:
-            raise NotImplementedError('mspl_amd: the depth branch (x_d) is outside the hot path (use_depth=False in every '
-                                      'multi-source script)')
+        """(main at H/2 x W/2, aux at H/4 x W/4 for aux_layer=2): decoder outputs before espdnet_ue.py:301-302.
+        With x_d the encoder follows espdnet_ue.py:186-270 line by line: depth features come from depth_base_net (its
+        DownSamplers get NO image reinforcement, :198,:209,:240), fusion after level1, level2 and after the level3 /
+        level4 stacks (after every block with dense_fuse)."""
         _check_input(x)
-        # level3[1:] run through depth_base_net's layers (espdnet_ue.py:226) -- reproduced on purpose
-        l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3)
+        if x_d is None:
+            # level3[1:] run through depth_base_net's layers (espdnet_ue.py:226) -- reproduced on purpose
+            l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3)
+            return self._decode(l1, l2, l3, l4, self.aux_layer)
+        l1, l2, l3, l4 = self._encode_rgbd(x, x_d)
         return self._decode(l1, l2, l3, l4, self.aux_layer)
 
     def forward(self, x, x_d=None):
@@ -230,6 +282,46 @@ class ESPDNetwithUncertaintyEstimation(_SegBase):
             return ag.bilinear(main, tuple(x.shape[2:])), ag.bilinear(aux, tuple(x.shape[2:]))
         r = ops.label_epilogue(main, aux, x.shape[2:], want_labels=False, want_logits=True)
         return r['main_up'], r['aux_up']
+
+
+class ESPDNetSegmentation(_SegBase):
+    """Single-head RGB(-D) network (model/segmentation/espdnet.py:18-309, `--os-model espdnet`): the ESPDNet-UE topology
+    without the auxiliary decoder; pyr_plane_proj = min(classes//2, 16|32) (:101); forward returns one logits tensor."""
+
+    def __init__(self, args, classes=21, dataset='pascal', dense_fuse=False, trainable_fusion=True):
+        super().__init__()
+        if dataset == 'forest':
+            raise KeyError('forest')                      # espdnet.py:91-99: the table has no 'forest' entry
+        self.base_net = EESPNet(args)
+        config = self.base_net.config
+        tmp_args = copy.deepcopy(args)
+        tmp_args.channels = 1
+        self.depth_base_net = EESPNet(tmp_args)
+        self.fusion_gate_level1 = FusionGate(nchannel=32, is_trainable=trainable_fusion)
+        self.fusion_gate_level2 = FusionGate(nchannel=128, is_trainable=trainable_fusion)
+        self.fusion_gate_level3 = FusionGate(nchannel=256, is_trainable=trainable_fusion)
+        self.fusion_gate_level4 = FusionGate(nchannel=512, is_trainable=trainable_fusion)
+        self._build_decoder(config, classes, dataset, min(classes // 2, DEC_FEAT[dataset]), False)
+        _init_params(self)
+        self.dense_fuse = dense_fuse
+        self.classes = classes
+
+    def get_depth_encoder_params(self):
+        return _param_gen([self.depth_base_net])
+
+    def forward_lowres(self, x, x_d=None):
+        _check_input(x)
+        if x_d is None:
+            l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3)      # espdnet.py:240: dlayer for i > 0
+        else:
+            l1, l2, l3, l4 = self._encode_rgbd(x, x_d)
+        return self._decode(l1, l2, l3, l4, -1)[0], None
+
+    def forward(self, x, x_d=None):
+        main, _ = self.forward_lowres(x, x_d)
+        if _training_path():
+            return ag.bilinear(main, tuple(x.shape[2:]))
+        return ops.bilinear(main, x.shape[2:])
 
 
 class ESPNetv2Segmentation(_SegBase):
@@ -308,4 +400,43 @@ def espnetv2_seg(args):
             raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
         base_dict.update(overlap)
         model.base_net.load_state_dict(base_dict)
+    return model
+
+
+def espdnet_seg(args):
+    """model/segmentation/espdnet.py:312-380: base_net takes the file's keys that match its own names; depth_base_net
+    takes the same file's matching keys with level1.conv.weight averaged over RGB (KeyError, like the reference, when the
+    file has no such key)."""
+    model = ESPDNetSegmentation(args, classes=args.classes, dataset=args.dataset, dense_fuse=args.dense_fuse,
+                                trainable_fusion=args.trainable_fusion)
+    if args.weights:
+        pretrained = _load_file(args.weights)
+        base_dict = model.base_net.state_dict()
+        overlap = {k: v for k, v in pretrained.items() if k in base_dict}
+        if len(overlap) == 0:
+            raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+        base_dict.update(overlap)
+        model.base_net.load_state_dict(base_dict)
+        d_dict = model.depth_base_net.state_dict()
+        overlap = {k: v for k, v in pretrained.items() if k in d_dict}
+        overlap['level1.conv.weight'] = torch.mean(overlap['level1.conv.weight'], dim=1, keepdim=True)
+        d_dict.update(overlap)
+        model.depth_base_net.load_state_dict(d_dict)
+    return model
+
+
+def espdnet_seg_with_pre_rgbd(args, ignore_layers=[], load_entire_weights=False):
+    """model/segmentation/espdnet.py:382-417: keys present in the model, not ignored, and ('base_net' in the key or
+    load_entire_weights)."""
+    model = ESPDNetSegmentation(args, classes=args.classes, dataset=args.dataset, dense_fuse=args.dense_fuse,
+                                trainable_fusion=args.trainable_fusion)
+    if args.weights:
+        pretrained = _load_file(args.weights)
+        model_dict = model.state_dict()
+        overlap = {k: v for k, v in pretrained.items()
+                   if (k in model_dict) and k not in ignore_layers and ('base_net' in k or load_entire_weights)}
+        if len(overlap) == 0:
+            raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+        model_dict.update(overlap)
+        model.load_state_dict(model_dict)
     return model

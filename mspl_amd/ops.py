@@ -211,6 +211,18 @@ def gap_gate(x, w):
     return gate
 
 
+def fusion_gate(z, rgb, depth):
+    """FusionGate blend (nn_layers/fusion_gate.py:36-44): sigmoid(z)-weighted mix, or rgb + depth when z is None."""
+    rgb, depth = _f32(rgb, 'rgb'), _f32(depth, 'depth')
+    if rgb.shape != depth.shape or (z is not None and z.shape != rgb.shape):
+        raise RuntimeError('mspl_amd: fusion_gate operands differ in shape: %s %s %s'
+                           % (tuple(rgb.shape), tuple(depth.shape), None if z is None else tuple(z.shape)))
+    out = torch.empty_like(rgb)
+    check(lib.mspl_fusion_gate_fwd(None if z is None else _p(_f32(z, 'z')), _p(rgb), _p(depth), rgb.numel(), _p(out),
+                                   _stream()))
+    return out
+
+
 def pyr_down_prep_fits(shape, sizes):
     """True when pyr_down_prep can stage a row band of an (N,P,h,w) map with these branch sizes in LDS
     (else: adaptive_avgpool + conv3x3 per branch)."""

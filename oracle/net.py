@@ -194,6 +194,44 @@ def _encoder(x, sd, image_for_l2, l3_tail_prefix):
     return l1, l2, l3, l4
 
 
+def fusion_gate(rgb, depth, sd, p, trainable=True):
+    """nn_layers/fusion_gate.py:26-47 (the `.to('cuda')` of :38 dropped: everything stays on the inputs' device)."""
+    if not trainable:
+        return rgb + depth
+    w = torch.sigmoid(F.conv2d(torch.cat((rgb, depth), 1), sd[p + '.conv_1x1.conv.weight']))
+    return rgb * w + depth * (torch.ones_like(w) - w)
+
+
+def _encoder_rgbd(x, x_d, sd, dense_fuse, trainable_fusion):
+    """espdnet_ue.py:186-270 with x_d given: the depth branch's DownSamplers get no image reinforcement
+    (:198,:209,:240); the RGB branch's level3[1:] still run through depth_base_net's blocks (:226)."""
+    b, d = 'base_net', 'depth_base_net'
+    gate = lambda r, dd, lvl: fusion_gate(r, dd, sd, 'fusion_gate_level%d' % lvl, trainable_fusion)
+    dl1 = enc_cbr(x_d, sd, d + '.level1', stride=2)
+    l1 = gate(enc_cbr(x, sd, b + '.level1', stride=2), dl1, 1)
+    dl2 = downsampler(dl1, sd, d + '.level2_0', RECEPT_LIMIT[0], None)
+    l2 = gate(downsampler(l1, sd, b + '.level2_0', RECEPT_LIMIT[0], x), dl2, 2)
+    l3 = downsampler(l2, sd, b + '.level3_0', RECEPT_LIMIT[1], x)
+    dl3 = downsampler(dl2, sd, d + '.level3_0', RECEPT_LIMIT[1], None)
+    for i in range(REP_LAYERS[1]):
+        l3 = eesp(l3, sd, '%s.level3.%d' % (b if i == 0 else d, i), 1, RECEPT_LIMIT[2])
+        dl3 = eesp(dl3, sd, '%s.level3.%d' % (d, i), 1, RECEPT_LIMIT[2])
+        if dense_fuse:
+            l3 = gate(l3, dl3, 3)
+    if not dense_fuse:
+        l3 = gate(l3, dl3, 3)
+    l4 = downsampler(l3, sd, b + '.level4_0', RECEPT_LIMIT[2], x)
+    dl4 = downsampler(dl3, sd, d + '.level4_0', RECEPT_LIMIT[2], None)
+    for i in range(REP_LAYERS[2]):
+        l4 = eesp(l4, sd, '%s.level4.%d' % (b, i), 1, RECEPT_LIMIT[3])
+        dl4 = eesp(dl4, sd, '%s.level4.%d' % (d, i), 1, RECEPT_LIMIT[3])
+        if dense_fuse:
+            l4 = gate(l4, dl4, 4)
+    if not dense_fuse:
+        l4 = gate(l4, dl4, 4)
+    return l1, l2, l3, l4
+
+
 def _decoder(sd, l1, l2, l3, l4, with_aux):
     """model/segmentation/espdnet_ue.py:272-299 / espnetv2.py:144-165."""
     bu = pyr_pool(l4, sd, 'bu_dec_l1')
@@ -207,17 +245,31 @@ def _decoder(sd, l1, l2, l3, l4, with_aux):
     return bu, aux
 
 
-def espdnet_ue_forward(sd, x):
-    """ESPDNetwithUncertaintyEstimation.forward with x_d=None, model/segmentation/espdnet_ue.py:169-302.
+def espdnet_ue_forward(sd, x, x_d=None, dense_fuse=False, trainable_fusion=True):
+    """ESPDNetwithUncertaintyEstimation.forward, model/segmentation/espdnet_ue.py:169-302 (x_d: the RGB-D path).
 
     Returns (main, aux) logits at input resolution.  Raises RuntimeError (from the tensor add) when
     H or W is not a multiple of 16, exactly like the reference.
     """
     size = x.shape[2:]
-    l1, l2, l3, l4 = _encoder(x, sd, x, 'depth_base_net')
+    if x_d is None:
+        l1, l2, l3, l4 = _encoder(x, sd, x, 'depth_base_net')
+    else:
+        l1, l2, l3, l4 = _encoder_rgbd(x, x_d, sd, dense_fuse, trainable_fusion)
     bu, aux = _decoder(sd, l1, l2, l3, l4, True)
     return (F.interpolate(bu, size=size, mode='bilinear', align_corners=True),
             F.interpolate(aux, size=size, mode='bilinear', align_corners=True))
+
+
+def espdnet_forward(sd, x, x_d=None, dense_fuse=False, trainable_fusion=True):
+    """ESPDNetSegmentation.forward, model/segmentation/espdnet.py:183-309: ESPDNet-UE without the auxiliary head."""
+    size = x.shape[2:]
+    if x_d is None:
+        l1, l2, l3, l4 = _encoder(x, sd, x, 'depth_base_net')
+    else:
+        l1, l2, l3, l4 = _encoder_rgbd(x, x_d, sd, dense_fuse, trainable_fusion)
+    bu, _ = _decoder(sd, l1, l2, l3, l4, False)
+    return F.interpolate(bu, size=size, mode='bilinear', align_corners=True)
 
 
 def espnetv2_forward(sd, x):

@@ -32,6 +32,21 @@ MODEL_CASES = {
     'ue_c13_256x480': ('espdnetue', 2.0, 13, 'camvid', (1, 3, 256, 480), 11, 4),
 }
 
+# RGB-D cases (x_d given, espdnet_ue.py:186-270): name -> (classes, dataset, input shape, sd seed, input seed, depth seed,
+# dense_fuse, trainable_fusion)
+RGBD_CASES = {
+    'ue_rgbd_gate': (5, 'greenhouse', (2, 3, 32, 48), 31, 6, 7, False, True),
+    'ue_rgbd_dense': (13, 'camvid', (1, 3, 48, 64), 32, 8, 9, True, True),
+    'ue_rgbd_add': (5, 'greenhouse', (1, 3, 32, 32), 33, 10, 11, False, False),
+}
+
+# single-head ESPDNetSegmentation (model/segmentation/espdnet.py): name -> (classes, dataset, input shape, sd seed, input seed,
+# depth seed or None, dense_fuse, trainable_fusion)
+ESPDNET_CASES = {
+    'espdnet_c5_rgb': (5, 'greenhouse', (2, 3, 32, 48), 41, 12, None, False, True),
+    'espdnet_c13_rgbd': (13, 'camvid', (1, 3, 48, 64), 42, 13, 14, False, True),
+}
+
 TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), sd_seed=21, in_seed=5,
                   lr=5e-4, weight_decay=5e-4, ignore_idx=4)
 

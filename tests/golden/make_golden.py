@@ -24,7 +24,7 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES, TRAIN_CASE  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
 from tests.synth import synth_input, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
@@ -34,6 +34,7 @@ from nn_layers.efficient_pt import EfficientPWConv  # noqa: E402
 from nn_layers import aspp as ref_aspp  # noqa: E402
 from model.segmentation.espdnet_ue import ESPDNetwithUncertaintyEstimation  # noqa: E402
 from model.segmentation.espnetv2 import ESPNetv2Segmentation  # noqa: E402
+from model.segmentation.espdnet import ESPDNetSegmentation  # noqa: E402
 from loss_fns.segmentation_loss import PixelwiseKLD, UncertaintyWeightedSegmentationLoss  # noqa: E402
 
 torch.set_num_threads(8)
@@ -111,6 +112,52 @@ def gen_models():
     print('param counts:', {k: sum(int(np.prod(s)) for kk, s in v.items()
                                    if not kk.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
                             for k, v in keysets.items()})
+
+
+class _cuda_means_here(object):
+    """nn_layers/fusion_gate.py:38 builds its ones tensor with a hard-coded `.to('cuda')`, which cannot run in this
+    GPU-less container: inside this context Tensor.to treats a 'cuda' target as "stay where you are" -- the reference's
+    arithmetic is untouched."""
+
+    def __enter__(self):
+        real_to = self.real_to = torch.Tensor.to
+
+        def cpu_to(t, *a, **k):
+            if a and isinstance(a[0], str) and a[0].startswith('cuda'):
+                return t
+            return real_to(t, *a, **k)
+        torch.Tensor.to = cpu_to
+
+    def __exit__(self, *exc):
+        torch.Tensor.to = self.real_to
+
+
+def gen_rgbd():
+    """ESPDNet-UE with a depth image (x_d), and the single-head ESPDNetSegmentation with and without one."""
+    out = {}
+    for name, (classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable) in sorted(RGBD_CASES.items()):
+        a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+        m = ESPDNetwithUncertaintyEstimation(a, classes=classes, dataset=dataset, dense_fuse=dense,
+                                             trainable_fusion=trainable, fix_pyr_plane_proj=True).eval()
+        m.load_state_dict(synth_state_dict(m.state_dict(), sd_seed))
+        x = synth_input(shp, in_seed)
+        x_d = synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+        with _cuda_means_here(), torch.no_grad():
+            main, aux = m(x, x_d)
+        out[name + '.main'], out[name + '.aux'] = main, aux
+    keys = {}
+    for name, (classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable) in sorted(ESPDNET_CASES.items()):
+        a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+        m = ESPDNetSegmentation(a, classes=classes, dataset=dataset, dense_fuse=dense, trainable_fusion=trainable).eval()
+        keys[name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(synth_state_dict(m.state_dict(), sd_seed))
+        x = synth_input(shp, in_seed)
+        x_d = None if d_seed is None else synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+        with _cuda_means_here(), torch.no_grad():
+            out[name] = m(x, x_d)
+    save('rgbd', **out)
+    with open(os.path.join(HERE, 'espdnet_keys.json'), 'w') as f:
+        json.dump(keys, f, sort_keys=True)
 
 
 def gen_zoo():
@@ -229,6 +276,6 @@ def gen_aspp():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd']
     for w in which:
         globals()['gen_' + w]()

@@ -15,7 +15,7 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES
+from tests.cases import ASPP_CASES, ESPDNET_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES
 from tests.conftest import GOLDEN
 from tests.synth import synth_input, synth_state_dict
 
@@ -274,3 +274,74 @@ def test_dense_conv_shapes():
         assert torch.all(dst[:, :3] == -3.0) and torch.all(dst[:, 3 + Cout:] == -3.0)
     with pytest.raises(RuntimeError, match='multiple of 32'):
         ops.dense_conv(torch.zeros(1, 24, 4, 4, device=DEV), torch.zeros(1, 8, 24, device=DEV), 1)
+
+
+@pytest.mark.parametrize('name', sorted(RGBD_CASES))
+def test_rgbd_forward_vs_reference_golden(name, golden):
+    """SURVEY 8f-3 / 8a-8 `model(x, x_d)`: depth encoder + fusion gates (matrix-core 1x1 over the two weight halves + blend
+    kernel) against the reference's own (main, aux) and the oracle."""
+    from mspl_amd import models
+    classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable = RGBD_CASES[name]
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=classes, dataset=dataset, dense_fuse=dense,
+                                                trainable_fusion=trainable, fix_pyr_plane_proj=True)
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % classes], sd_seed)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x, x_d = synth_input(shp, in_seed), synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+    with torch.no_grad():
+        main, aux = m(x.to(DEV), x_d.to(DEV))
+        o_main, o_aux = onet.espdnet_ue_forward(sd, x, x_d, dense_fuse=dense, trainable_fusion=trainable)
+    g = golden('rgbd')
+    for got, ref, ora in ((main, g[name + '.main'], o_main), (aux, g[name + '.aux'], o_aux)):
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(ref), rtol=1e-4, atol=1e-3)     # north_star: logits within 1e-3
+        torch.testing.assert_close(got.cpu(), ora, rtol=1e-4, atol=1e-3)
+    with torch.no_grad(), pytest.raises(RuntimeError, match='depth input'):
+        m(x.to(DEV), x_d[:, :, :16].to(DEV))
+
+
+@pytest.mark.parametrize('trainable', [True, False])
+def test_fusion_gate_gradients(trainable):
+    """FusionGate forward + backward kernels against torch autograd over the oracle's formula."""
+    from mspl_amd import models
+    g = torch.Generator().manual_seed(17)
+    C_, shp = 8, (2, 8, 5, 7)                                   # 280 elements per image: exercises the scalar tail too
+    gate = models.FusionGate(C_, is_trainable=trainable).to(DEV)
+    w = torch.randn(C_, 2 * C_, 1, 1, generator=g) * 0.3
+    gate.conv_1x1.conv.weight.data.copy_(w)
+    rgb, dep, gy = (torch.randn(shp, generator=g) for _ in range(3))
+    r1, d1 = rgb.to(DEV).requires_grad_(), dep.to(DEV).requires_grad_()
+    out = gate(r1, d1)
+    out.backward(gy.to(DEV))
+    r0, d0, w0 = rgb.clone().requires_grad_(), dep.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = onet.fusion_gate(r0, d0, {'g.conv_1x1.conv.weight': w0}, 'g', trainable)
+    ref.backward(gy)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r1.grad.cpu(), r0.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(d1.grad.cpu(), d0.grad, rtol=1e-4, atol=1e-5)
+    if trainable:
+        torch.testing.assert_close(gate.conv_1x1.conv.weight.grad.cpu(), w0.grad, rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        torch.testing.assert_close(gate(r1, d1).cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', sorted(ESPDNET_CASES))
+def test_espdnet_vs_reference_golden(name, golden):
+    """the single-head `espdnet` variant (model/segmentation/espdnet.py), same state_dict keys, with and
+    without a depth image, against the reference's own logits and the oracle."""
+    from mspl_amd import models
+    classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable = ESPDNET_CASES[name]
+    keys = json.load(open(os.path.join(GOLDEN, 'espdnet_keys.json')))[name]
+    m = models.ESPDNetSegmentation(argparse.Namespace(s=2.0, channels=3, num_classes=1000), classes=classes,
+                                   dataset=dataset, dense_fuse=dense, trainable_fusion=trainable)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == keys
+    sd = synth_state_dict(keys, sd_seed)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = synth_input(shp, in_seed)
+    x_d = None if d_seed is None else synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+    with torch.no_grad():
+        y = m(x.to(DEV), None if x_d is None else x_d.to(DEV)).cpu()
+        ora = onet.espdnet_forward(sd, x, x_d, dense_fuse=dense, trainable_fusion=trainable)
+    torch.testing.assert_close(y, torch.from_numpy(golden('rgbd')[name]), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(y, ora, rtol=1e-4, atol=1e-3)

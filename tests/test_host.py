@@ -14,6 +14,7 @@ import mspl_amd
 from mspl_amd import _native, layers, models, uest
 from tests.cases import LAYER_CASES
 from tests.conftest import GOLDEN, ROOT
+from tests.synth import synth_state_dict
 
 KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
 LAYER_KEYS = json.load(open(os.path.join(GOLDEN, 'layer_keys.json')))
@@ -136,6 +137,8 @@ def test_dropin_aliases():
                                             UncertaintyWeightedSegmentationLoss)
     from utilities.metrics.segmentation_miou import MIOU  # noqa: F401  (uest_seg_multi_os.py:33)
     from nn_layers.aspp import ASPP, ASPP_Bottleneck  # noqa: F401  (model/segmentation/deeplabv3.py)
+    from model.segmentation.espdnet import ESPDNetSegmentation, espdnet_seg, espdnet_seg_with_pre_rgbd  # noqa: F401
+    from nn_layers.fusion_gate import FusionGate  # noqa: F401
     from mspl_amd import losses
     assert EESP is layers.EESP and espdnetue_seg2 is models.espdnetue_seg2 and PixelwiseKLD is losses.PixelwiseKLD
     # the callers' keyword (uest_seg_multi_os.py:509) and the in-place zeroing of the ignore class (:152-153)
@@ -189,3 +192,38 @@ def test_lr_schedule_helpers():
     assert training.lr_poly(5e-4, 10, 100, 0.0) == 5e-4
     assert abs(training.lr_poly(1e-3, 25, 100, 0.9) - 1e-3 * 0.75 ** 0.9) < 1e-15
     assert training.adjust_learning_rate(o, 50, 100, 2e-3, 2.0) == o.param_groups[0]['lr'] == 2e-3 * 0.25
+
+
+def test_espdnet_state_dict_and_loaders(tmp_path):
+    """ESPDNetSegmentation: the reference's keys/shapes (table written by make_golden.py) and the two factory loaders'
+    key-selection rules (model/segmentation/espdnet.py:312-417)."""
+    from tests.cases import ESPDNET_CASES
+    tables = json.load(open(os.path.join(GOLDEN, 'espdnet_keys.json')))
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000, classes=5, dataset='greenhouse', dense_fuse=False,
+                           trainable_fusion=True, weights='')
+    for name, (classes, dataset, _, _, _, _, dense, trainable) in ESPDNET_CASES.items():
+        m = models.ESPDNetSegmentation(a, classes=classes, dataset=dataset, dense_fuse=dense, trainable_fusion=trainable)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == tables[name]
+    with pytest.raises(KeyError):
+        models.ESPDNetSegmentation(a, classes=5, dataset='forest')          # espdnet.py:91-99 has no 'forest' row
+    # espdnet_seg: a classification-style file (keys without the 'base_net.' prefix) fills base_net AND depth_base_net
+    src = models.EESPNet(a)
+    sd = synth_state_dict(src.state_dict(), 77)
+    f = tmp_path / 'cls.pth'
+    torch.save(sd, str(f))
+    a.weights = str(f)
+    m = models.espdnet_seg(a)
+    assert torch.equal(m.base_net.level3[1].proj_1x1.conv.weight, sd['level3.1.proj_1x1.conv.weight'])
+    assert torch.equal(m.depth_base_net.level1.conv.weight, sd['level1.conv.weight'].mean(1, keepdim=True))
+    assert torch.equal(m.depth_base_net.level4[6].conv_1x1_exp.conv.weight, sd['level4.6.conv_1x1_exp.conv.weight'])
+    # espdnet_seg_with_pre_rgbd: whole-model file; decoder keys only with load_entire_weights
+    full = synth_state_dict(m.state_dict(), 78)
+    g = tmp_path / 'full.pth'
+    torch.save(full, str(g))
+    a.weights = str(g)
+    m1 = models.espdnet_seg_with_pre_rgbd(a)
+    m2 = models.espdnet_seg_with_pre_rgbd(a, load_entire_weights=True, ignore_layers=['bu_br_l2.1.weight'])
+    k = 'bu_dec_l1.projection_layer.cbr.0.weight'
+    assert torch.equal(m1.state_dict()['depth_base_net.level1.conv.weight'], full['depth_base_net.level1.conv.weight'])
+    assert not torch.equal(m1.state_dict()[k], full[k]) and torch.equal(m2.state_dict()[k], full[k])
+    assert not torch.equal(m2.state_dict()['bu_br_l2.1.weight'], full['bu_br_l2.1.weight'])

@@ -12,7 +12,7 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import ASPP_CASES, LAYER_CASES, MODEL_CASES, TRAIN_CASE
+from tests.cases import ASPP_CASES, ESPDNET_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
 from tests.conftest import GOLDEN
 from tests.synth import synth_input, synth_labels, synth_state_dict
 
@@ -172,3 +172,29 @@ def test_aspp(name, golden):
     ref = torch.from_numpy(golden('aspp')[name])
     assert y.shape == ref.shape
     torch.testing.assert_close(y, ref, rtol=1e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize('name', sorted(RGBD_CASES))
+def test_rgbd_forward(name, golden):
+    """The x_d path (depth encoder + fusion gates, espdnet_ue.py:186-270) vs the reference's own (main, aux)."""
+    classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable = RGBD_CASES[name]
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % classes], sd_seed)
+    x, x_d = synth_input(shp, in_seed), synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+    with torch.no_grad():
+        main, aux = onet.espdnet_ue_forward(sd, x, x_d, dense_fuse=dense, trainable_fusion=trainable)
+    g = golden('rgbd')
+    torch.testing.assert_close(main, torch.from_numpy(g[name + '.main']), rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(aux, torch.from_numpy(g[name + '.aux']), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', sorted(ESPDNET_CASES))
+def test_espdnet_forward(name, golden):
+    """Single-head ESPDNetSegmentation (model/segmentation/espdnet.py), with and without a depth image."""
+    classes, dataset, shp, sd_seed, in_seed, d_seed, dense, trainable = ESPDNET_CASES[name]
+    keys = json.load(open(os.path.join(GOLDEN, 'espdnet_keys.json')))[name]
+    sd = synth_state_dict(keys, sd_seed)
+    x = synth_input(shp, in_seed)
+    x_d = None if d_seed is None else synth_input((shp[0], 1) + tuple(shp[2:]), d_seed)
+    with torch.no_grad():
+        y = onet.espdnet_forward(sd, x, x_d, dense_fuse=dense, trainable_fusion=trainable)
+    torch.testing.assert_close(y, torch.from_numpy(golden('rgbd')[name]), rtol=1e-5, atol=2e-5)
