@@ -115,6 +115,67 @@ def aspp_head_rate(dev, iters=10):
                          'unit': 'TFLOP/s', 'frac': round(tf / 157.3, 4)}}
 
 
+def loader_io_rate(dev, iters=20):
+    """SURVEY 8f-1, the steps on either side of the path: (1) Resize(480x256)+Normalize of a batch of 16 decoded 360x480 uint8
+    frames on the device (two launches, Pillow's fixed-point arithmetic, bit-exact) with Pillow + numpy on the host timed
+    beside it (the reference's own loader path, one image at a time); (2) the asynchronous PNG writer draining 16 label
+    maps (256x480 uint8).  Extra field."""
+    import tempfile
+    import numpy as np
+    import torch
+    from mspl_amd.io import LabelWriter, Preprocessor
+    from tests.synth import synth_image_u8
+    frames = np.stack([synth_image_u8(360, 480, 900 + i)[0] for i in range(BATCH)])
+    src = torch.from_numpy(frames).to(dev)
+    pre = Preprocessor(size=(480, 256))
+    for _ in range(3):
+        pre(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        pre(src)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) / 1e3 / iters
+    alg = BATCH * (360 * 480 * 3 + 3 * 256 * 480 * 4)               # uint8 frame in, fp32 NCHW out
+    out = {'device_transform': {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'us_per_batch': round(dt * 1e6, 1),
+                                'workload': '16 x 360x480x3 uint8 -> Resize((480,256), BILINEAR) -> Normalize -> 16x3x256x480 fp32',
+                                'roofline': {'bound': 'hbm', 'achieved': round(alg / dt / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                                             'unit': 'GB/s', 'frac': round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)}}}
+    try:
+        from PIL import Image
+        mean = np.asarray([0.485, 0.456, 0.406], np.float32)[:, None, None]
+        std = np.asarray([0.229, 0.224, 0.225], np.float32)[:, None, None]
+        t0 = time.perf_counter()
+        for f in frames:
+            r = np.asarray(Image.fromarray(f).resize((480, 256), Image.BILINEAR))
+            ((r.transpose(2, 0, 1).astype(np.float32) / np.float32(255)) - mean) / std
+        out['host_pillow'] = {'value': round(BATCH / (time.perf_counter() - t0), 1), 'unit': 'images/s', 'cores': 1,
+                              'kind': 'reference dependency (Pillow resize + numpy normalise, per image)'}
+    except ImportError:
+        pass
+    labels = torch.from_numpy(np.stack([synth_image_u8(256, 480, 950 + i)[1] % 5 for i in range(BATCH)])).to(dev)
+    names = ['/d/color/frame_%03d.jpg' % i for i in range(BATCH)]
+    with tempfile.TemporaryDirectory() as d:
+        w = LabelWriter(d, workers=8)
+        t0 = time.perf_counter()
+        for _ in range(2):                                # warm-up: pinned staging buffers are allocated once
+            w.submit(names, labels)
+        for f in w._futures:
+            f.result()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            w.submit(names, labels)
+        t_submit = time.perf_counter() - t0
+        w.close()
+        t_all = time.perf_counter() - t0
+    out['label_writer'] = {'value': round(8 * BATCH / t_all, 1), 'unit': 'images/s', 'workers': 8,
+                           'submit_us_per_batch': round(t_submit / 8 * 1e6, 1),
+                           'note': 'PNG encode + file write on worker threads; submit() is what the label loop waits for'}
+    return out
+
+
 def train_step_rate(dev, iters=10):
     """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
     KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as one hipGraph replay
@@ -150,6 +211,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the extra train-step field')
+    ap.add_argument('--no-io', action='store_true', help='skip the extra loader/writer field (SURVEY 8f-1)')
     ap.add_argument('--no-aspp', action='store_true', help='skip the extra ASPP-head field (BASELINE configs[4])')
     ap.add_argument('--no-bs64', action='store_true', help='skip the extra batch-64 K2 field (use for rocprofv3 --stats runs: '
                     'its launches would mix into the per-kernel averages)')
@@ -319,6 +381,8 @@ def main():
             out['train_step'] = train_step_rate(dev)
         if world == 1 and not args.no_aspp:
             out['aspp_head'] = aspp_head_rate(dev)
+        if world == 1 and not args.no_io:
+            out['loader_io'] = loader_io_rate(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sd, shape)
         print(json.dumps(out))

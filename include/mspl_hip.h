@@ -274,6 +274,32 @@ int mspl_weighted_ce_bwd(const float* pred, const int64_t* target, const float* 
                          int32_t ignore_index, int32_t N, int32_t C, int32_t HW, const float* g, const float* den,
                          float* gpred, float* gu, void* stream);
 
+/* ---- loader-side transforms: the step in front of the hot path -------------------------------------
+ * Replace, for a whole batch of decoded uint8 images, data_loader/segmentation/greenhouse.py:216-222 (val_transforms =
+ * Resize(size) -> Normalize()|Tensorize()) i.e. transforms/segmentation/data_transforms.py:191-212 (PIL BILINEAR for
+ * rgb/depth, PIL NEAREST for labels) and :15-46 (to_tensor /255, normalize (x-MEAN)/STD).  Pillow's arithmetic (22-bit
+ * fixed-point triangle filter, horizontal pass first, uint8 between the passes) is reproduced bit for bit.
+ *
+ * Host-side table builders (no GPU work; plain host arrays):
+ *   mspl_resample_ksize(in, out)            taps per output sample (>0) or a negative status
+ *   mspl_resample_coeffs(in, out, bounds, kk)   bounds (out,2) = (first source index, count); kk (out, ksize) weights
+ *   mspl_nearest_index(in, out, idx)        source index per destination index for PIL NEAREST
+ */
+int mspl_resample_ksize(int32_t in_size, int32_t out_size);
+int mspl_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk);
+int mspl_nearest_index(int32_t in_size, int32_t out_size, int32_t* idx);
+/* src (N,Hs,Ws,C) uint8 HWC (C = 3 RGB or 1 depth) -> out (N,C,H,W) fp32.  xb/xk/kx and yb/yk/ky: DEVICE copies of the
+ * tables above for Ws->W and Hs->H (xb/xk/tmp may be NULL when Ws == W: Pillow skips that pass).  mean/std: C device
+ * floats or both NULL (Tensorize).  flip: N device bytes (RandomFlip's mirror, data_transforms.py:49-66) or NULL.
+ * tmp: (N,Hs,W,C) uint8 workspace. */
+int mspl_preprocess_u8_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws, int32_t C, int32_t H, int32_t W,
+                           const int32_t* xb, const int32_t* xk, int32_t kx, const int32_t* yb, const int32_t* yk,
+                           int32_t ky, const float* mean, const float* stdv, const uint8_t* flip, uint8_t* tmp,
+                           float* out, void* stream);
+/* Label maps: src (N,Hs,Ws) uint8 -> out (N,H,W) int64 (torch.LongTensor(np.array(label)), data_transforms.py:38), NEAREST. */
+int mspl_resize_label_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W,
+                          const int32_t* yi, const int32_t* xi, const uint8_t* flip, int64_t* out, void* stream);
+
 /* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
 int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);

@@ -67,6 +67,12 @@ SIGNATURES = {
     'mspl_dense_conv_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
                             ctypes.c_void_p],
     'mspl_miou_areas_fwd': [c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32, c_i32, c_i32, ctypes.c_void_p, ctypes.c_void_p],
+    'mspl_resample_ksize': [c_i32, c_i32],
+    'mspl_resample_coeffs': [c_i32, c_i32, ctypes.c_void_p, ctypes.c_void_p],
+    'mspl_nearest_index': [c_i32, c_i32, ctypes.c_void_p],
+    'mspl_preprocess_u8_fwd': [ctypes.c_void_p] + [c_i32] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p,
+                               ctypes.c_void_p, c_i32] + [ctypes.c_void_p] * 6,
+    'mspl_resize_label_fwd': [ctypes.c_void_p] + [c_i32] * 5 + [ctypes.c_void_p] * 5,
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],

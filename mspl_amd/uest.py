@@ -3,7 +3,7 @@
 Reference functions mirrored (same names / argument meaning; paths relative to the reference root):
   get_output                          uest_seg_multi_os.py:669-693
   merge_outputs                       uest_seg_multi_os.py:695-718
-  generate_pseudo_label_multi_model   uest_seg_multi_os.py:832-956  -> PseudoLabelPass (batched, on device)
+  generate_pseudo_label_multi_model   uest_seg_multi_os.py:832-956  -> PseudoLabelPass (batched, on device) + the function itself
   id_*_to_greenhouse                  data_loader/segmentation/greenhouse.py:15-58
 
 The reference runs batch size 1, one source model after another, and post-processes on the host with
@@ -150,6 +150,30 @@ class PseudoLabelPass:
 
     def class_weights(self, policy='normal'):
         return torch.from_numpy(class_weights_from_histogram(self.hist.cpu().numpy(), policy)).float().to(self.device)
+
+
+def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
+                                      merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
+                                      use_graph=True, writer_workers=4):
+    """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
+    `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
+
+    testloader yields the reference's tuples `(image, label, name, _)` (or `(image, label, depth, name, _)` with
+    use_depth; depth is only used for the list file, like the reference's :936) with any batch size.  The label maps never
+    visit the host on the critical path: PseudoLabelPass keeps them on the device, mspl_amd.io.LabelWriter copies and
+    encodes them asynchronously while the next batch runs."""
+    import os.path as osp
+    from .io import LabelWriter, update_image_list
+    p = PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy, device=device,
+                        use_graph=use_graph)
+    tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
+    writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)
+    for batch in testloader:
+        image, name = batch[0], batch[-2]
+        writer.submit(list(name), p(image))
+    lists = writer.close()
+    update_image_list(tgt_train_lst, *lists)
+    return tgt_train_lst, p.class_weights(class_weighting)
 
 
 class SelfLabelPass:

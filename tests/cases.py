@@ -47,6 +47,16 @@ ESPDNET_CASES = {
     'espdnet_c13_rgbd': (13, 'camvid', (1, 3, 48, 64), 42, 13, 14, False, True),
 }
 
+# loader transforms: name -> (source H, source W, PIL size (W,H), seed, normalize, flip, with depth)
+IMAGEIO_CASES = {
+    'camvid_360x480_to_480x256': (360, 480, (480, 256), 50, True, False, False),      # BASELINE shape: vertical pass only
+    'camvid_360x480_to_480x288': (360, 480, (480, 288), 51, True, True, False),
+    'big_720x960_to_480x256': (720, 960, (480, 256), 52, True, False, True),           # 2x down-scale: 5-tap windows
+    'upscale_100x130_to_480x256': (100, 130, (480, 256), 53, False, False, True),
+    'odd_37x53_to_64x48': (37, 53, (64, 48), 54, True, True, True),
+    'same_256x480': (256, 480, (480, 256), 55, True, False, False),
+}
+
 TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), sd_seed=21, in_seed=5,
                   lr=5e-4, weight_decay=5e-4, ignore_idx=4)
 

@@ -24,8 +24,8 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, ESPDNET_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
-from tests.synth import synth_input, synth_labels, synth_state_dict  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, IMAGEIO_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
+from tests.synth import synth_image_u8, synth_input, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
@@ -275,7 +275,39 @@ def gen_aspp():
         json.dump(keys, f, sort_keys=True)
 
 
+def gen_imageio():
+    """Loader transforms: Pillow's own resize (PIL is importable here) followed by what torchvision's to_tensor / normalize
+    do (torchvision itself is absent: `pic.permute(2,0,1).float().div(255)`, then `sub_(mean).div_(std)` on CPU) -- the
+    val_transforms of data_loader/segmentation/greenhouse.py:216-222.  Outputs are stored as SHA-256 of the exact bytes
+    (bit-exact contract) plus a strided sample for diagnosis."""
+    import hashlib
+    from PIL import Image
+    mean = torch.tensor([0.485, 0.456, 0.406])[:, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+    out = {}
+    for name, (hs, ws, size, seed, norm, flip, with_depth) in sorted(IMAGEIO_CASES.items()):
+        rgb, label, depth = synth_image_u8(hs, ws, seed)
+        r = Image.fromarray(rgb).resize(size, Image.BILINEAR)
+        lab = Image.fromarray(label).resize(size, Image.NEAREST)
+        d = Image.fromarray(depth).resize(size, Image.BILINEAR)
+        if flip:
+            r, lab, d = (im.transpose(Image.FLIP_LEFT_RIGHT) for im in (r, lab, d))
+        t = torch.from_numpy(np.asarray(r).copy()).permute(2, 0, 1).float().div(255)
+        if norm:
+            t = t.sub_(mean).div_(std)
+        lt = torch.LongTensor(np.array(lab).astype(np.int64))
+        dt = torch.from_numpy(np.asarray(d).copy())[None].float().div(255)
+        out[name + '.rgb_sha'] = np.frombuffer(hashlib.sha256(t.contiguous().numpy().tobytes()).digest(), np.uint8)
+        out[name + '.label_sha'] = np.frombuffer(hashlib.sha256(lt.numpy().tobytes()).digest(), np.uint8)
+        out[name + '.rgb_s'] = t[:, ::7, ::5]
+        out[name + '.label_s'] = lt[::7, ::5].to(torch.uint8)
+        if with_depth:
+            out[name + '.depth_sha'] = np.frombuffer(hashlib.sha256(dt.contiguous().numpy().tobytes()).digest(), np.uint8)
+            out[name + '.depth_s'] = dt[:, ::7, ::5]
+    save('imageio', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio']
     for w in which:
         globals()['gen_' + w]()

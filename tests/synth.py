@@ -60,3 +60,17 @@ def synth_labels(shape, num_classes, seed):
     g = torch.Generator()
     g.manual_seed(2000003 + seed)
     return torch.randint(0, num_classes, tuple(shape), generator=g)
+
+
+def synth_image_u8(h, w, seed):
+    """(rgb (h,w,3), label (h,w) with ids 0..4 and some 255, depth (h,w)) uint8 numpy arrays: smooth blobs plus noise, so
+    that resampling sees both gradients and edges."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (127 + 90 * np.sin(yy / 9.0 + seed) * np.cos(xx / 13.0)).astype(np.int32)
+    rgb = np.clip(base[:, :, None] + rng.integers(-60, 61, (h, w, 3)), 0, 255).astype(np.uint8)
+    label = ((yy // 11 + xx // 17 + seed) % 5).astype(np.uint8)
+    label[rng.random((h, w)) < 0.02] = 255
+    depth = np.clip(base + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)
+    return rgb, label, depth
