@@ -300,6 +300,29 @@ int mspl_preprocess_u8_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws
 int mspl_resize_label_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W,
                           const int32_t* yi, const int32_t* xi, const uint8_t* flip, int64_t* out, void* stream);
 
+/* ---- supervised-loop pieces -------------------------------------------------------------------------
+ * nn.BatchNorm2d in train() (model.train(), utilities/train_eval_seg.py:174): per-channel batch mean and 1/sqrt(biased
+ * var + eps) over (N,HW) of z (N,C,HW); when running_mean/running_var are given they are updated in place,
+ * r = (1-momentum)*r + momentum*stat (unbiased variance M/(M-1)).  ws: 2*C doubles of device workspace. */
+int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                            float* running_mean, float* running_var, double* ws, float* mean, float* invstd, void* stream);
+/* torch.optim.SGD (train_segmentation.py:253) on a flat fp32 buffer: g += wd*p; buf = first_step ? g : momentum*buf + g;
+ * p -= lr*buf  (dampening 0, no Nesterov; buf may be NULL when momentum == 0).  One call per learning-rate group. */
+int mspl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
+                  int32_t first_step, void* stream);
+
+/* NIDLoss (loss_fns/segmentation_loss.py:54-144), the two heavy steps: soft-arg-max of the label logits (:124-141) and the
+ * soft joint histogram of get_probabilities (:76-101).  camera (B,3,H,W) network input, label (B,C,H,W) logits, K image bins.
+ * out: K*Cl + K + Cl floats = joint (K,Cl) | p_c (K) | p_l (Cl), Cl = min(C,K) (the reference fills label bins inside its
+ * loop over image bins), all divided by norm = B*H*W.  ws: mspl_nid_workspace_floats(C,H,W,K) floats.
+ * Backward w.r.t. the label logits: gjoint (K,Cl) and gpl (Cl) = dL/d joint, dL/d p_l ALREADY divided by norm; glabel
+ * (B,C,H,W) is overwritten.  K, C <= 32. */
+int64_t mspl_nid_workspace_floats(int32_t C, int32_t H, int32_t W, int32_t K);
+int mspl_nid_hist_fwd(const float* camera, const float* label, int32_t B, int32_t C, int32_t H, int32_t W, int32_t K,
+                      float bw_camera, float bw_label, float* ws, float* out, void* stream);
+int mspl_nid_hist_bwd(const float* camera, const float* label, int32_t B, int32_t C, int32_t H, int32_t W, int32_t K,
+                      float bw_camera, float bw_label, const float* gjoint, const float* gpl, float* glabel, void* stream);
+
 /* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
 int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);

@@ -73,6 +73,11 @@ SIGNATURES = {
     'mspl_preprocess_u8_fwd': [ctypes.c_void_p] + [c_i32] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p,
                                ctypes.c_void_p, c_i32] + [ctypes.c_void_p] * 6,
     'mspl_resize_label_fwd': [ctypes.c_void_p] + [c_i32] * 5 + [ctypes.c_void_p] * 5,
+    'mspl_bn_batch_stats_fwd': [c_f32p, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 6,
+    'mspl_sgd_step': [c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i32, ctypes.c_void_p],
+    'mspl_nid_workspace_floats': [c_i32, c_i32, c_i32, c_i32],
+    'mspl_nid_hist_fwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_nid_hist_bwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],
@@ -90,6 +95,7 @@ def _load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
+    lib.mspl_nid_workspace_floats.restype = ctypes.c_int64
     lib.mspl_version.restype = ctypes.c_char_p
     lib.mspl_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.mspl_last_error.restype = ctypes.c_size_t

@@ -307,6 +307,52 @@ def bn_affine(bn):
     return BNFoldFn.apply(bn.weight, bn.bias, bn.running_mean, c[1])
 
 
+class BNBatchStatsFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d as a differentiable fold: (scale, shift) = (gamma*invstd, beta - mean*gamma*invstd) with
+    mean / biased variance taken over (N,H,W) of z (nn.BatchNorm2d.forward in train(); the supervised loop of
+    train_segmentation.py / utilities/train_eval_seg.py:174).  The statistics kernel also applies the running-statistics
+    update (momentum, unbiased variance).  Backward: the statistics' dependence on z is an affine map per channel,
+    gz = p_c*z + q_c, one pointwise launch; the direct path through (z*scale + shift) is AffinePReLUFn's."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum):
+        z = _c(z)
+        N, C = z.shape[:2]
+        hw = z[0, 0].numel()
+        ws = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+        mean = torch.empty(C, dtype=torch.float32, device=z.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+        check(lib.mspl_bn_batch_stats_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(ws), _p(mean),
+                                          _p(invstd), _stream()))
+        scale = gamma * invstd
+        shift = torch.addcmul(beta, mean, scale, value=-1.0)
+        ctx.save_for_backward(z, gamma, mean, invstd, scale)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, gsc, gsh):
+        z, gamma, mean, invstd, scale = ctx.saved_tensors
+        M = z.numel() // z.shape[1]
+        t = torch.addcmul(gsc, mean, gsh, value=-1.0)              # gsc - mean*gsh
+        ggamma = t * invstd
+        p = (gamma * t) * invstd.pow(3) * (-1.0 / M)
+        q = (gsh * scale) * (-1.0 / M) - p * mean
+        gz = ops.pointwise(z, Epi(p.contiguous(), q.contiguous()))
+        return gz, ggamma, gsh, None, None, None, None
+
+
+def bn_batch_stats(z, bn):
+    """(scale, shift) of a BatchNorm2d in train() for the batch z; updates running_mean / running_var /
+    num_batches_tracked like nn.BatchNorm2d does."""
+    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+        raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
+                           'not on the path (the reference uses the defaults everywhere)')
+    out = BNBatchStatsFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return out
+
+
 avgpool = AvgPoolFn.apply
 bilinear = BilinearFn.apply
 adaptive_avgpool = AdaptivePoolFn.apply

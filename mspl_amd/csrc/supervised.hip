@@ -1,0 +1,126 @@
+// Pieces of the supervised loop (train_segmentation.py / utilities/train_eval_seg.py) that the frozen-BN uest
+// step does not need:
+//   bn_batch_stats   nn.BatchNorm2d in train(): per-channel mean / biased variance over (N,H,W) + the running-statistics
+//                    update (momentum, unbiased variance), model.train() at utilities/train_eval_seg.py:174
+//   sgd_step         torch.optim.SGD(momentum, weight_decay) on a flat fp32 buffer, train_segmentation.py:253
+// Both are HBM streaming passes (4 B read per element for the statistics; 12 B read + 8 B written per parameter for SGD).
+#include "common.hpp"
+
+namespace mspl {
+
+// grid (chunks, N, C): one workgroup sums a slice of one plane, shifted by k_c = z[0,c,0] so that E[(x-k)^2] - E[x-k]^2 does
+// not cancel when |mean| >> std; fp32 per thread (<= a few hundred terms), double across threads and workgroups.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int C, int HW, int per_block,
+                                                       double* __restrict__ ws) {
+    const int c = blockIdx.z, n = blockIdx.y;
+    const float k = z[(size_t)c * HW];
+    const float* p = z + ((size_t)n * C + c) * (size_t)HW;
+    const int lo = blockIdx.x * per_block;
+    const int hi = min(HW, lo + per_block);
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0 && (per_block & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float a = p[i] - k;
+            s1 += a;
+            s2 += a * a;
+        }
+    }
+    double d1 = s1, d2 = s2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        d1 += __shfl_down(d1, o, 64);
+        d2 += __shfl_down(d2, o, 64);
+    }
+    __shared__ double part[8];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = d1; part[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ws + 2 * c, (part[0] + part[1]) + (part[2] + part[3]));
+        atomicAdd(ws + 2 * c + 1, (part[4] + part[5]) + (part[6] + part[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ z, const double* __restrict__ ws, int C, int HW,
+                                                          double M, float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ mean,
+                                                          float* __restrict__ invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double k = z[(size_t)c * HW];
+    const double e1 = ws[2 * c] / M, e2 = ws[2 * c + 1] / M;
+    const double mu = k + e1;
+    double var = e2 - e1 * e1;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// torch.optim.SGD: g += wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf      (dampening 0, no Nesterov)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float momentum, float wd, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float b = gi;
+    if (momentum != 0.f) {
+        b = first ? gi : momentum * buf[i] + gi;
+        buf[i] = b;
+    }
+    p[i] = pi - lr * b;
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                       float* running_mean, float* running_var, double* ws, float* mean, float* invstd,
+                                       void* stream) {
+    MSPL_REQUIRE(z && ws && mean && invstd, MSPL_ERR_NULL_POINTER, "bn_batch_stats: null pointer");
+    MSPL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MSPL_ERR_NULL_POINTER,
+                 "bn_batch_stats: running_mean and running_var go together");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0 && N <= 65535 && C <= 65535, MSPL_ERR_BAD_SHAPE, "bn_batch_stats: bad shape N=%d C=%d HW=%d",
+                 N, C, HW);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)C, s) != hipSuccess) {
+        MSPL_REQUIRE(false, MSPL_ERR_HIP, "bn_batch_stats: hipMemsetAsync failed");
+    }
+    // slices of >= 4096 elements, and enough workgroups (~2048) to fill the chip when N*C is small
+    int chunks = ceil_div(2048, N * C);
+    if (chunks < 1) chunks = 1;
+    int per_block = ceil_div(HW, chunks);
+    if (per_block < 4096) per_block = 4096;
+    per_block = (per_block + 3) & ~3;
+    chunks = ceil_div(HW, per_block);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(256), 0, s, z, C, HW, per_block, ws);
+    MSPL_CHECK_LAUNCH("bn_batch_stats(sum)");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, s, z, ws, C, HW, (double)N * (double)HW, eps,
+                       momentum, running_mean, running_var, mean, invstd);
+    MSPL_CHECK_LAUNCH("bn_batch_stats(finalize)");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
+                             int32_t first_step, void* stream) {
+    MSPL_REQUIRE(p && g && (buf || momentum == 0.f), MSPL_ERR_NULL_POINTER, "sgd_step: null pointer");
+    MSPL_REQUIRE(n >= 0, MSPL_ERR_BAD_SHAPE, "sgd_step: n=%lld", (long long)n);
+    if (n == 0) return MSPL_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
+                       weight_decay, first_step);
+    MSPL_CHECK_LAUNCH("sgd_step");
+    return MSPL_OK;
+}

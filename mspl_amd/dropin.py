@@ -58,6 +58,9 @@ def install_dropin(force=False):
     from . import aspp as A
     _alias('nn_layers.aspp', ASPP=A.ASPP, ASPP_Bottleneck=A.ASPP_Bottleneck)
     from . import losses as S
+    from . import lr_scheduler as R
+    _alias('utilities.lr_scheduler', CyclicLR=R.CyclicLR, FixedMultiStepLR=R.FixedMultiStepLR, PolyLR=R.PolyLR,
+           LinearLR=R.LinearLR, HybirdLR=R.HybirdLR, CosineLR=R.CosineLR)
     from . import metrics as Q
     _alias('utilities.metrics.segmentation_miou', MIOU=Q.MIOU)
     _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,

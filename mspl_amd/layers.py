@@ -56,9 +56,9 @@ def cached(module, name, deps, builder):
 
 def _require_eval(bn):
     if bn.training:
-        raise RuntimeError('mspl_amd: BatchNorm in training mode (batch statistics) is not implemented natively; '
-                           'call model.eval() -- the uest label pass and self-training loop run frozen BN '
-                           '(uest_seg_multi_os.py:605-608)')
+        raise RuntimeError('mspl_amd: BatchNorm in training mode under torch.no_grad(): the fused inference kernels fold the '
+                           'running statistics; call model.eval() (the uest label pass runs frozen BN, '
+                           'uest_seg_multi_os.py:605-608), or enable gradients for the batch-statistics training path')
 
 
 def bn_fold(bn):
@@ -159,9 +159,17 @@ def _conv_train(x, conv):
     return ag.conv(x, conv.weight, conv.stride[0], conv.groups)
 
 
-def _bn_train(bn):
-    _require_eval(bn)
-    return ag.bn_affine(bn)
+def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
+    """PReLU(BN(z + pre_add) + residual) on the training path.  bn.eval(): frozen statistics folded into (scale, shift)
+    (the uest loop, uest_seg_multi_os.py:605-608).  bn.train(): batch statistics (the supervised loop, model.train() at
+    utilities/train_eval_seg.py:174) -- (scale, shift) then depend on z, running statistics are updated in place."""
+    if bn.training:
+        if pre_add is not None:
+            z, pre_add = z + pre_add, None
+        scale, shift = ag.bn_batch_stats(z, bn)
+    else:
+        scale, shift = ag.bn_affine(bn)
+    return ag.affine_prelu(z, scale, shift, alpha, pre_add=pre_add, residual=residual)
 
 
 def _conv_fwd(x, conv, ep, out=None, shuffle_groups=0):
@@ -185,8 +193,7 @@ class CBR(nn.Module):
 
     def forward(self, input):
         if _training_path():
-            scale, shift = _bn_train(self.bn)
-            return ag.affine_prelu(_conv_train(input, self.conv), scale, shift, self.act.weight)
+            return _bn_act(_conv_train(input, self.conv), self.bn, self.act.weight)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift, self.act.weight))
 
@@ -199,8 +206,7 @@ class BR(nn.Module):
 
     def forward(self, input):
         if _training_path():
-            scale, shift = _bn_train(self.bn)
-            return ag.affine_prelu(input, scale, shift, self.act.weight)
+            return _bn_act(input, self.bn, self.act.weight)
         scale, shift = bn_fold(self.bn)
         return ops.pointwise(input, Epi(scale, shift, self.act.weight))
 
@@ -214,8 +220,7 @@ class CB(nn.Module):
 
     def forward(self, input):
         if _training_path():
-            scale, shift = _bn_train(self.bn)
-            return ag.affine_prelu(_conv_train(input, self.conv), scale, shift)
+            return _bn_act(_conv_train(input, self.conv), self.bn)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift))
 
@@ -265,8 +270,7 @@ class DecCBR(nn.Module):
 
     def forward(self, x):
         if _training_path():
-            scale, shift = _bn_train(self.cbr[1])
-            return ag.affine_prelu(_conv_train(x, self.cbr[0]), scale, shift, self.cbr[2].weight)
+            return _bn_act(_conv_train(x, self.cbr[0]), self.cbr[1], self.cbr[2].weight)
         return _conv_fwd(x, self.cbr[0], self.epi())
 
 
@@ -279,8 +283,7 @@ class DecBR(nn.Module):
 
     def forward(self, x):
         if _training_path():
-            scale, shift = _bn_train(self.br[0])
-            return ag.affine_prelu(x, scale, shift, self.br[1].weight)
+            return _bn_act(x, self.br[0], self.br[1].weight)
         scale, shift = bn_fold(self.br[0])
         return ops.pointwise(x, Epi(scale, shift, self.br[1].weight))
 
@@ -339,12 +342,11 @@ class EESP(nn.Module):
         o1 = self.proj_1x1(input)
         cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
         cat = self.br_after_cat(cat)
-        scale, shift = _bn_train(self.conv_1x1_exp.bn)
         e = _conv_train(cat, self.conv_1x1_exp.conv)
         if self.stride == 2 and self.downAvg:
-            return ag.affine_prelu(e, scale, shift)
+            return _bn_act(e, self.conv_1x1_exp.bn)
         residual = input if (self.stride == 1 and e.shape[1] == input.shape[1]) else None
-        return ag.affine_prelu(e, scale, shift, self.module_act.weight, residual=residual)
+        return _bn_act(e, self.conv_1x1_exp.bn, self.module_act.weight, residual=residual)
 
     def forward(self, input):
         if _training_path():
@@ -562,8 +564,7 @@ class EfficientPyrPool(nn.Module):
         conv = self.merge_layer[3]
         c = ag.conv(out, conv.weight, 1, 1)
         if self.last_layer_br:
-            scale, shift = _bn_train(self.br.br[0])
-            return ag.affine_prelu(c, scale, shift, self.br.br[1].weight)
+            return _bn_act(c, self.br.br[0], self.br.br[1].weight)
         return ag.affine_prelu(c, None, conv.bias, None)
 
     def forward(self, x, fused=True):
@@ -610,7 +611,6 @@ def decoder_merge(pw_out, bu_lowres, br_seq):
         raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 2'
                            % (pw_out.shape[2], size[0]))
     if _training_path():
-        scale, shift = _bn_train(br_seq[0])
-        return ag.affine_prelu(ag.bilinear(bu_lowres, size), scale, shift, br_seq[1].weight, pre_add=pw_out)
+        return _bn_act(ag.bilinear(bu_lowres, size), br_seq[0], br_seq[1].weight, pre_add=pw_out)
     scale, shift = bn_fold(br_seq[0])
     return ops.bilinear(bu_lowres, size, Epi(scale, shift, br_seq[1].weight, pre_add=pw_out))

@@ -124,7 +124,67 @@ class SegmentationLoss(nn.Module):
         return self._one(inputs, target)
 
 
+class _NIDHistFn(torch.autograd.Function):
+    """(joint (K,C), p_c (K), p_l (C)) of NIDLoss.get_probabilities applied to the soft-arg-max of the label logits."""
+
+    @staticmethod
+    def forward(ctx, camera, label, K, bw_c, bw_l):
+        camera, label = camera.contiguous().float(), label.contiguous().float()
+        B, C, H, W = label.shape
+        if camera.shape != (B, 3, H, W):
+            raise RuntimeError('mspl_amd: NIDLoss expects camera (B,3,H,W) matching label (B,C,H,W), got %s / %s'
+                               % (tuple(camera.shape), tuple(label.shape)))
+        Cl = min(C, K)
+        n_ws = lib.mspl_nid_workspace_floats(C, H, W, K)
+        if n_ws < 0:
+            check(int(n_ws))
+        ws = torch.empty(n_ws, dtype=torch.float32, device=label.device)
+        out = torch.empty(K * Cl + K + Cl, dtype=torch.float32, device=label.device)
+        check(lib.mspl_nid_hist_fwd(_p(camera), _p(label), B, C, H, W, K, bw_c, bw_l, _p(ws), _p(out), _stream()))
+        ctx.save_for_backward(camera, label)
+        ctx.cfg = (K, bw_c, bw_l, Cl)
+        joint = torch.zeros(K, C, dtype=torch.float32, device=label.device)
+        joint[:, :Cl] = out[:K * Cl].view(K, Cl)
+        p_l = torch.zeros(C, dtype=torch.float32, device=label.device)
+        p_l[:Cl] = out[K * Cl + K:]
+        return joint, out[K * Cl:K * Cl + K].clone(), p_l
+
+    @staticmethod
+    def backward(ctx, gj, gpc, gpl):
+        camera, label = ctx.saved_tensors
+        K, bw_c, bw_l, Cl = ctx.cfg
+        B, C, H, W = label.shape
+        inv = 1.0 / (B * H * W)
+        gj = (gj[:, :Cl] * inv).contiguous()
+        gpl = (gpl[:Cl] * inv).contiguous()
+        glabel = torch.zeros_like(label) if Cl < C else torch.empty_like(label)
+        check(lib.mspl_nid_hist_bwd(_p(camera), _p(label), B, C, H, W, K, bw_c, bw_l, _p(gj), _p(gpl), _p(glabel), _stream()))
+        return None, glabel, None, None, None
+
+
 class NIDLoss(nn.Module):
-    def __init__(self, *a, **k):
+    """loss_fns/segmentation_loss.py:54-121: (NID(camera grey levels, soft-arg-max labels) - 0.95) * 20.  The soft histograms
+    run in two HIP kernels (nid.hip); the K x C entropy arithmetic below is the reference's, on tiny device tensors.  The
+    reference's hard-coded `.to('cuda')` calls have no counterpart (tensors stay on the inputs' device)."""
+
+    def __init__(self, image_bin=16, label_bin=4, bw_camera=0.005, bw_label=0.001):
         super().__init__()
-        raise RuntimeError('mspl_amd: NIDLoss is outside the hot path (SURVEY section 8f); use the reference implementation')
+        self.K, self.C = image_bin, label_bin
+        self.bw_camera, self.bw_label = bw_camera, bw_label
+
+    def nid(self, p_cl, p_c, p_l, eps=1e-7):
+        I = torch.sum(p_cl * (torch.log(p_cl + eps) - torch.log(torch.mm(p_c, torch.t(p_l)) + eps)))
+        H = -torch.sum(p_cl * torch.log(p_cl + eps))
+        return 1 - I / H
+
+    def forward(self, camera, label):
+        if label.shape[1] < self.C:
+            raise RuntimeError('mspl_amd: NIDLoss(label_bin=%d) got logits with %d classes' % (self.C, label.shape[1]))
+        p_cl, p_c, p_l = _NIDHistFn.apply(camera, label, self.K, float(self.bw_camera), float(self.bw_label))
+        # label_bin rows of the label histogram (:91-93 fills k < self.C); classes beyond label_bin never get a bin
+        p_cl, p_l = p_cl[:, :self.C], p_l[:self.C]
+        p_cl = p_cl / p_cl.sum()
+        p_c = p_c / p_c.sum()
+        p_l = p_l / p_l.sum()
+        nid = self.nid(p_cl, p_c.reshape(-1, 1), p_l.reshape(-1, 1))
+        return (nid - 0.95) * 20

@@ -1,0 +1,132 @@
+"""The supervised source-model loop on the HIP path: what train_segmentation.py needs beyond the frozen-BN
+uest step.
+
+Reference surface mirrored (paths relative to the reference root):
+  utilities/train_eval_seg.py:164-225   train_seg_ue: model.train() (batch-statistics BatchNorm), loss =
+                                        criterion(out + 0.5*aux, target).mean() [+ add_criterion(inputs, out)*weight],
+                                        flooding `(loss - b).abs() + b` with b = 0.015 (:221), zero_grad/backward/step
+  train_segmentation.py:241-253         torch.optim.SGD over 2-3 learning-rate groups (base net lr, segmentation head and
+                                        depth encoder lr*lr_mult), momentum, weight_decay
+  train_segmentation.py:353-362         per-epoch learning rates written into optimizer.param_groups[i]['lr']
+  utilities/lr_scheduler.py             -> mspl_amd/lr_scheduler.py
+
+Batch-statistics BatchNorm runs through mspl_amd.autograd.BNBatchStatsFn (statistics kernel + the existing affine/PReLU
+kernels); `FlatSGD` keeps parameters, gradients and momentum buffers of all groups in three flat fp32 buffers laid out group
+after group, so a step is one kernel per group and the multi-GPU exchange one all-reduce.
+"""
+import torch
+
+from . import dist as mdist
+from . import layers
+from ._native import check, lib
+from .ops import _p, _stream
+
+FLOOD_LEVEL = 0.015          # utilities/train_eval_seg.py:178
+
+
+class FlatSGD:
+    """torch.optim.SGD semantics (momentum, L2 weight_decay, dampening 0, no Nesterov; parameters whose gradient is None
+    are skipped) over torch-style parameter groups `[{'params': iterable, 'lr': float}, ...]`.  Build it AFTER the first
+    backward, like FlatAdam.  A parameter listed in two groups raises, as torch.optim does."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{'params': groups}]
+        self.param_groups, seen, flat = [], set(), []
+        for g in groups:
+            ps = [p for p in g['params'] if p.requires_grad and p.grad is not None]
+            for p in ps:
+                if id(p) in seen:
+                    raise ValueError('some parameters appear in more than one parameter group')
+                seen.add(id(p))
+            self.param_groups.append({'params': ps, 'lr': g.get('lr', lr), 'momentum': g.get('momentum', momentum),
+                                      'weight_decay': g.get('weight_decay', weight_decay)})
+            flat += ps
+        if not flat:
+            raise RuntimeError('FlatSGD: run one backward before constructing the optimizer (no parameter has a gradient)')
+        dev = flat[0].device
+        n = sum(p.numel() for p in flat)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
+        self.buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for g in self.param_groups:
+                g['_lo'] = off
+                for p in g['params']:
+                    k = p.numel()
+                    pv, gv = self.flat_p[off:off + k].view_as(p), self.flat_g[off:off + k].view_as(p)
+                    pv.copy_(p.data)
+                    gv.copy_(p.grad)
+                    p.data, p.grad = pv, gv
+                    off += k
+                g['_hi'] = off
+        self.params = flat
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def all_reduce_grads(self):
+        _, w = mdist.world()
+        if w > 1:
+            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM)
+            self.flat_g.div_(w)
+
+    def step(self):
+        first = 1 if self.step_count == 0 else 0
+        self.step_count += 1
+        for g in self.param_groups:
+            lo, hi = g['_lo'], g['_hi']
+            if hi > lo:
+                check(lib.mspl_sgd_step(_p(self.flat_p[lo:hi]), _p(self.flat_g[lo:hi]), _p(self.buf[lo:hi]), hi - lo, float(g['lr']),
+                                        float(g['momentum']), float(g['weight_decay']), first, _stream()))
+        layers.bump_param_epoch()
+
+
+def segmentation_param_groups(model, lr, lr_mult, use_depth=False):
+    """train_segmentation.py:244-250."""
+    groups = [{'params': model.get_basenet_params(), 'lr': lr},
+              {'params': model.get_segment_params(), 'lr': lr * lr_mult}]
+    if use_depth:
+        groups.append({'params': model.get_depth_encoder_params(), 'lr': lr * lr_mult})
+    return groups
+
+
+def set_epoch_learning_rates(optimizer, lr_base, lr_mult, use_depth=False):
+    """train_segmentation.py:356-362 (including its depth-group rule: group 2 gets lr_base, not lr_base*lr_mult)."""
+    optimizer.param_groups[0]['lr'] = lr_base
+    if len(optimizer.param_groups) > 1:
+        optimizer.param_groups[1]['lr'] = lr_base * lr_mult
+    if use_depth:
+        optimizer.param_groups[2]['lr'] = lr_base
+    return lr_base, lr_base * lr_mult
+
+
+def flood(loss, b=FLOOD_LEVEL):
+    """utilities/train_eval_seg.py:221."""
+    return (loss - b).abs() + b
+
+
+def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=None, add_criterion=None, weight=1.0,
+                      lr=0.009, lr_mult=10.0, momentum=0.9, weight_decay=4e-5, b=FLOOD_LEVEL):
+    """One iteration of train_seg_ue (utilities/train_eval_seg.py:179-225) for a two-head model in train() mode.
+    Returns (flooded loss, (main + 0.5*aux) logits detached -- what the reference hands to MIOU --, optimizer).  Pass
+    optimizer=None on the first call: it is built after the first backward from segmentation_param_groups."""
+    if optimizer is not None:
+        optimizer.zero_grad()
+    with torch.enable_grad():
+        out = model(inputs, depth) if depth is not None else model(inputs)
+        outputs = out[0] + 0.5 * out[1]
+        loss = criterion(outputs, target).mean()
+        if add_criterion is not None:
+            loss = loss + add_criterion(inputs, outputs) * weight
+        loss = flood(loss, b)
+        loss.backward()
+    if optimizer is None:
+        optimizer = FlatSGD(segmentation_param_groups(model, lr, lr_mult, depth is not None), lr=lr * lr_mult,
+                            momentum=momentum, weight_decay=weight_decay)
+    optimizer.all_reduce_grads()
+    optimizer.step()
+    return loss.detach(), outputs.detach(), optimizer

@@ -114,3 +114,38 @@ def miou_areas(output, target, num_classes):
     a_p = torch.histc(pred.float(), bins=k, min=1, max=k)
     a_m = torch.histc(target.float(), bins=k, min=1, max=k)
     return a_i.numpy(), (a_p + a_m - a_i + 1e-6).numpy()
+
+
+def soft_arg_max(A, beta=500.0, epsilon=1e-12):
+    """SoftArgMax.soft_arg_max, loss_fns/segmentation_loss.py:124-141 -> (B,1,H,W)."""
+    A_max = torch.max(A, dim=1, keepdim=True)[0]
+    A_exp = torch.exp((A - A_max) * beta)
+    A_softmax = A_exp / (torch.sum(A_exp, dim=1, keepdim=True) + epsilon)
+    indices = torch.arange(start=0, end=A.size(1)).float().reshape(1, A.size(1), 1, 1)
+    return F.conv2d(A_softmax, indices)
+
+
+def nid_loss(camera, label, image_bin=16, label_bin=4, bw_camera=0.005, bw_label=0.001, eps=1e-7):
+    """NIDLoss.forward, loss_fns/segmentation_loss.py:54-121 (device moves dropped)."""
+    K, C = image_bin, label_bin
+    cam = torch.sum(camera, 1) / 3
+    lab = soft_arg_max(label)
+    lab = lab.reshape(lab.size(0), lab.size(2), lab.size(3))
+    num_pixel = cam.size(1) * cam.size(2)
+    batch = cam.size(0)
+    cam_1d = cam.reshape(batch, -1)
+    lab_1d = lab.reshape(batch, -1)
+    L_c, L_l = 1 / K, 1
+    P_c, P_l = [], [torch.zeros(num_pixel) for _ in range(C)]
+    for k in range(K):
+        mu = L_c * (k + 1 / 2)
+        P_c.append(torch.sum(torch.sigmoid((cam_1d - mu + L_c / 2) / bw_camera) - torch.sigmoid((cam_1d - mu - L_c / 2) / bw_camera), 0))
+        if k < C:
+            P_l[k] = torch.sum(torch.sigmoid((lab_1d - k + L_l / 2) / bw_label) - torch.sigmoid((lab_1d - k - L_l / 2) / bw_label), 0)
+    P_c, P_l = torch.stack(P_c), torch.stack(P_l)
+    norm = num_pixel * batch
+    p_cl, p_c, p_l = torch.mm(P_c, P_l.t()) / norm, torch.sum(P_c, 1) / norm, torch.sum(P_l, 1) / norm
+    p_cl, p_c, p_l = p_cl / p_cl.sum(), (p_c / p_c.sum()).reshape(-1, 1), (p_l / p_l.sum()).reshape(-1, 1)
+    I = torch.sum(p_cl * (torch.log(p_cl + eps) - torch.log(torch.mm(p_c, p_l.t()) + eps)))
+    H = -torch.sum(p_cl * torch.log(p_cl + eps))
+    return ((1 - I / H) - 0.95) * 20

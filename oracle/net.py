@@ -40,9 +40,23 @@ def eesp_dilations(r_lim, k=BRANCHES):
 
 
 # ---------------------------------------------------------------- primitives
+BN_MODE = {'training': False, 'momentum': 0.1}
+
+
+class bn_training(object):
+    """Context: BatchNorm uses batch statistics and updates sd[...running_mean/var] in place (nn.BatchNorm2d in train(),
+    the supervised loop's model.train(), utilities/train_eval_seg.py:174)."""
+
+    def __enter__(self):
+        BN_MODE['training'] = True
+
+    def __exit__(self, *exc):
+        BN_MODE['training'] = False
+
+
 def _bn(x, sd, p):
-    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'],
-                        sd[p + '.weight'], sd[p + '.bias'], False, 0.0, BN_EPS)
+    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
+                        BN_MODE['training'], BN_MODE['momentum'], BN_EPS)
 
 
 def _enc_conv(x, sd, p, stride=1, groups=1, dilation=1):

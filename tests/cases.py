@@ -61,6 +61,29 @@ TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), 
                   lr=5e-4, weight_decay=5e-4, ignore_idx=4)
 
 
+# one supervised iteration (train_seg_ue + SGD with learning-rate groups, batch-statistics BatchNorm), SURVEY 8f-4
+SUPERVISED_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(4, 3, 64, 64), sd_seed=51, in_seed=15, lr=0.009,
+                       lr_mult=10.0, momentum=0.9, weight_decay=4e-5, ignore_idx=4, flood=0.015)
+
+# epoch-wise schedules (utilities/lr_scheduler.py): (class name, kwargs, epochs)
+LR_CASES = [
+    ('CyclicLR', dict(min_lr=0.009, cycle_len=5, steps=[51, 101, 131], gamma=0.5), 160),
+    ('CyclicLR', dict(min_lr=0.01, cycle_len=3, steps=[10], gamma=0.7), 40),
+    ('FixedMultiStepLR', dict(base_lr=0.1, steps=[30, 60, 90], gamma=0.1), 100),
+    ('PolyLR', dict(base_lr=0.009, max_epochs=200, power=0.9), 200),
+    ('LinearLR', dict(base_lr=0.009, max_epochs=100), 100),
+    ('HybirdLR', dict(base_lr=0.009, clr_max=61, max_epochs=200, cycle_len=5), 200),
+    ('HybirdLR', dict(base_lr=0.01, clr_max=11, max_epochs=30, cycle_len=4), 30),
+    ('CosineLR', dict(base_lr=0.05, max_epochs=120), 120),
+]
+
+# NIDLoss (loss_fns/segmentation_loss.py:54-144): name -> (camera shape, label classes, image_bin, seed)
+NID_CASES = {
+    'nid_k16_c5': ((2, 3, 32, 48), 5, 16, 80),        # uest: image_bin=args.nid_bin, label_bin=args.classes
+    'nid_k32_c13': ((3, 3, 24, 40), 13, 32, 81),      # train_segmentation.py:287: image_bin=32, label_bin=seg_classes
+    'nid_k4_c5': ((1, 3, 17, 23), 5, 4, 82),          # fewer image bins than classes: label bins >= K stay empty
+}
+
 # ASPP heads (nn_layers/aspp.py, BASELINE configs[4]): name -> (class name, num_classes, input shape, sd seed, input seed).
 # Small maps on purpose: the dilations (6 / 12 / 18) then reach past every border.
 ASPP_CASES = {

@@ -24,8 +24,8 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, ESPDNET_CASES, IMAGEIO_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
-from tests.synth import synth_image_u8, synth_input, synth_labels, synth_state_dict  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, IMAGEIO_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
+from tests.synth import synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
@@ -35,7 +35,7 @@ from nn_layers import aspp as ref_aspp  # noqa: E402
 from model.segmentation.espdnet_ue import ESPDNetwithUncertaintyEstimation  # noqa: E402
 from model.segmentation.espnetv2 import ESPNetv2Segmentation  # noqa: E402
 from model.segmentation.espdnet import ESPDNetSegmentation  # noqa: E402
-from loss_fns.segmentation_loss import PixelwiseKLD, UncertaintyWeightedSegmentationLoss  # noqa: E402
+from loss_fns.segmentation_loss import NIDLoss, PixelwiseKLD, SegmentationLoss, UncertaintyWeightedSegmentationLoss  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -275,6 +275,69 @@ def gen_aspp():
         json.dump(keys, f, sort_keys=True)
 
 
+def gen_supervised():
+    """One iteration of the supervised loop with the reference's modules: the body of train_seg_ue
+    (utilities/train_eval_seg.py:179-225; the file itself imports tensorboard-era helpers and is restated here line by
+    line) on ESPDNet-UE in train() mode, SegmentationLoss (CrossEntropy), flooding, torch.optim.SGD over the two
+    learning-rate groups of train_segmentation.py:248-253.  Also the epoch-wise schedules of utilities/lr_scheduler.py."""
+    import copy
+    from utilities import lr_scheduler as ref_lr
+    c = SUPERVISED_CASE
+    m = build_model('espdnetue', c['s'], c['classes'], c['dataset'])
+    m.load_state_dict(synth_state_dict(m.state_dict(), c['sd_seed']))
+    m.train()
+    x = synth_input(c['shape'], c['in_seed'])
+    target = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed'])
+    crit = SegmentationLoss(n_classes=c['classes'], device='cpu', ignore_idx=c['ignore_idx'], class_weights=None)
+    groups = [{'params': m.get_basenet_params(), 'lr': c['lr']},
+              {'params': m.get_segment_params(), 'lr': c['lr'] * c['lr_mult']}]
+    opt = torch.optim.SGD(groups, lr=c['lr'] * c['lr_mult'], momentum=c['momentum'], weight_decay=c['weight_decay'])
+    outputs = m(x)
+    kld = PixelwiseKLD()(outputs[0], outputs[1])  # noqa: F841  (computed and unused, :197)
+    out = outputs[0] + 0.5 * outputs[1]
+    loss = crit(out, target).mean()
+    b = c['flood']
+    loss = (loss - b).abs() + b
+    opt.zero_grad()
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in m.named_parameters()])
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt.step()
+    moved = np.array([bool((p.detach() != before[n]).any()) for n, p in m.named_parameters()])
+    keep = ['base_net.level1.conv.weight', 'base_net.level1.bn.weight', 'base_net.level4.6.spp_dw.3.conv.weight',
+            'bu_dec_l4.merge_layer.3.bias', 'bu_dec_l2.stages.1.weight', 'merge_enc_dec_l3.wt_layer.1.weight', 'bu_br_l3.0.bias',
+            'base_net.level3_0.eesp.conv_1x1_exp.bn.weight']
+    stats = ['base_net.level1.bn.running_mean', 'base_net.level1.bn.running_var', 'base_net.level4.3.br_after_cat.bn.running_var',
+             'bu_br_l2.0.running_mean', 'bu_dec_l3.projection_layer.cbr.1.running_var', 'depth_base_net.level3.1.proj_1x1.bn.running_mean',
+             'aux_decoder.merge_layer.0.br.0.running_var', 'base_net.level1.bn.num_batches_tracked']
+    pd, sd = dict(m.named_parameters()), m.state_dict()
+    save('supervised_step', loss=loss.detach(), logits=out.detach()[:, :, ::4, ::4], names=np.array(names), gnorm=gnorm, moved=moved,
+         keep=np.array(keep), stats=np.array(stats), **{'after_%d' % i: pd[k].detach() for i, k in enumerate(keep)},
+         **{'stat_%d' % i: sd[k] for i, k in enumerate(stats)})
+    tables = []
+    for name, kw, epochs in LR_CASES:
+        sch = getattr(ref_lr, name)(**copy.deepcopy(kw))
+        tables.append([sch.step(e) for e in range(epochs)])
+    with open(os.path.join(HERE, 'lr_schedules.json'), 'w') as f:
+        json.dump(tables, f)
+
+
+def gen_nid():
+    """NIDLoss value and gradient w.r.t. the label logits (its `.to('cuda')` calls mapped to "stay here", see
+    _cuda_means_here)."""
+    out = {}
+    for name, (shape, classes, K, seed) in sorted(NID_CASES.items()):
+        cam, lab = synth_nid_inputs(shape, classes, seed)
+        lab.requires_grad_()
+        with _cuda_means_here():
+            loss = NIDLoss(image_bin=K, label_bin=classes)(cam, lab)
+            loss.backward()
+        out[name + '.loss'] = loss.detach()
+        out[name + '.grad'] = lab.grad
+    save('nid', **out)
+
+
 def gen_imageio():
     """Loader transforms: Pillow's own resize (PIL is importable here) followed by what torchvision's to_tensor / normalize
     do (torchvision itself is absent: `pic.permute(2,0,1).float().div(255)`, then `sub_(mean).div_(std)` on CPU) -- the
@@ -308,6 +371,6 @@ def gen_imageio():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio', 'supervised', 'nid']
     for w in which:
         globals()['gen_' + w]()

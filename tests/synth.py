@@ -74,3 +74,23 @@ def synth_image_u8(h, w, seed):
     label[rng.random((h, w)) < 0.02] = 255
     depth = np.clip(base + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)
     return rgb, label, depth
+
+
+def synth_nid_inputs(shape, classes, seed):
+    """(camera (B,3,H,W) in roughly [-0.3, 1.3], label logits (B,C,H,W)).  About 15 % of the pixels get two ADJACENT classes
+    as near-ties (difference of a few 1e-3), so that the soft-arg-max lands between two label bins and the loss has a
+    gradient there (with beta = 500 and bw_label = 1e-3 it is zero to fp32 precision everywhere else)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    B, _, H, W = shape
+    cam = torch.rand((B, 3, H, W), generator=g) * 1.6 - 0.3
+    lab = torch.randn((B, classes, H, W), generator=g) * 3
+    tie = torch.rand((B, H, W), generator=g) < 0.15
+    c0 = torch.randint(0, classes - 1, (B, H, W), generator=g)
+    delta = (torch.rand((B, H, W), generator=g) - 0.5) * 0.008
+    top = lab.max(1)[0] + 1.0
+    for c in range(classes - 1):
+        m = tie & (c0 == c)
+        lab[:, c][m] = top[m]
+        lab[:, c + 1][m] = (top + delta)[m]
+    return cam, lab
