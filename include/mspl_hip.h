@@ -226,6 +226,12 @@ int mspl_plane_dot(const float* a, const float* b, int32_t planes, int32_t HW, f
 /* gx[i,p] (+)= v[i] * mul. */
 int mspl_plane_broadcast(const float* v, int32_t planes, int32_t HW, float mul, int32_t accumulate, float* gx,
                          void* stream);
+/* Same backward when (scale, shift) is a folded FROZEN BatchNorm, scale = gamma*inv, shift = beta - mean*gamma*inv
+ * (inv = rsqrt(running_var + eps)): the per-channel sums are transformed on the fly and ACCUMULATED into ggamma / gbeta /
+ * galpha -- which may be the parameters' own gradient buffers (the caller's optimizer zeroes them once per step). */
+int mspl_bn_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy, const float* scale,
+                      const float* shift, const float* alpha, const float* bn_mean, const float* bn_inv, int32_t N, int32_t C,
+                      int32_t HW, float* gz, float* gc, float* ggamma, float* gbeta, float* galpha, void* stream);
 /* Backward of mspl_gap_gate_fwd's gate = sigmoid(W . mean): gw (Cout,Cin), gmean (N,Cin). */
 int mspl_gap_gate_bwd(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
                       int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream);

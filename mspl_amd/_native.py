@@ -47,6 +47,7 @@ SIGNATURES = {
     'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
+    'mspl_bn_prelu_bwd': [c_f32p] * 9 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
     'mspl_avgpool3x3s2_bwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_bilinear_bwd': [c_f32p] + [c_i32] * 6 + [c_f32p, ctypes.c_void_p],
     'mspl_adaptive_avgpool_bwd': [c_f32p] + [c_i32] * 6 + [c_f32p, ctypes.c_void_p],

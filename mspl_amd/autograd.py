@@ -6,6 +6,7 @@ expressions of gamma/beta and the running statistics, so gamma/beta still receiv
 torch.cat / view / transpose in this path are pure data movement (no arithmetic).
 """
 import ctypes
+import os
 
 import torch
 
@@ -18,6 +19,33 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- direct gradient sinks ---------------------------------------------------------------------------------------------
+# Inside `with grad_sinks():` the parameter-gradient kernels accumulate straight into an existing `param.grad` buffer (the
+# flat gradient buffer of FlatAdam / FlatSGD, zeroed once per step) and return None to autograd, instead of producing a
+# temporary that AccumulateGrad adds with one tiny kernel per parameter (340 of them per step).  Only valid for
+# `loss.backward()` with accumulating .grad semantics, which is why it is opt-in (the training steps opt in).
+_SINKS = [False]
+
+
+class grad_sinks(object):
+    def __init__(self, enabled=True):
+        self.enabled = enabled and os.environ.get('MSPL_GRAD_SINKS', '1') != '0'
+
+    def __enter__(self):
+        self.prev = _SINKS[0]
+        _SINKS[0] = self.enabled
+
+    def __exit__(self, *exc):
+        _SINKS[0] = self.prev
+
+
+def _sink(p):
+    if not _SINKS[0] or p is None or not p.requires_grad or not p.is_leaf:
+        return None
+    g = p.grad
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
+
+
 class ConvFn(torch.autograd.Function):
     """Bias-free grouped conv, K in {1,3} (dilation 1), stride 1|2."""
 
@@ -28,6 +56,7 @@ class ConvFn(torch.autograd.Function):
         y = ops.conv1x1(x, w, groups) if k == 1 else ops.conv3x3(x, w, groups, stride)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride if k == 3 else 1, groups, k)
+        ctx.wsink = _sink(w)
         return y
 
     @staticmethod
@@ -53,8 +82,10 @@ class ConvFn(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
-            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gw), _stream()))
+            sink = ctx.wsink
+            gw = torch.empty_like(w) if sink is None else None
+            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0 if sink is None else 1,
+                                           _p(gw if sink is None else sink), _stream()))
         return gx, gw, None, None
 
 
@@ -68,6 +99,7 @@ class EespDwFn(torch.autograd.Function):
         y = ops.eesp_dw_hff(x, w4, dil, stride)
         ctx.save_for_backward(x, w4)
         ctx.cfg = (tuple(dil), stride, w0.shape)
+        ctx.wsinks = [_sink(w) for w in (w0, w1, w2, w3)]
         return y
 
     @staticmethod
@@ -85,40 +117,60 @@ class EespDwFn(torch.autograd.Function):
             gk, wk = gs[k], w4[k]
             if gx is not None:
                 check(lib.mspl_conv_bwd_data(_p(gk), _p(wk), N, n, n, n, H, W, 3, stride, dil[k], 1 if k else 0, _p(gx), _stream()))
-            gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
-            check(lib.mspl_conv_bwd_weight(_p(gk), _p(x), N, n, n, n, H, W, 3, stride, dil[k], 0, _p(gw), _stream()))
+            sink = ctx.wsinks[k]
+            gw = torch.empty(wshape, device=x.device, dtype=torch.float32) if sink is None else None
+            check(lib.mspl_conv_bwd_weight(_p(gk), _p(x), N, n, n, n, H, W, 3, stride, dil[k], 0 if sink is None else 1,
+                                           _p(gw if sink is None else sink), _stream()))
             gws.append(gw)
         return (gx, *gws, None, None)
 
 
 class AffinePReLUFn(torch.autograd.Function):
-    """y = PReLU((c + pre_add) * scale + shift + residual); any of scale/shift/alpha/pre_add/residual may be None."""
+    """y = PReLU((c + pre_add) * scale + shift + residual); any of scale/shift/alpha/pre_add/residual may be None.
+
+    Frozen-BatchNorm form (gamma given): scale/shift are the folded, non-differentiable (gamma*inv, beta - mean*gamma*inv);
+    the backward kernel turns its per-channel sums into d gamma / d beta on the fly (mspl_bn_prelu_bwd), so no separate
+    fold/unfold kernels run per BatchNorm.  Per-channel parameter gradients go to the parameters' .grad buffers directly
+    inside `grad_sinks()`."""
 
     @staticmethod
-    def forward(ctx, c, scale, shift, alpha, pre_add, residual):
+    def forward(ctx, c, scale, shift, alpha, pre_add, residual, gamma, beta, mean, inv):
         c = _c(c)
         pre_add = None if pre_add is None else _c(pre_add)
         residual = None if residual is None else _c(residual)
         y = ops.pointwise(c, Epi(scale, shift, alpha, pre_add=pre_add, residual=residual))
-        ctx.save_for_backward(c, scale, shift, alpha, pre_add, residual)
+        ctx.save_for_backward(c, scale, shift, alpha, pre_add, residual, mean, inv)
+        ctx.bn = gamma is not None
+        ctx.sinks = (_sink(gamma if ctx.bn else scale), _sink(beta if ctx.bn else shift), _sink(alpha))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        c, scale, shift, alpha, pre_add, residual = ctx.saved_tensors
+        c, scale, shift, alpha, pre_add, residual, mean, inv = ctx.saved_tensors
         gy = _c(gy)
         N, C = c.shape[:2]
         hw = c[0, 0].numel()
         dev = c.device
         gz = torch.empty_like(c) if residual is not None else None
         gc = torch.empty_like(c)
-        gacc = torch.zeros(3, C, device=dev)            # one fill for the three per-channel accumulators
-        gsc = gacc[0] if scale is not None else None
-        gsh = gacc[1] if shift is not None else None
-        gal = gacc[2] if alpha is not None else None
-        check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
-                                        _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
-        return gc, gsc, gsh, gal, (gc if pre_add is not None else None), gz
+        s_sc, s_sh, s_al = ctx.sinks
+        gacc = torch.zeros(3, C, device=dev) if (s_sc is None or s_sh is None or s_al is None) else None
+        gsc = (s_sc if s_sc is not None else gacc[0]) if scale is not None else None
+        gsh = (s_sh if s_sh is not None else gacc[1]) if shift is not None else None
+        gal = (s_al if s_al is not None else gacc[2]) if alpha is not None else None
+        if ctx.bn:
+            check(lib.mspl_bn_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(mean), _p(inv),
+                                        N, C, hw, _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
+        else:
+            check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
+                                            _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
+        r_sc = gsc if s_sc is None else None
+        r_sh = gsh if s_sh is None else None
+        r_al = gal if s_al is None else None
+        gpre = gc if pre_add is not None else None
+        if ctx.bn:
+            return gc, None, None, r_al, gpre, gz, r_sc, r_sh, None, None
+        return gc, r_sc, r_sh, r_al, gpre, gz, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):
@@ -273,7 +325,24 @@ def eesp_dw(x, ws, dil, stride):
 
 
 def affine_prelu(c, scale=None, shift=None, alpha=None, pre_add=None, residual=None):
-    return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual)
+    return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual, None, None, None, None)
+
+
+def frozen_bn_inv(bn):
+    """rsqrt(running_var + eps), cached on the module until running_var is written (frozen statistics)."""
+    rv = bn.running_var
+    key = (rv.data_ptr(), rv._version)
+    c = bn.__dict__.get('_mspl_inv')
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, torch.rsqrt(rv + bn.eps))
+        bn.__dict__['_mspl_inv'] = c
+    return c[1]
+
+
+def bn_prelu(c, bn, scale, shift, alpha=None, pre_add=None, residual=None):
+    """PReLU(frozenBN(c + pre_add) + residual) with (scale, shift) the current no-grad fold of bn."""
+    return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual, bn.weight, bn.bias, bn.running_mean, frozen_bn_inv(bn))
 
 
 class BNFoldFn(torch.autograd.Function):
@@ -297,14 +366,7 @@ def bn_affine(bn):
     """Differentiable eval-mode BatchNorm fold: (scale, shift) as functions of gamma/beta (C-sized tensors).  The
     running statistics are frozen on this path (uest_seg_multi_os.py:605-608), so rsqrt(var+eps) is cached on the
     module and refreshed only when running_var is written."""
-    rv = bn.running_var
-    key = (rv.data_ptr(), rv._version)
-    c = bn.__dict__.get('_mspl_inv')
-    if c is None or c[0] != key:
-        with torch.no_grad():
-            c = (key, torch.rsqrt(rv + bn.eps))
-        bn.__dict__['_mspl_inv'] = c
-    return BNFoldFn.apply(bn.weight, bn.bias, bn.running_mean, c[1])
+    return BNFoldFn.apply(bn.weight, bn.bias, bn.running_mean, frozen_bn_inv(bn))
 
 
 class BNBatchStatsFn(torch.autograd.Function):

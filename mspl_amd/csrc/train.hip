@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
                                                                const float* __restrict__ alpha, int C, int HW, int chunks,
                                                                float* __restrict__ gz_out, float* __restrict__ gc_out,
                                                                float* __restrict__ gscale, float* __restrict__ gshift,
-                                                               float* __restrict__ galpha) {
+                                                               float* __restrict__ galpha, const float* __restrict__ bn_mean,
+                                                               const float* __restrict__ bn_inv) {
     int b = blockIdx.x;
     const int chunk = b % chunks;  b /= chunks;
     const int ch = b % C;
@@ -265,8 +266,12 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (gscale) atomicAdd(&gscale[ch], (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
-        if (gshift) atomicAdd(&gshift[ch], (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
+        const float t_scale = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        const float t_shift = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+        // frozen BatchNorm folded into (scale, shift) = (gamma*inv, beta - mean*gamma*inv): the map from (dscale, dshift) to
+        // (dgamma, dbeta) is linear, so every workgroup's partial goes straight to the parameters' gradient buffers
+        if (gscale) atomicAdd(&gscale[ch], bn_inv ? (t_scale - bn_mean[ch] * t_shift) * bn_inv[ch] : t_scale);
+        if (gshift) atomicAdd(&gshift[ch], t_shift);
         if (galpha && act) atomicAdd(&galpha[ch], (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]));
     }
 }
@@ -553,10 +558,10 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
     return MSPL_OK;
 }
 
-extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy,
-                                     const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
-                                     int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,
-                                     void* stream) {
+static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const float* residual, const float* gy,
+                                   const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
+                                   int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,
+                                   const float* bn_mean, const float* bn_inv, void* stream) {
     MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
     int chunks = 1;
@@ -564,9 +569,26 @@ extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const
     const int64_t blocks = (int64_t)N * C * chunks;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: grid too large");
     hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, pre_add, residual, gy,
-                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha);
+                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha, bn_mean, bn_inv);
     MSPL_CHECK_LAUNCH("affine_prelu_bwd");
     return MSPL_OK;
+}
+
+extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy,
+                                     const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
+                                     int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,
+                                     void* stream) {
+    return affine_prelu_bwd_launch(c, pre_add, residual, gy, scale, shift, alpha, N, C, HW, gz, gc, gscale, gshift, galpha, nullptr,
+                                   nullptr, stream);
+}
+
+extern "C" int mspl_bn_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy, const float* scale,
+                                 const float* shift, const float* alpha, const float* bn_mean, const float* bn_inv, int32_t N,
+                                 int32_t C, int32_t HW, float* gz, float* gc, float* ggamma, float* gbeta, float* galpha,
+                                 void* stream) {
+    MSPL_REQUIRE(scale && shift && bn_mean && bn_inv, MSPL_ERR_NULL_POINTER, "bn_prelu_bwd: null pointer");
+    return affine_prelu_bwd_launch(c, pre_add, residual, gy, scale, shift, alpha, N, C, HW, gz, gc, ggamma, gbeta, galpha, bn_mean,
+                                   bn_inv, stream);
 }
 
 static int rs_geom(const char* who, const float* gy, float* gx, int N, int C, int Hi, int Wi, int Ho, int Wo, RsG& g) {

@@ -168,8 +168,33 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
             z, pre_add = z + pre_add, None
         scale, shift = ag.bn_batch_stats(z, bn)
     else:
-        scale, shift = ag.bn_affine(bn)
+        scale, shift = train_fold(bn)
+        return ag.bn_prelu(z, bn, scale, shift, alpha, pre_add=pre_add, residual=residual)
     return ag.affine_prelu(z, scale, shift, alpha, pre_add=pre_add, residual=residual)
+
+
+def train_fold(bn):
+    """No-grad (scale, shift) of a frozen BatchNorm for the training forward, cached until a parameter changes (every
+    optimizer step); prefold_frozen_bn() fills the caches of a whole model with two multi-tensor launches."""
+    def build():
+        scale = bn.weight * ag.frozen_bn_inv(bn)
+        return scale, torch.addcmul(bn.bias, bn.running_mean, scale, value=-1.0)
+    return cached(bn, 'tfold', [bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+
+def prefold_frozen_bn(model):
+    """Fold every eval-mode BatchNorm2d of `model` at once (torch._foreach: a handful of launches instead of two per
+    module) and store the results where train_fold() looks."""
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d) and not m.training]
+    if not bns:
+        return
+    with torch.no_grad():
+        invs = [ag.frozen_bn_inv(m) for m in bns]
+        scales = torch._foreach_mul([m.weight for m in bns], invs)
+        shifts = torch._foreach_addcmul([m.bias for m in bns], [m.running_mean for m in bns], scales, value=-1.0)
+    for m, sc, sh in zip(bns, scales, shifts):
+        store = m.__dict__.setdefault('_mspl_cache', {})
+        store['tfold'] = (_key([m.weight, m.bias, m.running_mean, m.running_var]), (sc, sh))
 
 
 def _conv_fwd(x, conv, ep, out=None, shuffle_groups=0):

@@ -16,6 +16,7 @@ after group, so a step is one kernel per group and the multi-GPU exchange one al
 """
 import torch
 
+from . import autograd as ag
 from . import dist as mdist
 from . import layers
 from ._native import check, lib
@@ -116,7 +117,8 @@ def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=No
     optimizer=None on the first call: it is built after the first backward from segmentation_param_groups."""
     if optimizer is not None:
         optimizer.zero_grad()
-    with torch.enable_grad():
+    with torch.enable_grad(), ag.grad_sinks():
+        layers.prefold_frozen_bn(model)
         out = model(inputs, depth) if depth is not None else model(inputs)
         outputs = out[0] + 0.5 * out[1]
         loss = criterion(outputs, target).mean()

@@ -110,7 +110,8 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
     after the first backward (which reveals the gradient-bearing parameters)."""
     if optimizer is not None:
         optimizer.zero_grad()
-    with torch.enable_grad():
+    with torch.enable_grad(), ag.grad_sinks():
+        layers.prefold_frozen_bn(model)
         pred, aux = model(images)
         loss = uest_loss(pred, aux, labels, class_weights, ignore_idx, ce_scale)
         loss.backward()
@@ -141,7 +142,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.optimizer.zero_grad()
-            with torch.enable_grad():
+            with torch.enable_grad(), ag.grad_sinks():
+                layers.prefold_frozen_bn(model)
                 pred, aux = model(self.images)
                 self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)
                 self.loss.backward()

@@ -200,6 +200,32 @@ def test_graphed_train_step_equals_eager():
         np.testing.assert_allclose(q.cpu().numpy(), p.cpu().numpy(), rtol=0, atol=5e-5, err_msg=k)
 
 
+def test_direct_gradient_sinks_equal_autograd_accumulation(monkeypatch):
+    """Steps 2-3 with the parameter-gradient kernels writing straight into the flat gradient buffer (grad_sinks, the default
+    of train_step) against the same steps with autograd's own AccumulateGrad (MSPL_GRAD_SINKS=0)."""
+    from mspl_amd import models, training
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    x = synth_input((2, 3, 32, 48), 18).to(DEV)
+    y = synth_labels((2, 32, 48), 5, 18).to(DEV)
+    cw = torch.ones(5)
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('MSPL_GRAD_SINKS', flag)
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(KEYS['espdnetue_s2.0_c5'], 4))
+        m = m.to(DEV).eval()
+        opt, losses = None, []
+        for _ in range(3):
+            l, opt = training.train_step(m, x, y, cw, opt, ignore_idx=4)
+            losses.append(float(l))
+        outs.append((losses, opt.flat_g.clone(), {k: v.clone() for k, v in m.state_dict().items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    g1, g0 = outs[0][1], outs[1][1]
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-7
+    for k in outs[0][2]:
+        np.testing.assert_allclose(outs[0][2][k].cpu().numpy(), outs[1][2][k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
+
+
 def _ref_losses():
     """Torch-CPU statements of the three loss modules (loss_fns/segmentation_loss.py:11-52,146-189)."""
     import torch.nn.functional as F
