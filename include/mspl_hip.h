@@ -329,6 +329,13 @@ int mspl_nid_hist_fwd(const float* camera, const float* label, int32_t B, int32_
 int mspl_nid_hist_bwd(const float* camera, const float* label, int32_t B, int32_t C, int32_t H, int32_t W, int32_t K,
                       float bw_camera, float bw_label, const float* gjoint, const float* gpl, float* glabel, void* stream);
 
+/* Backward of mspl_eesp_dw_hff_fwd (K2) in two launches.  gs: the suffix-summed output gradient from mspl_hff_suffix_sum,
+ * branch-major (4,N,n,Ho,Wo); x: the forward input (N,n,H,W); w4: (4,n,3,3); dil: 4 dilations; stride 1|2.
+ * gx (N,n,H,W): overwritten, NULL = skip.  gw: 4 device pointers to (n,3,3) buffers that are ACCUMULATED into (zeroed by
+ * the caller, or the parameters' own gradient buffers), NULL = skip. */
+int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4, const int32_t* dil, int32_t stride, int32_t N,
+                     int32_t n, int32_t H, int32_t W, float* gx, float* const* gw, void* stream);
+
 /* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
 int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);

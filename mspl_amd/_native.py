@@ -79,6 +79,8 @@ SIGNATURES = {
     'mspl_nid_workspace_floats': [c_i32, c_i32, c_i32, c_i32],
     'mspl_nid_hist_fwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_nid_hist_bwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_eesp_dw_bwd': [c_f32p, c_f32p, c_f32p, ctypes.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p,
+                         ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],

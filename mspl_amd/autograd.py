@@ -112,16 +112,14 @@ class EespDwFn(torch.autograd.Function):
         gs = torch.empty((4, N, n, Ho, Wo), device=x.device, dtype=torch.float32)
         check(lib.mspl_hff_suffix_sum(_p(gy), N, n, Ho * Wo, _p(gs), _stream()))
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gws = []
-        for k in range(4):
-            gk, wk = gs[k], w4[k]
-            if gx is not None:
-                check(lib.mspl_conv_bwd_data(_p(gk), _p(wk), N, n, n, n, H, W, 3, stride, dil[k], 1 if k else 0, _p(gx), _stream()))
-            sink = ctx.wsinks[k]
-            gw = torch.empty(wshape, device=x.device, dtype=torch.float32) if sink is None else None
-            check(lib.mspl_conv_bwd_weight(_p(gk), _p(x), N, n, n, n, H, W, 3, stride, dil[k], 0 if sink is None else 1,
-                                           _p(gw if sink is None else sink), _stream()))
-            gws.append(gw)
+        # all four branches in one data-gradient launch and one weight-gradient launch (eesp_dw_bwd.hip)
+        sinks = ctx.wsinks
+        tmp = torch.zeros((4,) + tuple(wshape), device=x.device, dtype=torch.float32) if any(s_ is None for s_ in sinks) else None
+        dst = [sinks[k] if sinks[k] is not None else tmp[k] for k in range(4)]
+        ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dst])
+        dil_c = (ctypes.c_int32 * 4)(*dil)
+        check(lib.mspl_eesp_dw_bwd(_p(gs), _p(x), _p(w4), dil_c, stride, N, n, H, W, _p(gx), ptrs, _stream()))
+        gws = [None if sinks[k] is not None else tmp[k] for k in range(4)]
         return (gx, *gws, None, None)
 
 
