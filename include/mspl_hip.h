@@ -214,8 +214,8 @@ int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* res
 
 /* Backward of mspl_avgpool3x3s2_fwd (gather form, gx overwritten). */
 int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int32_t H, int32_t W, float* gx, void* stream);
-/* Backward of mspl_bilinear_fwd (gather form, gx overwritten) and of mspl_adaptive_avgpool_fwd (atomic scatter: the
- * caller zero-fills gx). */
+/* Backward of mspl_bilinear_fwd and of mspl_adaptive_avgpool_fwd (both gather form: one thread per input pixel,
+ * deterministic, gx overwritten). */
 int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                       float* gx, void* stream);
 int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,

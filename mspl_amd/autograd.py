@@ -208,7 +208,7 @@ class AdaptivePoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         N, C, H, W = ctx.shape
-        gx = torch.zeros(ctx.shape, device=gy.device, dtype=torch.float32)
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
         check(lib.mspl_adaptive_avgpool_bwd(_p(_c(gy)), N, C, H, W, gy.shape[2], gy.shape[3], _p(gx), _stream()))
         return gx, None
 

@@ -310,6 +310,36 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
     if (g.sw > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)ceilf((float)(ix + 1) / g.sw) + 1); }
     float acc = 0.f;
+    constexpr int MAXC = 12;
+    const int nx = xhi - xlo + 1;
+    if (nx <= MAXC) {
+        // the column weights do not depend on the row: evaluate them once (x2 / x4 up-sampling: 7 / 11 candidates, at most 4
+        // of them non-zero), then each candidate row costs one weight evaluation and the loads of the non-zero columns only
+        float wxs[MAXC];
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            wxs[j] = 0.f;
+            if (j < nx) {
+                int x0, x1;  float wx0, wx1;
+                bilinear_src(g.sw, xlo + j, g.Wi, x0, x1, wx0, wx1);
+                wxs[j] = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+            }
+        }
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1;  float wy0, wy1;
+            bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+            const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            if (wy == 0.f) continue;
+            const float* row = gp + (size_t)oy * g.Wo + xlo;
+            float rowacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j)
+                if (wxs[j] != 0.f) rowacc = fmaf(wxs[j], row[j], rowacc);
+            acc = fmaf(wy, rowacc, acc);
+        }
+        gx[idx] = acc;
+        return;
+    }
     for (int oy = ylo; oy <= yhi; ++oy) {
         int y0, y1;  float wy0, wy1;
         bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
@@ -327,17 +357,28 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     gx[idx] = acc;
 }
 
+// Gather form (deterministic, no atomics, no zero fill): one thread per INPUT pixel; the outputs whose window
+// [floor(o*I/O), ceil((o+1)*I/O)) contains it are o in [floor(i*O/I), ceil((i+1)*O/I) - 1] (1-2 per axis when pooling down,
+// 2-3 when the "pool" enlarges the map, the 2.0 / 1.5 pyramid scales).
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int ox = (int)(idx % g.Wo);  int64_t t = idx / g.Wo;
-    const int oy = (int)(t % g.Ho);  t /= g.Ho;
-    const int ys = (int)(((int64_t)oy * g.Hi) / g.Ho), ye = (int)((((int64_t)oy + 1) * g.Hi + g.Ho - 1) / g.Ho);
-    const int xs = (int)(((int64_t)ox * g.Wi) / g.Wo), xe = (int)((((int64_t)ox + 1) * g.Wi + g.Wo - 1) / g.Wo);
-    const float v = gy[idx] / (float)((ye - ys) * (xe - xs));
-    float* gp = gx + (size_t)t * g.Hi * g.Wi;
-    for (int iy = ys; iy < ye; ++iy)
-        for (int ix = xs; ix < xe; ++ix) atomicAdd(&gp[(size_t)iy * g.Wi + ix], v);
+    const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.N * g.C || pi >= g.Hi * g.Wi) return;
+    const int iy = pi / g.Wi, ix = pi - iy * g.Wi;
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    const int oy0 = (int)(((int64_t)iy * g.Ho) / g.Hi), oy1 = min(g.Ho - 1, (int)((((int64_t)iy + 1) * g.Ho + g.Hi - 1) / g.Hi) - 1);
+    const int ox0 = (int)(((int64_t)ix * g.Wo) / g.Wi), ox1 = min(g.Wo - 1, (int)((((int64_t)ix + 1) * g.Wo + g.Wi - 1) / g.Wi) - 1);
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const int ys = (int)(((int64_t)oy * g.Hi) / g.Ho), ye = (int)((((int64_t)oy + 1) * g.Hi + g.Ho - 1) / g.Ho);
+        if (iy < ys || iy >= ye) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int xs = (int)(((int64_t)ox * g.Wi) / g.Wo), xe = (int)((((int64_t)ox + 1) * g.Wi + g.Wo - 1) / g.Wo);
+            if (ix < xs || ix >= xe) continue;
+            acc += gp[(size_t)oy * g.Wo + ox] / (float)((ye - ys) * (xe - xs));
+        }
+    }
+    gx[(size_t)t * g.Hi * g.Wi + pi] = acc;
 }
 
 // ---- per-plane dot product: out[n*C + c] = sum_p a[n,c,p] * b[n,c,p]   (gate gradient; b == nullptr: plain sum)
@@ -621,13 +662,15 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
     return MSPL_OK;
 }
 
-/* gx must be zero-filled by the caller (atomic scatter). */
+/* Gather form: gx is overwritten. */
 extern "C" int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                                          float* gx, void* stream) {
     RsG g;
     if (int rc = rs_geom("adaptive_avgpool_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
-    const int64_t total = (int64_t)N * C * Ho * Wo;
-    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    const int64_t total = (int64_t)N * C * Hi * Wi;
+    const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)),
+                       dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("adaptive_avgpool_bwd");
     return MSPL_OK;
 }

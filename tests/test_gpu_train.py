@@ -89,6 +89,14 @@ def test_resample_fns():
     check_op(lambda a: ag.bilinear(a, (7, 9)), lambda a: F.interpolate(a, (7, 9), mode='bilinear', align_corners=True), [x])
     check_op(lambda a: ag.adaptive_avgpool(a, (5, 5)), lambda a: F.adaptive_avg_pool2d(a, (5, 5)), [x])
     check_op(lambda a: ag.adaptive_avgpool(a, (10, 14)), lambda a: F.adaptive_avg_pool2d(a, (10, 14)), [x])
+    # the pyramid's enlarging "pools" (scales 2.0 / 1.5), the x4 logits up-sampling and the x10 up-sampling of the 0.1 branch
+    check_op(lambda a: ag.adaptive_avgpool(a, (30, 42)), lambda a: F.adaptive_avg_pool2d(a, (30, 42)), [x])
+    check_op(lambda a: ag.adaptive_avgpool(a, (22, 31)), lambda a: F.adaptive_avg_pool2d(a, (22, 31)), [x])
+    check_op(lambda a: ag.adaptive_avgpool(a, (1, 1)), lambda a: F.adaptive_avg_pool2d(a, (1, 1)), [x])
+    check_op(lambda a: ag.bilinear(a, (60, 84)), lambda a: F.interpolate(a, (60, 84), mode='bilinear', align_corners=True), [x])
+    y = rnd(1, 2, 5, 6, seed=2)
+    check_op(lambda a: ag.bilinear(a, (64, 120)), lambda a: F.interpolate(a, (64, 120), mode='bilinear', align_corners=True), [y])
+    check_op(lambda a: ag.bilinear(a, (5, 6)), lambda a: F.interpolate(a, (5, 6), mode='bilinear', align_corners=True), [y])
 
 
 def test_gate_fns():
