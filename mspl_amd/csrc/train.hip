@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
             const float* row = gp + (size_t)oy * g.Wo + xlo;
             float rowacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < MAXC; ++j)
-                if (wxs[j] != 0.f) rowacc = fmaf(wxs[j], row[j], rowacc);
+            for (int j = 0; j < MAXC; ++j)                       // unconditional clamped loads: the row's reads issue as one batch
+                if (j < nx) rowacc = fmaf(wxs[j], row[j], rowacc);
             acc = fmaf(wy, rowacc, acc);
         }
         gx[idx] = acc;
@@ -357,6 +357,45 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     gx[idx] = acc;
 }
 
+// Large up-sampling ratios (the pyramid's 0.1 branch: 7x12 -> 64x120, 24x24 candidate outputs per input pixel, and only a
+// few hundred input pixels per plane): one WAVE per input pixel, lanes over the candidate columns, rows walked together.
+__global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total_in) {
+    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= total_in) return;                                  // wave-uniform
+    const int hw = g.Hi * g.Wi;
+    const int64_t t = w / hw;
+    const int pi = (int)(w - t * hw);
+    const int iy = pi / g.Wi, ix = pi - iy * g.Wi;
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    int ylo = 0, yhi = g.Ho - 1, xlo = 0, xhi = g.Wo - 1;
+    if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
+    if (g.sw > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)ceilf((float)(ix + 1) / g.sw) + 1); }
+    float acc = 0.f;
+    for (int xb = xlo; xb <= xhi; xb += 64) {
+        const int ox = xb + lane;
+        float wx = 0.f;
+        if (ox <= xhi) {
+            int x0, x1;  float wx0, wx1;
+            bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
+            wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+        }
+        const int oxc = min(ox, xhi);
+        float col = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1;  float wy0, wy1;
+            bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+            const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            if (wy == 0.f) continue;                            // wave-uniform
+            col = fmaf(wy, gp[(size_t)oy * g.Wo + oxc], col);
+        }
+        acc = fmaf(wx, col, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) gx[w] = acc;
+}
+
 // Gather form (deterministic, no atomics, no zero fill): one thread per INPUT pixel; the outputs whose window
 // [floor(o*I/O), ceil((o+1)*I/O)) contains it are o in [floor(i*O/I), ceil((i+1)*O/I) - 1] (1-2 per axis when pooling down,
 // 2-3 when the "pool" enlarges the map, the 2.0 / 1.5 pyramid scales).
@@ -366,14 +405,16 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* 
     if (t >= g.N * g.C || pi >= g.Hi * g.Wi) return;
     const int iy = pi / g.Wi, ix = pi - iy * g.Wi;
     const float* gp = gy + (size_t)t * g.Ho * g.Wo;
-    const int oy0 = (int)(((int64_t)iy * g.Ho) / g.Hi), oy1 = min(g.Ho - 1, (int)((((int64_t)iy + 1) * g.Ho + g.Hi - 1) / g.Hi) - 1);
-    const int ox0 = (int)(((int64_t)ix * g.Wo) / g.Wi), ox1 = min(g.Wo - 1, (int)((((int64_t)ix + 1) * g.Wo + g.Wi - 1) / g.Wi) - 1);
+    // 32-bit unsigned arithmetic (the launcher checks Hi*Ho, Wi*Wo < 2^31): 64-bit divisions cost ~100 instructions each
+    const unsigned Hi = g.Hi, Wi = g.Wi, Ho = g.Ho, Wo = g.Wo, uy = iy, ux = ix;
+    const int oy0 = (int)(uy * Ho / Hi), oy1 = min(g.Ho - 1, (int)(((uy + 1) * Ho + Hi - 1) / Hi) - 1);
+    const int ox0 = (int)(ux * Wo / Wi), ox1 = min(g.Wo - 1, (int)(((ux + 1) * Wo + Wi - 1) / Wi) - 1);
     float acc = 0.f;
     for (int oy = oy0; oy <= oy1; ++oy) {
-        const int ys = (int)(((int64_t)oy * g.Hi) / g.Ho), ye = (int)((((int64_t)oy + 1) * g.Hi + g.Ho - 1) / g.Ho);
+        const int ys = (int)((unsigned)oy * Hi / Ho), ye = (int)((((unsigned)oy + 1) * Hi + Ho - 1) / Ho);
         if (iy < ys || iy >= ye) continue;
         for (int ox = ox0; ox <= ox1; ++ox) {
-            const int xs = (int)(((int64_t)ox * g.Wi) / g.Wo), xe = (int)((((int64_t)ox + 1) * g.Wi + g.Wo - 1) / g.Wo);
+            const int xs = (int)((unsigned)ox * Wi / Wo), xe = (int)((((unsigned)ox + 1) * Wi + Wo - 1) / Wo);
             if (ix < xs || ix >= xe) continue;
             acc += gp[(size_t)oy * g.Wo + ox] / (float)((ye - ys) * (xe - xs));
         }
@@ -655,6 +696,14 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
     RsG g;
     if (int rc = rs_geom("bilinear_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
     const int64_t total = (int64_t)N * C * Hi * Wi;
+    // candidate window per input pixel is 2/scale + 3 wide: beyond 12 columns a wave per input pixel is the better shape
+    const bool wide = g.sw <= 0.f || 2.0f / g.sw + 3.0f > 12.0f;
+    if (wide && total * 64 < (1ll << 31) * 256ll) {
+        hipLaunchKernelGGL(bilinear_bwd_wave_kernel, dim3((unsigned)ceil_div64(total * 64, 256)), dim3(256), 0, (hipStream_t)stream, gy, g,
+                           gx, total);
+        MSPL_CHECK_LAUNCH("bilinear_bwd(wave)");
+        return MSPL_OK;
+    }
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)), dim3(256), 0,
                        (hipStream_t)stream, gy, g, gx, total);
@@ -667,6 +716,8 @@ extern "C" int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, 
                                          float* gx, void* stream) {
     RsG g;
     if (int rc = rs_geom("adaptive_avgpool_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
+    MSPL_REQUIRE((int64_t)(Hi + 1) * Ho < (1ll << 31) && (int64_t)(Wi + 1) * Wo < (1ll << 31), MSPL_ERR_BAD_SHAPE,
+                 "adaptive_avgpool_bwd: map too large for 32-bit window arithmetic");
     const int64_t total = (int64_t)N * C * Hi * Wi;
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
     hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)),
