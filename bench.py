@@ -204,6 +204,36 @@ def train_step_rate(dev, iters=10):
             'loss_finite': bool(torch.isfinite(loss))}
 
 
+def supervised_step_rate(dev, iters=6):
+    """one train_seg_ue iteration of the supervised source-model loop (model.train(): batch-statistics BatchNorm,
+    CrossEntropy on main + 0.5*aux, flooding, SGD with two learning-rate groups), ESPDNet-UE C=13, bs=16 at 288x480 (the
+    CamVid crop of train_espdnetue_camvid.sh), eager launches.  Extra field."""
+    import torch
+    from mspl_amd import losses, models, supervised
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 10))
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((BATCH, 3, 288, 480), generator=g).to(dev)
+    y = torch.randint(0, 13, (BATCH, 288, 480), generator=g).to(dev)
+    crit = losses.SegmentationLoss(n_classes=13, device=dev, ignore_idx=255)
+    loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit)
+    for _ in range(2):
+        loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit, opt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
+            'workload': 'train_seg_ue iteration, ESPDNet-UE s=2.0 C=13 in train() (batch-statistics BN), bs=16 x 3 x 288 x 480 fp32, '
+                        'CrossEntropy + flooding + SGD(2 lr groups), eager',
+            'loss_finite': bool(torch.isfinite(loss))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -379,6 +409,7 @@ def main():
         }
         if world == 1 and not args.no_train:
             out['train_step'] = train_step_rate(dev)
+            out['supervised_step'] = supervised_step_rate(dev)
         if world == 1 and not args.no_aspp:
             out['aspp_head'] = aspp_head_rate(dev)
         if world == 1 and not args.no_io:
