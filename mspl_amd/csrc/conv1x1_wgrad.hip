@@ -1,0 +1,102 @@
+// Weight gradient of the grouped 1x1 convolutions (K1 / K3 / decoder projections) on the matrix cores:
+//     gw[g, m, k] += sum_{n,p} gy[n, g*M + m, p] * x[n, g*K + k, p]            (an "NT" GEMM whose reduction runs over pixels)
+// One wave owns one 32x32 tile of gw for one slice of the (image, pixel) range.  v_mfma_f32_32x32x2_f32 takes A[row][k] from
+// lane (row, k = lane>>5) and B[k][col] from lane (col, k = lane>>5): with lane (r, h) loading the 16 bytes at pixel
+// p0 + 4h of row r of BOTH operands, element j of the two float4 is a valid (A, B) pair for one MFMA -- no LDS, no transposes,
+// eight pixels per iteration, every byte loaded is used.  Partial tiles are combined with float atomics (gw zeroed by the
+// launcher, or the parameter's gradient buffer when accumulating).
+#include "common.hpp"
+
+namespace mspl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgG {
+    int N, G, M, K, P;          // images, groups, cout_g, cin_g, pixels per plane
+    int tm, tk;                 // 32-tiles along M and K
+    int nslots, reps;           // waves per (tile, image) (multiple of 4: one workgroup = 4 slots of one tile), 64-pixel groups per wave
+};
+
+// One wave: `reps` groups of 64 pixels.  All 16 float4 of a group (8 per operand) are requested before the first MFMA, so a
+// wave exposes ONE memory latency per 32 MFMAs (the first version waited on memory every 8 MFMAs and ran at the speed of
+// the load latency).  The four waves of a workgroup hold four slices of the same tile: they are summed through LDS and
+// leave with one atomic per tile element.
+__global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
+                                                                 float* __restrict__ gw) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int bslots = g.nslots >> 2;                                   // workgroups per (tile, image)
+    const int64_t bid = blockIdx.x;
+    const int64_t tn = bid / bslots;                                    // (tile, image)
+    const int slot = (int)(bid - tn * bslots) * 4 + wave;
+    const int64_t tile = tn / g.N;
+    const int n = (int)(tn - tile * g.N);
+    const int grp = (int)(tile / (g.tm * g.tk));
+    const int tt = (int)(tile - (int64_t)grp * g.tm * g.tk);
+    const int m0 = (tt / g.tk) * 32, k0 = (tt % g.tk) * 32;
+    const bool am = m0 + r < g.M, bk = k0 + r < g.K;
+    // rows outside the tile read row 0 of the tile (always valid); their products land in elements that are never stored
+    const float* ap = gy + ((size_t)n * g.G * g.M + (size_t)grp * g.M + m0 + (am ? r : 0)) * (size_t)g.P;
+    const float* bp = x + ((size_t)n * g.G * g.K + (size_t)grp * g.K + k0 + (bk ? r : 0)) * (size_t)g.P;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rep = 0; rep < g.reps; ++rep) {
+        const int p0 = (slot + rep * g.nslots) * 64;
+        if (p0 >= g.P) break;                                           // wave-uniform
+        float4 a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pc = min(p0 + 8 * i + 4 * h, g.P - 4);            // clamped, unconditional: P % 4 == 0, so a float4 is
+            a[i] = *reinterpret_cast<const float4*>(ap + pc);           // entirely inside or outside the plane
+            b[i] = *reinterpret_cast<const float4*>(bp + pc);
+        }
+        // all sixteen requests leave before anything consumes them (hipcc otherwise sinks each load to its first use and the
+        // loop degenerates into load -> wait -> mfma)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // rows / columns outside the tile are discarded at the store; only pixels past the plane must contribute zero
+            if (p0 + 8 * i + 4 * h >= g.P) { a[i] = zero; b[i] = zero; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    // 1024 tile elements, 4 per thread.  Element (i, l): row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), column = l & 31
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int i = e >> 6, l = e & 63;
+        const float v = (red[0][i][l] + red[1][i][l]) + (red[2][i][l] + red[3][i][l]);
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), col = l & 31;
+        if (m0 + row < g.M && k0 + col < g.K) atomicAdd(gw + ((size_t)grp * g.M + m0 + row) * g.K + k0 + col, v);
+    }
+}
+
+// Called by mspl_conv_bwd_weight for K == 1 (gw already zeroed unless accumulating).  Returns 1 when the shape is left to the
+// 16x16 LDS kernel (tiny groups such as the 3-channel image reinforcement, planes that are not a multiple of 4 pixels).
+int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M, int K, int P, float* gw, hipStream_t s) {
+    if (M < 8 || K < 8 || (P & 3) != 0) return 1;
+    WgG g;
+    g.N = N; g.G = G; g.M = M; g.K = K; g.P = P;
+    g.tm = ceil_div(M, 32); g.tk = ceil_div(K, 32);
+    const int64_t tiles = (int64_t)G * g.tm * g.tk;
+    const int groups = ceil_div(P, 64);
+    // ~16k waves at most: more 64-pixel groups per wave when the plane is large
+    int reps = 1;
+    while (tiles * N * ceil_div(groups, reps) > 16384 && reps < groups) reps *= 2;
+    g.reps = reps;
+    g.nslots = (ceil_div(groups, reps) + 3) & ~3;
+    const int64_t blocks = tiles * N * (g.nslots >> 2);
+    if (blocks >= (1ll << 31)) return 1;
+    hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, gw);
+    return 0;
+}
+
+}  // namespace mspl

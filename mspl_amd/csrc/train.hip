@@ -5,9 +5,13 @@
 // Round-1 form: generic, direct and correct (gather-style data gradients, block-reduced weight gradients,
 // atomic scatter for the resampling ops).  They are native HIP behind the same C ABI; the specialised MFMA /
 // LDS-tiled versions of the hot ones (1x1 wgrad/dgrad, depthwise dilated dgrad) are the next optimisation step.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
+
+int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M, int K, int P, float* gw, hipStream_t s);
 
 struct ConvGeom {
     int N, Cin, Cout, G, cin_g, cout_g, H, W, Ho, Wo, K, stride, dil, pad;
@@ -605,7 +609,13 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_REQUIRE(e == hipSuccess, MSPL_ERR_HIP, "conv_bwd_weight: memset failed: %s", hipGetErrorString(e));
     }
     const int64_t total = (int64_t)N * g.Ho * g.Wo;
-    if (K == 1) {       // (the 16x16 tile is zero padded for groups with fewer channels, e.g. the 3-channel image reinforcement)
+    if (K == 1) {
+        static const bool no_mfma = getenv("MSPL_WGRAD_LDS") != nullptr;      // A/B aid: force the 16x16 LDS kernel
+        if (!no_mfma && conv1x1_wgrad_mfma_try(gy, x, N, groups, g.cout_g, g.cin_g, g.Ho * g.Wo, gw, s) == 0) {
+            MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1, mfma)");
+            return MSPL_OK;
+        }
+        // (the 16x16 tile is zero padded for groups with fewer channels, e.g. the 3-channel image reinforcement)
         const int tiles_m = ceil_div(g.cout_g, 16), tiles_k = ceil_div(g.cin_g, 16);
         int64_t base = (int64_t)groups * tiles_m * tiles_k;
         int chunks = 1;

@@ -46,7 +46,10 @@ def check_op(gpu_fn, cpu_fn, tensors, atol=2e-4, rtol=2e-3):
 
 
 @pytest.mark.parametrize('cfg', [(2, 32, 24, 4, 9, 13, 1, 1), (1, 64, 64, 4, 6, 10, 1, 1), (2, 3, 8, 1, 12, 16, 3, 2),
-                                 (1, 16, 16, 16, 11, 9, 3, 1), (1, 20, 4, 4, 7, 7, 3, 1), (1, 24, 12, 4, 8, 8, 3, 2)])
+                                 (1, 16, 16, 16, 11, 9, 3, 1), (1, 20, 4, 4, 7, 7, 3, 1), (1, 24, 12, 4, 8, 8, 3, 2),
+                                 # 1x1 weight gradient on the matrix cores: several 32-tiles, partial tiles, pixel tails, slices
+                                 (2, 128, 96, 1, 8, 12, 1, 1), (3, 512, 512, 4, 18, 30, 1, 1), (2, 48, 40, 1, 6, 10, 1, 1),
+                                 (1, 64, 256, 2, 36, 60, 1, 1)])
 def test_conv_fn(cfg):
     from mspl_amd import autograd as ag
     N, ci, co, g, h, w, k, s = cfg
