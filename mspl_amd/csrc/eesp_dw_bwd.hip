@@ -71,10 +71,14 @@ __global__ __launch_bounds__(256) void eesp_dw_bwd_weight_kernel(const float* __
         const int oy = p / g.Wo, ox = p - oy * g.Wo;
         const float* gp = gs + ((size_t)img * g.n + c) * npix + p;
         const float* xp = x + ((size_t)img * g.n + c) * plane;
+        // all 40 reads of this position are requested before the first use (clamped, unconditional; hipcc otherwise issues
+        // load -> wait -> fma per tap and the loop runs at one memory latency per tap)
+        float gv[4], xv[36];
+        bool ok[36];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int d = g.dil[k];
-            const float gv = gp[(size_t)k * branch];
+            gv[k] = gp[(size_t)k * branch];
             const int by = oy * g.stride - d, bx = ox * g.stride - d;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -84,11 +88,14 @@ __global__ __launch_bounds__(256) void eesp_dw_bwd_weight_kernel(const float* __
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = bx + kx * d;
-                    const float xv = xp[(size_t)iyc * g.W + min(max(ix, 0), g.W - 1)];
-                    acc[k * 9 + ky * 3 + kx] = fmaf((oky && ix >= 0 && ix < g.W) ? gv : 0.f, xv, acc[k * 9 + ky * 3 + kx]);
+                    xv[k * 9 + ky * 3 + kx] = xp[(size_t)iyc * g.W + min(max(ix, 0), g.W - 1)];
+                    ok[k * 9 + ky * 3 + kx] = oky && ix >= 0 && ix < g.W;
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 36; ++t) acc[t] = fmaf(ok[t] ? gv[t / 9] : 0.f, xv[t], acc[t]);
     }
     __shared__ float part[4][36];
 #pragma unroll

@@ -119,10 +119,17 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_kernel(const float* __res
                 msk[ky * 3 + kx] = (oky && ix >= 0 && ix < g.W) ? gv : 0.f;
             }
         }
+        // request every tap of this position before the first use (hipcc otherwise emits load -> wait -> fma per tap)
+        float xv[CG * 9];
 #pragma unroll
         for (int ci = 0; ci < CG; ++ci)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[ci * 9 + t] = fmaf(msk[t], xp[ci * plane + offs[t]], acc[ci * 9 + t]);
+            for (int t = 0; t < 9; ++t) xv[ci * 9 + t] = xp[ci * plane + offs[t]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[ci * 9 + t] = fmaf(msk[t], xv[ci * 9 + t], acc[ci * 9 + t]);
     }
     __shared__ float part[4][CG * 9];
 #pragma unroll
