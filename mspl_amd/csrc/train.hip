@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __re
 // Gather form (deterministic, no atomics): one thread per INPUT pixel, loops over the output rows/columns whose
 // two bilinear sources include it.  Output y uses source rows floor(y*sh) and +1, so the candidates for input row iy
 // are y in [ceil((iy-1)/sh), floor((iy+1)/sh)] (clamped); same along x.
+template <int MAXC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
     const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
     const int pi = blockIdx.x * 256 + threadIdx.x;
@@ -318,10 +319,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     const int64_t idx = (int64_t)t * g.Hi * g.Wi + pi;
     const float* gp = gy + (size_t)t * g.Ho * g.Wo;
     int ylo = 0, yhi = g.Ho - 1, xlo = 0, xhi = g.Wo - 1;
-    if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
-    if (g.sw > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)ceilf((float)(ix + 1) / g.sw) + 1); }
+    // outputs whose source floor(o*s) is i-1 or i lie in [ceil((i-1)/s), ceil((i+1)/s) - 1]; one extra on each side covers the
+    // float rounding of o*s in the forward (the weights below are evaluated exactly as the forward does, so extras get 0)
+    if (g.sh > 0.f) { ylo = max(0, (int)ceilf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)floorf((float)(iy + 1) / g.sh) + 1); }
+    if (g.sw > 0.f) { xlo = max(0, (int)ceilf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)floorf((float)(ix + 1) / g.sw) + 1); }
     float acc = 0.f;
-    constexpr int MAXC = 12;
     const int nx = xhi - xlo + 1;
     if (nx <= MAXC) {
         // the column weights do not depend on the row: evaluate them once (x2 / x4 up-sampling: 7 / 11 candidates, at most 4
@@ -342,10 +344,13 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
             const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
             if (wy == 0.f) continue;
             const float* row = gp + (size_t)oy * g.Wo + xlo;
+            float rv[MAXC];
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) rv[j] = row[min(j, nx - 1)];      // clamped and unconditional (wxs is 0 past nx):
+            __builtin_amdgcn_sched_barrier(0);                                // the row's reads leave as one batch
             float rowacc = 0.f;
 #pragma unroll
-            for (int j = 0; j < MAXC; ++j)                       // unconditional clamped loads: the row's reads issue as one batch
-                if (j < nx) rowacc = fmaf(wxs[j], row[j], rowacc);
+            for (int j = 0; j < MAXC; ++j) rowacc = fmaf(wxs[j], rv[j], rowacc);
             acc = fmaf(wy, rowacc, acc);
         }
         gx[idx] = acc;
@@ -722,8 +727,11 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
         return MSPL_OK;
     }
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)), dim3(256), 0,
-                       (hipStream_t)stream, gy, g, gx, total);
+    const dim3 grid((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd));
+    if (g.sw > 0.f && 2.0f / g.sw + 3.0f <= 8.0f)          // x2 up-sampling (the decoder, the heads): at most 7 candidate columns
+        hipLaunchKernelGGL(bilinear_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    else
+        hipLaunchKernelGGL(bilinear_bwd_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("bilinear_bwd");
     return MSPL_OK;
 }
