@@ -207,7 +207,7 @@ def train_step_rate(dev, iters=10):
 def supervised_step_rate(dev, iters=6):
     """one train_seg_ue iteration of the supervised source-model loop (model.train(): batch-statistics BatchNorm,
     CrossEntropy on main + 0.5*aux, flooding, SGD with two learning-rate groups), ESPDNet-UE C=13, bs=16 at 288x480 (the
-    CamVid crop of train_espdnetue_camvid.sh), eager launches.  Extra field."""
+    CamVid crop of train_espdnetue_camvid.sh), zero_grad + forward + loss + backward as one hipGraph replay.  Extra field."""
     import torch
     from mspl_amd import losses, models, supervised
     from tests.synth import synth_state_dict
@@ -219,18 +219,18 @@ def supervised_step_rate(dev, iters=6):
     x = torch.randn((BATCH, 3, 288, 480), generator=g).to(dev)
     y = torch.randint(0, 13, (BATCH, 288, 480), generator=g).to(dev)
     crit = losses.SegmentationLoss(n_classes=13, device=dev, ignore_idx=255)
-    loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit)
+    step = supervised.GraphedSupervisedStep(m, x, y, crit)
     for _ in range(2):
-        loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit, opt)
+        loss, _ = step(x, y)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        loss, _, opt = supervised.train_seg_ue_step(m, x, y, crit, opt)
+        loss, _ = step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
             'workload': 'train_seg_ue iteration, ESPDNet-UE s=2.0 C=13 in train() (batch-statistics BN), bs=16 x 3 x 288 x 480 fp32, '
-                        'CrossEntropy + flooding + SGD(2 lr groups), eager',
+                        'CrossEntropy + flooding + SGD(2 lr groups), hipGraph replay + SGD kernels',
             'loss_finite': bool(torch.isfinite(loss))}
 
 

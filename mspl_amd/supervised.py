@@ -132,3 +132,43 @@ def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=No
     optimizer.all_reduce_grads()
     optimizer.step()
     return loss.detach(), outputs.detach(), optimizer
+
+
+class GraphedSupervisedStep:
+    """train_seg_ue_step with zero_grad + forward + loss + backward replayed as ONE hipGraph (the iteration is ~900 launches);
+    the gradient all-reduce and the SGD kernels (their learning rates change per epoch) stay outside.  The first call runs one
+    eager iteration (reveals the gradient-bearing parameters, builds FlatSGD, consumes SGD's first-step rule) and captures;
+    shapes are fixed at construction.  BatchNorm running statistics and num_batches_tracked advance inside the graph."""
+
+    def __init__(self, model, inputs, target, criterion, depth=None, lr=0.009, lr_mult=10.0, momentum=0.9, weight_decay=4e-5,
+                 b=FLOOD_LEVEL):
+        self.model, self.criterion, self.b = model, criterion, b
+        self.inputs = inputs.detach().clone()
+        self.target = target.detach().clone()
+        self.depth = None if depth is None else depth.detach().clone()
+        _, _, self.optimizer = train_seg_ue_step(model, self.inputs, self.target, criterion, None, self.depth, None, 1.0, lr, lr_mult,
+                                                 momentum, weight_decay, b)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.optimizer.zero_grad()
+            with torch.enable_grad(), ag.grad_sinks():
+                layers.prefold_frozen_bn(model)
+                out = model(self.inputs, self.depth) if self.depth is not None else model(self.inputs)
+                self.outputs = out[0] + 0.5 * out[1]
+                self.loss = flood(criterion(self.outputs, self.target).mean(), b)
+                self.loss.backward()
+        self._finish()                                  # the capture did not execute: run the iteration it recorded
+
+    def _finish(self):
+        self.graph.replay()
+        self.optimizer.all_reduce_grads()
+        self.optimizer.step()
+        return self.loss.detach(), self.outputs.detach()
+
+    def __call__(self, inputs, target, depth=None):
+        self.inputs.copy_(inputs)
+        self.target.copy_(target)
+        if self.depth is not None:
+            self.depth.copy_(depth)
+        return self._finish()

@@ -169,6 +169,32 @@ def test_supervised_step_vs_reference_golden(golden):
     assert torch.isfinite(y).all()
 
 
+@pytest.mark.gpu
+def test_graphed_supervised_step_equals_eager():
+    """The supervised iteration replayed as one hipGraph (running statistics advancing inside the graph) against eager steps."""
+    from mspl_amd import losses, models, supervised
+    c = SUPERVISED_CASE
+    a = argparse.Namespace(s=c['s'], channels=3, num_classes=1000)
+    x = synth_input((2, 3, 32, 48), 28).cuda()
+    y = synth_labels((2, 32, 48), c['classes'], 28).cuda()
+    crit = losses.SegmentationLoss(n_classes=c['classes'], device='cuda', ignore_idx=c['ignore_idx'])
+    nets = []
+    for _ in range(2):
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=c['classes'], dataset=c['dataset'], fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(KEYS['espdnetue_s%s_c%d' % (c['s'], c['classes'])], 5))
+        nets.append(m.cuda().train())
+    opt, eager = None, []
+    for _ in range(4):
+        l, _, opt = supervised.train_seg_ue_step(nets[0], x, y, crit, opt)
+        eager.append(float(l))
+    gs = supervised.GraphedSupervisedStep(nets[1], x, y, crit)                   # eager step 1 + captured step 2
+    graphed = [float(gs(x, y)[0]) for _ in range(2)]
+    np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4, atol=1e-6)
+    for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+        np.testing.assert_allclose(q.float().cpu().numpy(), p.float().cpu().numpy(), rtol=1e-4, atol=2e-4, err_msg=k)
+    assert int(nets[1].state_dict()['base_net.level1.bn.num_batches_tracked']) == 4
+
+
 # ------------------------------------------------------------------ NIDLoss
 from tests.cases import NID_CASES  # noqa: E402
 from tests.synth import synth_nid_inputs  # noqa: E402
