@@ -288,7 +288,10 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
 }
 
 // ---- resampling backward (atomic scatter of the output gradient; gx zeroed by the caller)
-struct RsG { int N, C, Hi, Wi, Ho, Wo; float sh, sw; };
+struct RsG { int N, C, Hi, Wi, Ho, Wo; float sh, sw; unsigned mHi, mWi, mHo, mWo; };   // m*: ceil(2^32/d) division magics
+
+// n / d for n * d < 2^32 with m = ceil(2^32 / d) (d == 1: m overflows to 0, handled)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
 
 __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -419,19 +422,20 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* 
     const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
     const int pi = blockIdx.x * 256 + threadIdx.x;
     if (t >= g.N * g.C || pi >= g.Hi * g.Wi) return;
-    const int iy = pi / g.Wi, ix = pi - iy * g.Wi;
     const float* gp = gy + (size_t)t * g.Ho * g.Wo;
-    // 32-bit unsigned arithmetic (the launcher checks Hi*Ho, Wi*Wo < 2^31): 64-bit divisions cost ~100 instructions each
-    const unsigned Hi = g.Hi, Wi = g.Wi, Ho = g.Ho, Wo = g.Wo, uy = iy, ux = ix;
-    const int oy0 = (int)(uy * Ho / Hi), oy1 = min(g.Ho - 1, (int)(((uy + 1) * Ho + Hi - 1) / Hi) - 1);
-    const int ox0 = (int)(ux * Wo / Wi), ox1 = min(g.Wo - 1, (int)(((ux + 1) * Wo + Wi - 1) / Wi) - 1);
+    // divisions by the four (launch-constant) sizes through mul-hi magics: exact while numerator * divisor < 2^32, which the
+    // launcher checks; a 32-bit hardware-less division is ~30 instructions, and this kernel does ten of them per pixel
+    const unsigned Hi = g.Hi, Wi = g.Wi, Ho = g.Ho, Wo = g.Wo;
+    const unsigned uy = udiv_magic(pi, Wi, g.mWi), ux = pi - uy * Wi;
+    const int oy0 = (int)udiv_magic(uy * Ho, Hi, g.mHi), oy1 = min(g.Ho - 1, (int)udiv_magic((uy + 1) * Ho + Hi - 1, Hi, g.mHi) - 1);
+    const int ox0 = (int)udiv_magic(ux * Wo, Wi, g.mWi), ox1 = min(g.Wo - 1, (int)udiv_magic((ux + 1) * Wo + Wi - 1, Wi, g.mWi) - 1);
     float acc = 0.f;
     for (int oy = oy0; oy <= oy1; ++oy) {
-        const int ys = (int)((unsigned)oy * Hi / Ho), ye = (int)((((unsigned)oy + 1) * Hi + Ho - 1) / Ho);
-        if (iy < ys || iy >= ye) continue;
+        const int ys = (int)udiv_magic((unsigned)oy * Hi, Ho, g.mHo), ye = (int)udiv_magic(((unsigned)oy + 1) * Hi + Ho - 1, Ho, g.mHo);
+        if ((int)uy < ys || (int)uy >= ye) continue;
         for (int ox = ox0; ox <= ox1; ++ox) {
-            const int xs = (int)((unsigned)ox * Wi / Wo), xe = (int)((((unsigned)ox + 1) * Wi + Wo - 1) / Wo);
-            if (ix < xs || ix >= xe) continue;
+            const int xs = (int)udiv_magic((unsigned)ox * Wi, Wo, g.mWo), xe = (int)udiv_magic(((unsigned)ox + 1) * Wi + Wo - 1, Wo, g.mWo);
+            if ((int)ux < xs || (int)ux >= xe) continue;
             acc += gp[(size_t)oy * g.Wo + ox] / (float)((ye - ys) * (xe - xs));
         }
     }
@@ -700,6 +704,8 @@ static int rs_geom(const char* who, const float* gy, float* gx, int N, int C, in
     MSPL_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, MSPL_ERR_BAD_SHAPE, "%s: bad shape", who);
     g.N = N; g.C = C; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo;
     g.sh = bilinear_scale(Hi, Ho); g.sw = bilinear_scale(Wi, Wo);
+    auto magic = [](int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+    g.mHi = magic(Hi); g.mWi = magic(Wi); g.mHo = magic(Ho); g.mWo = magic(Wo);
     return MSPL_OK;
 }
 
@@ -741,8 +747,10 @@ extern "C" int mspl_adaptive_avgpool_bwd(const float* gy, int32_t N, int32_t C, 
                                          float* gx, void* stream) {
     RsG g;
     if (int rc = rs_geom("adaptive_avgpool_bwd", gy, gx, N, C, Hi, Wi, Ho, Wo, g)) return rc;
-    MSPL_REQUIRE((int64_t)(Hi + 1) * Ho < (1ll << 31) && (int64_t)(Wi + 1) * Wo < (1ll << 31), MSPL_ERR_BAD_SHAPE,
-                 "adaptive_avgpool_bwd: map too large for 32-bit window arithmetic");
+    // numerators reach (Hi+1)*Ho + Hi resp. Hi*Wi; the magics are exact while numerator * divisor < 2^32
+    MSPL_REQUIRE(((int64_t)(Hi + 1) * Ho + Hi) * (Hi > Ho ? Hi : Ho) < (1ll << 32) && ((int64_t)(Wi + 1) * Wo + Wi) * (Wi > Wo ? Wi : Wo) < (1ll << 32) &&
+                     (int64_t)Hi * Wi * Wi < (1ll << 32),
+                 MSPL_ERR_BAD_SHAPE, "adaptive_avgpool_bwd: map too large for the 32-bit window arithmetic");
     const int64_t total = (int64_t)N * C * Hi * Wi;
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
     hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)),
