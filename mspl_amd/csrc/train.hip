@@ -294,10 +294,11 @@ struct RsG { int N, C, Hi, Wi, Ho, Wo; float sh, sw; unsigned mHi, mWi, mHo, mWo
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
 
 __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int ix = (int)(idx % g.Wi);  int64_t t = idx / g.Wi;
-    const int iy = (int)(t % g.Hi);  t /= g.Hi;            // t = n*C + c
+    const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.N * g.C || pi >= g.Hi * g.Wi) return;
+    const int iy = (int)udiv_magic(pi, g.Wi, g.mWi), ix = pi - iy * g.Wi;
+    const int64_t idx = (int64_t)t * g.Hi * g.Wi + pi;
     const float* gp = gy + (size_t)t * g.Ho * g.Wo;
     float acc = 0.f;                                         // gather: outputs whose 3x3/s2/p1 window covers (iy, ix)
     for (int oy = max(0, iy / 2); oy <= min(g.Ho - 1, (iy + 1) / 2); ++oy) {
@@ -713,7 +714,10 @@ extern "C" int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int3
     RsG g;
     if (int rc = rs_geom("avgpool3x3s2_bwd", gy, gx, N, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, g)) return rc;
     const int64_t total = (int64_t)N * C * H * W;
-    hipLaunchKernelGGL(avgpool3x3s2_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);
+    MSPL_REQUIRE((int64_t)H * W * W < (1ll << 32), MSPL_ERR_BAD_SHAPE, "avgpool3x3s2_bwd: plane too large for 32-bit index arithmetic");
+    const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
+    hipLaunchKernelGGL(avgpool3x3s2_bwd_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)), dim3(256), 0,
+                       (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("avgpool3x3s2_bwd");
     return MSPL_OK;
 }
