@@ -162,8 +162,7 @@ def loader_io_rate(dev, iters=20):
         t0 = time.perf_counter()
         for _ in range(2):                                # warm-up: pinned staging buffers are allocated once
             w.submit(names, labels)
-        for f in w._futures:
-            f.result()
+        w._retire('all')
         t0 = time.perf_counter()
         for _ in range(8):
             w.submit(names, labels)
@@ -172,7 +171,37 @@ def loader_io_rate(dev, iters=20):
         t_all = time.perf_counter() - t0
     out['label_writer'] = {'value': round(8 * BATCH / t_all, 1), 'unit': 'images/s', 'workers': 8,
                            'submit_us_per_batch': round(t_submit / 8 * 1e6, 1),
-                           'note': 'PNG encode + file write on worker threads; submit() is what the label loop waits for'}
+                           'note': 'PNG encode + file write on native worker threads; submit() is what the label loop waits for'}
+    # (3) the whole chain, host buffers in / files out: pinned uint8 frames -> H2D (PCIe) -> Resize+Normalize -> 13-class label pass
+    #     (hipGraph) -> asynchronous D2H + PNG files.  This is the PCIe-inclusive rate; `value` above is the device-resident one.
+    from mspl_amd import models, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 0))
+    lp = uest.SelfLabelPass(m, classes=13, device=dev, use_graph=True, with_kld=False)
+    pinned = torch.from_numpy(frames).pin_memory()
+    pre288 = Preprocessor(size=(480, 288))
+    with tempfile.TemporaryDirectory() as d:
+        w = LabelWriter(d, workers=8)
+        w.warm((BATCH, 288, 480))
+        for _ in range(3):                                    # warm-up: graph capture
+            labels, _ = lp(pre288(pinned)[0])
+            w.submit(names, labels)
+        w._retire('all')
+        torch.cuda.synchronize()
+        nb = 12
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            labels, _ = lp(pre288(pinned)[0])
+            w.submit(names, labels)
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t0
+        w.close()
+        t_all = time.perf_counter() - t0
+    out['end_to_end'] = {'value': round(nb * BATCH / t_all, 1), 'unit': 'images/s', 'gpu_side_images_per_s': round(nb * BATCH / t_gpu, 1),
+                         'workload': 'pinned uint8 360x480 frames -> H2D -> Resize(480x288)+Normalize -> ESPDNet-UE C=13 label pass -> '
+                                     'async D2H + PNG files, %d batches of %d' % (nb, BATCH)}
     return out
 
 

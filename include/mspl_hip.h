@@ -306,6 +306,18 @@ int mspl_preprocess_u8_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws
 int mspl_resize_label_fwd(const uint8_t* src, int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W,
                           const int32_t* yi, const int32_t* xi, const uint8_t* flip, int64_t* out, void* stream);
 
+/* Native label-map writer (host threads + zlib; no device work): replaces the per-image `Image.fromarray(label).save(png)`
+ * of the label loop (uest_seg_multi_os.py:929-931).  create(workers, deflate level 0..9) -> handle or NULL.
+ * submit: `host` = n maps (n,H,W) uint8 in host memory that must stay valid and unchanged until the ticket is done; paths: n
+ * file names (copied); event: a hipEvent_t recorded after the device->host copy that fills `host`, or NULL when the data is
+ * already there.  Returns a ticket >= 0 or a negative status.  poll(ticket, block): 1 = all n files written (ticket is then
+ * forgotten), 0 = pending, negative = failed.  destroy drains the queue and joins the threads. */
+void* mspl_png_writer_create(int32_t workers, int32_t level);
+int64_t mspl_png_writer_submit(void* writer, const uint8_t* host, int32_t n, int32_t H, int32_t W, const char* const* paths,
+                               void* event);
+int mspl_png_writer_poll(void* writer, int64_t ticket, int32_t block);
+int mspl_png_writer_destroy(void* writer);
+
 /* ---- supervised-loop pieces -------------------------------------------------------------------------
  * nn.BatchNorm2d in train() (model.train(), utilities/train_eval_seg.py:174): per-channel batch mean and 1/sqrt(biased
  * var + eps) over (N,HW) of z (N,C,HW); when running_mean/running_var are given they are updated in place,

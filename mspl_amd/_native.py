@@ -81,6 +81,10 @@ SIGNATURES = {
     'mspl_nid_hist_bwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_eesp_dw_bwd': [c_f32p, c_f32p, c_f32p, ctypes.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p,
                          ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
+    'mspl_png_writer_create': [c_i32, c_i32],
+    'mspl_png_writer_submit': [ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p],
+    'mspl_png_writer_poll': [ctypes.c_void_p, c_i64, c_i32],
+    'mspl_png_writer_destroy': [ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p],
@@ -99,6 +103,8 @@ def _load():
         fn.restype = ctypes.c_int
     lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
     lib.mspl_nid_workspace_floats.restype = ctypes.c_int64
+    lib.mspl_png_writer_create.restype = ctypes.c_void_p          # a handle
+    lib.mspl_png_writer_submit.restype = ctypes.c_int64           # a ticket (or a negative status)
     lib.mspl_version.restype = ctypes.c_char_p
     lib.mspl_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.mspl_last_error.restype = ctypes.c_size_t

@@ -11,14 +11,13 @@ What changes: the reference resizes and normalises one image at a time with Pill
 (workers=0, uest_seg_multi_os.py:577) and blocks on a PNG encode per image in the label loop.  Here decoded uint8 images
 go to the device as they are (3 B/pixel instead of 12) and `Preprocessor` does Resize + Normalize for the whole batch in two
 launches with Pillow's exact fixed-point arithmetic; `LabelWriter` copies the merged uint8 maps back on a side stream into
-pinned memory and encodes/writes the PNGs on worker threads while the next batch is on the GPU.  Decoding the source JPEG /
+pinned memory and native worker threads (C++ + zlib inside the library) encode/write the PNGs while the next batch is on the GPU.  Decoding the source JPEG /
 PNG files stays with PIL on the host (file formats are outside the path).
 """
+import ctypes
 import os
 import struct
-import threading
 import zlib
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -181,53 +180,76 @@ class LabelWriter(object):
     """Asynchronous replacement of the per-image save in the label loop (uest_seg_multi_os.py:923-940).
 
     `submit(names, labels)` takes the merged (N,H,W) uint8 maps as they leave the label pass (device tensor), starts a
-    device->pinned-host copy of a snapshot on a side stream and returns at once (the caller may overwrite `labels`); worker threads wait for the copy, encode and write
+    device->pinned-host copy of a snapshot on a side stream and returns at once (the caller may overwrite `labels`); native
+    worker threads (mspl_png_writer_*, host C++ + zlib: no interpreter lock involved) wait for the copy, encode and write
     `<save_dir>/<image_name>.png` (image_name = basename without its extension, :924-926).  `close()` drains the queue and
     returns (image_path_list, label_path_list[, depth_path_list]) in submission order -- the arguments of
-    update_image_list.  Also usable as a context manager."""
+    update_image_list.  At most `max_inflight` batches are staged (pinned buffers are reused); beyond that submit() waits
+    for the oldest one.  Also usable as a context manager."""
 
-    def __init__(self, save_dir, workers=4, use_depth=False, level=3):
+    def __init__(self, save_dir, workers=4, use_depth=False, level=3, max_inflight=None):
         self.save_dir = save_dir
         os.makedirs(save_dir, exist_ok=True)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.use_depth = use_depth
         self.level = level
         self.image_paths, self.label_paths, self.depth_paths = [], [], []
-        self._futures = []
+        self.max_inflight = max_inflight or 2 * max(1, workers)
+        self._handle = lib.mspl_png_writer_create(max(1, workers), level)
+        if not self._handle:
+            raise RuntimeError('mspl_amd: could not start the PNG writer (workers=%r level=%r)' % (workers, level))
+        self._free = {}             # shape -> pinned staging buffers not in use
+        self._staged = 0            # staging buffers in existence
+        self._inflight = []         # (ticket, staging buffer or None, keep-alive objects) in submission order
         self._stream = None
-        self._lock = threading.Lock()
-        self._free = {}                                    # pinned staging buffers by shape (hipHostMalloc is slow: reuse)
 
     def label_path(self, path_name):
         name = path_name.split('/')[-1]
         return '%s/%s.png' % (self.save_dir, name.rsplit('.', 1)[0])
 
-    def _write_batch(self, host, event, paths):
-        if event is not None:
-            event.synchronize()
-        arr = host.numpy()
-        for i, p in enumerate(paths):
-            data = encode_png_gray8(arr[i], self.level)
-            with open(p, 'wb') as f:
-                f.write(data)
-        if event is not None:
-            with self._lock:
+    def _retire(self, block):
+        """Collect finished batches (all of them when block is set to 'all', the oldest one when True)."""
+        while self._inflight:
+            ticket, host, _ = self._inflight[0]
+            rc = lib.mspl_png_writer_poll(self._handle, ticket, 1 if block else 0)
+            if rc == 0:
+                return
+            self._inflight.pop(0)
+            if host is not None:
                 self._free.setdefault(tuple(host.shape), []).append(host)
+            if rc < 0:
+                check(rc)
+            if block is True:
+                return
+
+    def _staging(self, shape):
+        self._retire(False)
+        while True:
+            pool = self._free.get(shape)
+            if pool:
+                return pool.pop()
+            if self._staged < self.max_inflight:
+                self._staged += 1
+                return torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+            self._retire(True)                              # back-pressure: wait for the oldest batch in flight
+
+    def warm(self, shape, count=None):
+        """Allocate the staging buffers for (N,H,W) batches up front (first-use hipHostMalloc costs ~0.5 ms each)."""
+        n = min(count or self.max_inflight, self.max_inflight) - self._staged
+        bufs = [self._staging(tuple(shape)) for _ in range(max(0, n))]
+        self._free.setdefault(tuple(shape), []).extend(bufs)
 
     def submit(self, names, labels):
         if labels.dtype != torch.uint8 or labels.dim() != 3 or labels.shape[0] != len(names):
             raise RuntimeError('mspl_amd: LabelWriter.submit expects (N,H,W) uint8 labels and N names, got %s %s / %d names'
                                % (labels.dtype, tuple(labels.shape), len(names)))
+        if self._handle is None:
+            raise RuntimeError('mspl_amd: LabelWriter is closed')
         paths = [self.label_path(n) for n in names]
-        event = None
+        event, staged = None, None
         if labels.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=labels.device)
-            with self._lock:
-                pool = self._free.get(tuple(labels.shape))
-                host = pool.pop() if pool else None
-            if host is None:
-                host = torch.empty(labels.shape, dtype=torch.uint8, pin_memory=True)
+            host = staged = self._staging(tuple(labels.shape))
             snap = labels.clone()                          # contents as of submit(): the caller may reuse `labels` at once
             self._stream.wait_stream(torch.cuda.current_stream(labels.device))
             with torch.cuda.stream(self._stream):
@@ -237,18 +259,24 @@ class LabelWriter(object):
             snap.record_stream(self._stream)
         else:
             host = labels.contiguous().clone()
-        with self._lock:
-            self.image_paths += list(names)
-            self.label_paths += paths
-            if self.use_depth:
-                self.depth_paths += [n.replace('color', 'depth') for n in names]          # uest_seg_multi_os.py:936
-            self._futures.append(self.pool.submit(self._write_batch, host, event, paths))
+        N, H, W = host.shape
+        cpaths = (ctypes.c_char_p * N)(*[p.encode() for p in paths])
+        ticket = lib.mspl_png_writer_submit(self._handle, host.data_ptr(), N, H, W, cpaths, None if event is None else event.cuda_event)
+        if ticket < 0:
+            check(int(ticket))
+        self._inflight.append((ticket, staged, (host, event)))
+        self.image_paths += list(names)
+        self.label_paths += paths
+        if self.use_depth:
+            self.depth_paths += [n.replace('color', 'depth') for n in names]          # uest_seg_multi_os.py:936
 
     def close(self):
-        for f in self._futures:
-            f.result()                                             # re-raises a worker's exception
-        self._futures = []
-        self.pool.shutdown(wait=True)
+        if self._handle is not None:
+            try:
+                self._retire('all')
+            finally:
+                lib.mspl_png_writer_destroy(self._handle)
+                self._handle = None
         if self.use_depth:
             return self.image_paths, self.label_paths, self.depth_paths
         return self.image_paths, self.label_paths
@@ -258,3 +286,9 @@ class LabelWriter(object):
 
     def __exit__(self, *exc):
         self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -80,6 +80,27 @@ def test_png_writer_round_trip():
         encode_png_gray8(np.zeros((4, 4), np.int64))
 
 
+def test_native_label_writer_host_tensors(tmp_path):
+    """The native writer (C++ threads + zlib inside the library) with host tensors: no GPU involved; files decode to the maps,
+    back-pressure with a single staging slot, error reporting for an unwritable directory."""
+    from mspl_amd.io import LabelWriter
+    rng = np.random.default_rng(5)
+    maps = torch.from_numpy(np.repeat(np.repeat(rng.integers(0, 5, (4, 9, 13), dtype=np.uint8), 5, 1), 5, 2))
+    with LabelWriter(str(tmp_path / 'pred'), workers=3, max_inflight=1) as w:
+        for b in range(6):
+            w.submit(['/data/color/f%d_%d.png' % (b, i) for i in range(4)], maps)
+    assert len(w.label_paths) == 24 and w.label_paths[5] == '%s/f1_1.png' % (tmp_path / 'pred')
+    for i, p in enumerate(w.label_paths):
+        assert np.array_equal(oio.png_decode_gray8(open(p, 'rb').read()), maps[i % 4].numpy())
+    w2 = LabelWriter(str(tmp_path / 'gone'), workers=1)
+    os.rmdir(str(tmp_path / 'gone'))
+    w2.submit(['a.png'], maps[:1])
+    with pytest.raises(RuntimeError, match='file write'):
+        w2.close()
+    with pytest.raises(RuntimeError, match='closed'):
+        w2.submit(['b.png'], maps[:1])
+
+
 def test_image_list_round_trip(tmp_path):
     from mspl_amd.io import read_image_list, update_image_list
     files = []
