@@ -275,6 +275,9 @@ def main():
     ap.add_argument('--no-bs64', action='store_true', help='skip the extra batch-64 K2 field (use for rocprofv3 --stats runs: '
                     'its launches would mix into the per-kernel averages)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--in-flight', type=int, default=2, help='label passes (independent batches) in flight on the GPU; 1 = one '
+                    'hipGraph replayed back to back on one stream (use it for rocprofv3 --stats runs: overlapping launches stretch '
+                    'each other and the per-kernel averages stop describing the kernels)')
     args = ap.parse_args()
 
     import torch
@@ -302,30 +305,55 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)        # every rank labels its own shard of the image list
     x = torch.randn(shape, generator=g).to(dev)
 
-    lp = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=not args.no_graph)
-    lp(x)                                                  # builds caches / captures the graph
-    xin = lp.static_input(shape)
-    if xin is not None:
-        xin.copy_(x)
-        x = xin
+    depth = max(1, args.in_flight)
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=not args.no_graph),
+                                  depth=depth, device=dev)
+    for _ in range(depth):
+        plp(x)                                             # builds caches / captures one graph per lane
+    list(plp.flush())
+    xs = plp.static_inputs(shape)                          # every lane labels its own resident copy of the batch: no input copy
+    for i, xi in enumerate(xs):
+        if xi is not None:
+            xi.copy_(x)
+        else:
+            xs[i] = x
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        lp(x)
+    def run(steps):
+        for _ in range(steps):
+            plp(xs[plp.next_lane])
+        list(plp.flush())
+
+    run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lp(x)
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the same K steps with ONE pass in flight (lane 0 alone, back to back): the per-batch latency, reported beside the value
+    single = None
+    if depth > 1 and rank == 0:
+        lane0 = plp.lanes[0]
+        for _ in range(min(5, args.warmup)):
+            lane0(xs[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lane0(xs[0])
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        single = {'value': round(BATCH * args.steps / e1, 2), 'unit': 'images/s', 'ms_per_step': round(e1 / args.steps * 1e3, 4),
+                  'note': 'one hipGraph replayed back to back on one stream (= latency of a batch)'}
+    x = xs[0]
 
     # ---- roofline of the dominant kernel (K2): HIP events on the launch stream.  The 13 K2 launches of one
     # forward are recorded (same tensors, same shapes), then each is re-issued REPS times back to back between one
@@ -416,8 +444,9 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: ESPDNet-UE s=2.0 C=13 single-source pseudo-label gen '
                                    '(forward + pred+0.5aux argmax + KL uncertainty + histogram), bs=16/GPU, '
-                                   '16x3x288x480 fp32, hipGraph replay' + (' off' if args.no_graph else ''),
-                       'per_gpu_batch': BATCH, 'input': [BATCH, 3, H, W], 'classes': CLASSES,
+                                   '16x3x288x480 fp32, hipGraph replay' + (' off' if args.no_graph else '') +
+                                   ', %d independent batches in flight per GPU' % depth,
+                       'per_gpu_batch': BATCH, 'batches_in_flight': depth, 'input': [BATCH, 3, H, W], 'classes': CLASSES,
                        'sharding': 'image list sharded by rank, no data-path collective'},
             'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff_kernel (K2, %d launches/forward)' % k2_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -431,6 +460,7 @@ def main():
                 'kernel': 'eesp_dw_hff_kernel, same 13 shapes at batch 64', 'achieved': round(4 * k2_bytes / k2_launches / avg64_s / 1e9, 1),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(4 * k2_bytes / k2_launches / avg64_s / 1e9 / HBM_PEAK_GBS, 4),
                 'avg_launch_us': round(avg64_s * 1e6, 3)},
+            'single_in_flight': single,
             'path_roofline': {'algorithmic_bytes_per_image': PATH_BYTES_PER_IMAGE,
                               'achieved': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9, 1),
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -110,3 +110,34 @@ def test_config3_train_step_bs16_256x480():
     graphed = [float(gs(x, y)) for _ in range(2)]
     assert np.isfinite(eager).all() and eager[-1] < eager[0]
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4)
+
+
+def test_pipelined_label_pass_equals_single_lane():
+    """Two label passes in flight (PipelinedLabelPass, hipGraph lanes on two streams): the same label maps, uncertainty maps and
+    class histogram as one pass at a time, batch by batch, at the BASELINE shape."""
+    import argparse
+    from mspl_amd import models, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 3))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(77)
+    batches = [torch.randn((16, 3, 288, 480), generator=g).cuda() for _ in range(5)]
+    ref = uest.SelfLabelPass(m, classes=13, use_graph=True)
+    want = []
+    for b in batches:
+        lab, kld = ref(b)
+        want.append((lab.clone(), kld.clone()))
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=2)
+    got = []
+    for b in batches:
+        out = plp(b)
+        if out is not None:
+            got.append((out[0].clone(), out[1].clone()))
+    got += [(o[0].clone(), o[1].clone()) for o in plp.flush()]
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for (l1, k1), (l0, k0) in zip(got, want):
+        assert torch.equal(l1, l0) and torch.equal(k1, k0)
+    assert torch.equal(plp.hist, ref.hist) and int(plp.hist.sum()) == 5 * 16 * 288 * 480
