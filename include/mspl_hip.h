@@ -180,7 +180,7 @@ int mspl_label_epilogue_fwd(const float* main, const float* aux, int32_t N, int3
 
 /* K10  cross-source label merge + class histogram.  Replaces uest_seg_multi_os.py:695-718
  *     (merge_outputs) and :919-921.  src[s]: npix uint8 class maps (already in target ids),
- *     S <= 8, num_classes <= 16.  out[p] = first-max argmax_c count_c(p), or `fill` when the
+ *     S <= 8, num_classes <= 32.  out[p] = first-max argmax_c count_c(p), or `fill` when the
  *     winning count < thresh.  hist (num_classes x uint64, device) is ACCUMULATED into (caller zeroes).
  */
 int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64_t npix, int32_t num_classes,

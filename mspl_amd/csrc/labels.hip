@@ -270,8 +270,10 @@ static void launch_merge(int ncls, dim3 grid, hipStream_t st, const MergeSrc& ms
                          uint8_t* out, unsigned long long* hist, int vec_ok) {
     if (ncls <= 8)
         hipLaunchKernelGGL((merge_labels_kernel<S, 8>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
-    else
+    else if (ncls <= 16)
         hipLaunchKernelGGL((merge_labels_kernel<S, 16>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
+    else        // 20 / 21-class self-label passes (Cityscapes / Pascal source models relabelling their own domain)
+        hipLaunchKernelGGL((merge_labels_kernel<S, 32>), grid, dim3(256), 0, st, ms, npix, ncls, thresh, fill, out, hist, vec_ok);
 }
 
 // MIOU.get_iou (utilities/metrics/segmentation_miou.py:13-44) without the host round trip: per pixel
@@ -348,7 +350,7 @@ extern "C" int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64
                                      void* stream) {
     MSPL_REQUIRE(src && out, MSPL_ERR_NULL_POINTER, "merge_labels: null pointer");
     MSPL_REQUIRE(S >= 1 && S <= 8, MSPL_ERR_UNSUPPORTED, "merge_labels: %d sources (1..8)", S);
-    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 16, MSPL_ERR_UNSUPPORTED, "merge_labels: %d classes (1..16)", num_classes);
+    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 32, MSPL_ERR_UNSUPPORTED, "merge_labels: %d classes (1..32)", num_classes);
     MSPL_REQUIRE(fill >= 0 && fill <= 255, MSPL_ERR_BAD_SHAPE, "merge_labels: fill %d", fill);
     MSPL_REQUIRE(npix >= 0, MSPL_ERR_BAD_SHAPE, "merge_labels: negative pixel count");
     if (npix == 0) return MSPL_OK;   // empty input: nothing to write, histogram untouched

@@ -81,6 +81,24 @@ _SIDE_ENABLED = os.environ.get('MSPL_SIDE_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
 
 
+class side_streams(object):
+    """with side_streams(False): run (or capture) the forward on one stream only.  PipelinedLabelPass captures its lanes this
+    way: a linear hipGraph executes on its launch stream alone, so two lanes on two hardware queues overlap for certain,
+    whereas the internal streams a branched graph is given at instantiation may land on the other lane's queue."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _SIDE_ENABLED
+        self.prev = _SIDE_ENABLED
+        _SIDE_ENABLED = self.enabled and os.environ.get('MSPL_SIDE_STREAMS', '1') != '0'
+
+    def __exit__(self, *exc):
+        global _SIDE_ENABLED
+        _SIDE_ENABLED = self.prev
+
+
 def _side_stream(idx, device, parent):
     """Side stream idx of the stream `parent` (keyed by parent so that concurrent source models do not share one)."""
     dev = device.index if device.index is not None else torch.cuda.current_device()

@@ -14,7 +14,7 @@ source models on the GPU; the only tensors that ever exist at full resolution ar
 import numpy as np
 import torch
 
-from . import ops
+from . import layers, ops
 
 # data_loader/segmentation/greenhouse.py:15-58 (literal tables: source class id -> greenhouse class id)
 id_camvid_to_greenhouse = np.array([4, 2, 2, 3, 3, 1, 2, 2, 2, 4, 4, 2, 4])
@@ -152,14 +152,51 @@ class PseudoLabelPass:
         return torch.from_numpy(class_weights_from_histogram(self.hist.cpu().numpy(), policy)).float().to(self.device)
 
 
+def _concurrent_streams(n, device, candidates=12, spin_cycles=400000):
+    """n streams whose kernels really run side by side.  HIP multiplexes streams onto a few hardware queues (4 by default,
+    GPU_MAX_HW_QUEUES); two streams on the same queue execute in order, and which queue a torch stream lands on depends on how
+    many streams the process created before.  Measured, not assumed: a spin kernel on the candidate and on every stream
+    chosen so far must take about as long as one spin, not the sum.  Falls back to plain new streams when no n-subset overlaps
+    (e.g. GPU_MAX_HW_QUEUES=1)."""
+    import time
+    if n == 1:
+        return [torch.cuda.Stream(device=device)]
+
+    def spin_ms(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin_cycles)
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) * 1e3
+
+    pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
+    spin_ms(pool[:1])                                   # first use of the spin kernel (module load)
+    one = min(spin_ms(pool[:1]) for _ in range(3))
+    chosen = [pool[0]]
+    for st in pool[1:]:
+        if len(chosen) == n:
+            break
+        if min(spin_ms(chosen + [st]) for _ in range(2)) < one * (1.0 + 0.5 * len(chosen)):
+            chosen.append(st)
+    while len(chosen) < n:
+        chosen.append(torch.cuda.Stream(device=device))
+    return chosen
+
+
 class PipelinedLabelPass:
     """`depth` label passes in flight: lane i owns a pass object (its hipGraph, static buffers and histogram) and a stream; batch k
     goes to lane k % depth.  Images are independent in the label loop (the reference runs them one at a time), so consecutive
     batches may overlap -- and they should: most kernels of a pass are single-round launches whose ramp, tail and
-    load/compute/store phases leave the chip partly idle; a second pass in flight fills those holes (+29 % images/s at
-    depth 2 on MI355X; deeper pipelines start to thrash the caches: 3 -> +20 %, 4 -> +14 %).
+    load/compute/store phases leave the chip partly idle; a second pass in flight fills those holes (+22 % images/s at
+    depth 2, +33 % at depth 3 on MI355X; at depth 4 the lanes outnumber the free hardware queues and it drops again).  Two things make the overlap
+    dependable rather than lucky: the lanes' streams are CHOSEN by measurement (`_concurrent_streams`: HIP multiplexes
+    streams onto 4 hardware queues and two streams on one queue run in order), and the lanes are captured WITHOUT the
+    models' internal side streams -- a branched hipGraph is handed internal streams at instantiation that may land on
+    the other lane's queue, which silently serialises the two passes (seen as x1.00 on two of four pass types).
 
-        plp = PipelinedLabelPass(lambda: SelfLabelPass(model, use_graph=True), depth=2)
+        plp = PipelinedLabelPass(lambda: SelfLabelPass(model, use_graph=True), depth=3)
         for images in loader:
             out = plp(images)            # outputs of the batch submitted depth-1 calls earlier, None while the pipe fills
             if out is not None: consume(out)
@@ -168,13 +205,13 @@ class PipelinedLabelPass:
     What `plp(...)` returns is valid on the current stream until the next call (its lane's static buffers are reused depth calls
     later, and every submit first waits for the work already queued on the current stream).  `hist` sums the lanes' histograms."""
 
-    def __init__(self, make_pass, depth=2, device='cuda'):
+    def __init__(self, make_pass, depth=3, device='cuda'):
         if depth < 1:
             raise ValueError('PipelinedLabelPass: depth must be >= 1')
         self.device = torch.device(device)
         self.depth = depth
         self.lanes = [make_pass() for _ in range(depth)]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.streams = _concurrent_streams(depth, self.device)
         self._pending = []
         self._n = 0
 
@@ -207,7 +244,7 @@ class PipelinedLabelPass:
         st = self.streams[i]
         cur = torch.cuda.current_stream(self.device)
         st.wait_stream(cur)             # the inputs, and whatever still reads this lane's previous outputs, are on `cur`
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st), layers.side_streams(self.depth == 1):    # lanes are captured as linear graphs
             out = self.lanes[i](images)
             ev = torch.cuda.Event()
             ev.record(st)
@@ -231,7 +268,7 @@ class PipelinedLabelPass:
 
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
-                                      use_graph=True, writer_workers=4, in_flight=2):
+                                      use_graph=True, writer_workers=4, in_flight=3):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
 

@@ -144,6 +144,16 @@ def test_merge_random_maps_and_histogram(golden):
     np.testing.assert_array_equal(out, olab.merge_outputs(src, 5, 'half'))
     # empty input
     assert uest.merge_outputs(np.zeros((3, 0), dtype=np.uint8), 5, 'all').shape == (0,)
+    # 20 / 21-class label spaces (a Cityscapes / Pascal source model relabelling its own domain): identity vote + histogram
+    for ncls in (20, 21, 32):
+        src = rng.randint(0, ncls, size=(2, 5000)).astype(np.uint8)
+        t = torch.from_numpy(src).to(DEV)
+        hist = torch.zeros(ncls, dtype=torch.int64, device=DEV)
+        out = ops.merge_labels([t[0]], ncls, 1, 4, hist).cpu().numpy()
+        np.testing.assert_array_equal(out, src[0])
+        np.testing.assert_array_equal(hist.cpu().numpy(), np.bincount(src[0], minlength=ncls))
+        out2 = ops.merge_labels([t[0], t[1]], ncls, 2, 4).cpu().numpy()
+        np.testing.assert_array_equal(out2, olab.merge_outputs(src, ncls, 'all'))
 
 
 @pytest.mark.parametrize('C', [5, 13, 20])

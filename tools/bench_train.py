@@ -22,6 +22,19 @@ for _ in range(20):
     p(x)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 20
 print('3-source label pass: %.2f ms/batch16 -> %.0f img/s' % (t * 1e3, 16 / t))
+for depth in (2, 3):
+    plp = uest.PipelinedLabelPass(lambda: uest.PseudoLabelPass(nets, ['camvid', 'cityscapes', 'forest'], merge_label_policy='all',
+                                                               device=dev, use_graph=True), depth=depth, device=dev)
+    for _ in range(2 * depth + 2):
+        plp(x)
+    list(plp.flush())
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(24):
+        plp(x)
+    list(plp.flush())
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 24
+    print('3-source label pass, %d batches in flight: %.2f ms/batch16 -> %.0f img/s' % (depth, t * 1e3, 16 / t))
+    del plp
 
 tgt = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
 tgt.load_state_dict(synth_state_dict(tgt.state_dict(), 9))
