@@ -180,9 +180,8 @@ def loader_io_rate(dev, iters=20):
     m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
     m.load_state_dict(synth_state_dict(m.state_dict(), 0))
     # (one pass in flight here: with the host in the loop the chain is paced by the interpreter, not by the GPU, and the extra
-    #  bookkeeping of three lanes costs more than the overlap returns: 6 000 vs 7 200 images/s)
-    lp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, device=dev, use_graph=True, with_kld=False), depth=1,
-                                 device=dev)
+    #  bookkeeping of several lanes costs more than the overlap returns: 6 000 vs 7 200 images/s)
+    lp = uest.SelfLabelPass(m, classes=13, device=dev, use_graph=True, with_kld=False)
     pinned = torch.from_numpy(frames).pin_memory()
     pre288 = Preprocessor(size=(480, 288))
     with tempfile.TemporaryDirectory() as d:
@@ -191,12 +190,9 @@ def loader_io_rate(dev, iters=20):
 
         def chain(nb):
             for _ in range(nb):
-                r = lp(pre288(pinned)[0])
-                if r is not None:
-                    w.submit(names, r[0])
-            for r in lp.flush():
-                w.submit(names, r[0])
-        chain(6)                                              # warm-up: graph capture on every lane
+                labels, _ = lp(pre288(pinned)[0])
+                w.submit(names, labels)
+        chain(3)                                              # warm-up: graph capture
         w._retire('all')
         torch.cuda.synchronize()
         nb = 12
