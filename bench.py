@@ -435,6 +435,12 @@ def main():
     if os.path.exists(tpath):
         k2_traffic = int(json.load(open(tpath))['avg_traffic_bytes_per_launch'])
         k2_traffic_src = 'profiles/r01_k2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
+    # measured HBM bytes of one whole pass (every kernel; tools/pass_traffic.py, same PMC recipe)
+    path_traffic, path_traffic_src = None, None
+    ppath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_m_pass_hbm_traffic.json')
+    if os.path.exists(ppath):
+        path_traffic = int(json.load(open(ppath))['total_MB_per_image'] * 1e6)
+        path_traffic_src = 'profiles/r01_m_pass_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)'
     avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
     achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
 
@@ -471,7 +477,8 @@ def main():
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(4 * k2_bytes / k2_launches / avg64_s / 1e9 / HBM_PEAK_GBS, 4),
                 'avg_launch_us': round(avg64_s * 1e6, 3)},
             'single_in_flight': single,
-            'path_roofline': {'algorithmic_bytes_per_image': PATH_BYTES_PER_IMAGE,
+            'path_roofline': {'algorithmic_bytes_per_image': PATH_BYTES_PER_IMAGE, 'traffic_bytes_per_image': path_traffic,
+                              'traffic_source': path_traffic_src,
                               'achieved': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9, 1),
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
