@@ -159,8 +159,8 @@ def _concurrent_streams(n, device, candidates=12, spin_cycles=400000):
     chosen so far must take about as long as one spin, not the sum.  Falls back to plain new streams when no n-subset overlaps
     (e.g. GPU_MAX_HW_QUEUES=1)."""
     import time
-    if n == 1:
-        return [torch.cuda.Stream(device=device)]
+    if n == 1 or not hasattr(torch.cuda, '_sleep'):
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
 
     def spin_ms(streams):
         torch.cuda.synchronize(device)
