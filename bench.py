@@ -179,9 +179,8 @@ def loader_io_rate(dev, iters=20):
     a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
     m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
     m.load_state_dict(synth_state_dict(m.state_dict(), 0))
-    # (one pass in flight here: with the host in the loop the chain is paced by the interpreter, not by the GPU, and the extra
-    #  bookkeeping of several lanes costs more than the overlap returns: 6 000 vs 7 200 images/s)
-    lp = uest.SelfLabelPass(m, classes=13, device=dev, use_graph=True, with_kld=False)
+    lp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, device=dev, use_graph=True, with_kld=False), depth=3,
+                                 device=dev)
     pinned = torch.from_numpy(frames).pin_memory()
     pre288 = Preprocessor(size=(480, 288))
     with tempfile.TemporaryDirectory() as d:
@@ -190,12 +189,15 @@ def loader_io_rate(dev, iters=20):
 
         def chain(nb):
             for _ in range(nb):
-                labels, _ = lp(pre288(pinned)[0])
-                w.submit(names, labels)
-        chain(3)                                              # warm-up: graph capture
+                r = lp(pre288(pinned)[0])
+                if r is not None:
+                    w.submit(names, r[0])
+            for r in lp.flush():
+                w.submit(names, r[0])
+        chain(9)                                              # warm-up: graph capture on every lane, allocator steady state
         w._retire('all')
         torch.cuda.synchronize()
-        nb = 12
+        nb = 36
         t0 = time.perf_counter()
         chain(nb)
         torch.cuda.synchronize()
@@ -203,7 +205,7 @@ def loader_io_rate(dev, iters=20):
         w.close()
         t_all = time.perf_counter() - t0
     out['end_to_end'] = {'value': round(nb * BATCH / t_all, 1), 'unit': 'images/s', 'gpu_side_images_per_s': round(nb * BATCH / t_gpu, 1),
-                         'workload': 'pinned uint8 360x480 frames -> H2D -> Resize(480x288)+Normalize -> ESPDNet-UE C=13 label pass (1 batch in '
+                         'workload': 'pinned uint8 360x480 frames -> H2D -> Resize(480x288)+Normalize -> ESPDNet-UE C=13 label pass (3 batches in '
                                      'flight) -> async D2H + PNG files, %d batches of %d' % (nb, BATCH)}
     return out
 
