@@ -173,7 +173,8 @@ def test_label_writer_async(tmp_path):
 
 
 @pytest.mark.gpu
-def test_generate_pseudo_label_multi_model_end_to_end(tmp_path):
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_generate_pseudo_label_multi_model_end_to_end(tmp_path, use_graph):
     """The whole reference function (uest_seg_multi_os.py:832-956): uint8 frames -> device Resize+Normalize -> three source
     models -> LUT -> merge -> PNG files + tgt_train.lst + class weights; every stage checked against the oracle."""
     import argparse
@@ -192,14 +193,14 @@ def test_generate_pseudo_label_multi_model_end_to_end(tmp_path):
         ms.append(m)
         sds.append(sd)
     pre = Preprocessor(size=(64, 48))
-    frames = [np.stack([synth_image_u8(72, 96, 70 + 4 * b + i)[0] for i in range(2)]) for b in range(2)]
-    names = [['/d/color/f_%d_%d.jpg' % (b, i) for i in range(2)] for b in range(2)]
+    frames = [np.stack([synth_image_u8(72, 96, 70 + 4 * b + i)[0] for i in range(2)]) for b in range(5)]     # 5 batches: the 3 lanes wrap
+    names = [['/d/color/f_%d_%d.jpg' % (b, i) for i in range(2)] for b in range(5)]
     loader = [(pre(torch.from_numpy(f))[0], None, n, 0.0) for f, n in zip(frames, names)]
-    lst, cw = uest.generate_pseudo_label_multi_model(ms, [s[2] for s in specs], loader, str(tmp_path), use_graph=False)
+    lst, cw = uest.generate_pseudo_label_multi_model(ms, [s[2] for s in specs], loader, str(tmp_path), use_graph=use_graph)
     images, labels, _ = read_image_list(lst, check_files=False)
     assert images == sum(names, []) and all(os.path.isfile(p) for p in labels)
     hist = np.zeros(5)
-    for b in range(2):
+    for b in range(5):
         for i in range(2):
             x = torch.from_numpy(oio.val_transform(frames[b][i], size=(64, 48))[0])[None]
             srcs = []
