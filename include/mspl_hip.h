@@ -280,6 +280,11 @@ int mspl_weighted_ce_bwd(const float* pred, const int64_t* target, const float* 
                          int32_t ignore_index, int32_t N, int32_t C, int32_t HW, const float* g, const float* den,
                          float* gpred, float* gu, void* stream);
 
+/* Launch-shape preference for callers that keep several independent passes in flight (mspl_amd.uest.PipelinedLabelPass): non-zero
+ * = prefer fewer, longer workgroups.  Returns the previous setting.  Results never change; it is read when a kernel is launched
+ * (under hipGraph capture: once, at capture). */
+int mspl_set_throughput_mode(int32_t on);
+
 /* ---- loader-side transforms: the step in front of the hot path -------------------------------------
  * Replace, for a whole batch of decoded uint8 images, data_loader/segmentation/greenhouse.py:216-222 (val_transforms =
  * Resize(size) -> Normalize()|Tensorize()) i.e. transforms/segmentation/data_transforms.py:191-212 (PIL BILINEAR for

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/mspl_hip.h"
 
 namespace mspl {
@@ -30,6 +32,8 @@ void set_error(const char* fmt, ...);
             return MSPL_ERR_HIP;                                                     \
         }                                                                            \
     } while (0)
+
+extern std::atomic<int> g_throughput_mode;     // api.hip: mspl_set_throughput_mode
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

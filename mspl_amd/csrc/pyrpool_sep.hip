@@ -538,8 +538,11 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
     g.dscoff = off;  off += P2_MAXB * P2_NDESC;
     const size_t lds = (size_t)off * sizeof(float);
     if (lds > 64 * 1024) return 1;
+    // planes per workgroup (each workgroup walks them with the next plane's loads in flight): as many as keep >= 2048 workgroups
+    // for a lone pass; in throughput mode 512 are enough -- fewer, longer workgroups (+2.5 % images/s with three passes in flight)
+    const int64_t min_blocks = g_throughput_mode.load() ? 512 : 2048;
     int cpb = 1;
-    while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= 2048) cpb *= 2;
+    while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= min_blocks) cpb *= 2;
     static const int dbg_cpb = getenv("MSPL_PYR_CPB") ? atoi(getenv("MSPL_PYR_CPB")) : 0;
     if (dbg_cpb > 0 && P % dbg_cpb == 0) cpb = dbg_cpb;
     g.CPB = cpb; g.cblocks = P / cpb;

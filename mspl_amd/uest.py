@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import layers, ops
+from ._native import lib
 
 # data_loader/segmentation/greenhouse.py:15-58 (literal tables: source class id -> greenhouse class id)
 id_camvid_to_greenhouse = np.array([4, 2, 2, 3, 3, 1, 2, 2, 2, 4, 4, 2, 4])
@@ -244,8 +245,13 @@ class PipelinedLabelPass:
         st = self.streams[i]
         cur = torch.cuda.current_stream(self.device)
         st.wait_stream(cur)             # the inputs, and whatever still reads this lane's previous outputs, are on `cur`
-        with torch.cuda.stream(st), layers.side_streams(self.depth == 1):    # lanes are captured as linear graphs
-            out = self.lanes[i](images)
+        prev = lib.mspl_set_throughput_mode(1 if self.depth > 1 else 0)      # launch shapes for a shared chip (read at capture)
+        try:
+            with torch.cuda.stream(st), layers.side_streams(self.depth == 1):    # lanes are captured as linear graphs
+                out = self.lanes[i](images)
+        finally:
+            lib.mspl_set_throughput_mode(prev)
+        with torch.cuda.stream(st):
             ev = torch.cuda.Event()
             ev.record(st)
         if torch.is_tensor(images) and images.is_cuda:
