@@ -141,9 +141,12 @@ class _SegBase(nn.Module):
                 self.aux_decoder = EfficientPyrPool(in_planes=dec[aux_layer], proj_planes=pyr_plane_proj,
                                                     out_planes=dec[3], last_layer_br=False)
 
-    def _encode(self, x, image_for_l2, l3_tail):
+    def _encode(self, x, image_for_l2, l3_tail, pyr=None):
         b = self.base_net
-        pyr = ImagePyramid(x.detach()) if b.input_reinforcement else None
+        if not b.input_reinforcement:
+            pyr = None
+        elif pyr is None:
+            pyr = ImagePyramid(x.detach())
         l1 = b.level1(x)
         l2 = b.level2_0(l1, pyr if image_for_l2 else None)
         l3 = b.level3_0(l2, pyr)
@@ -263,15 +266,16 @@ class ESPDNetwithUncertaintyEstimation(_SegBase):
     def get_classification_layer_params(self):
         return self.get_segment_params()
 
-    def forward_lowres(self, x, x_d=None):
+    def forward_lowres(self, x, x_d=None, pyr=None):
         """(main at H/2 x W/2, aux at H/4 x W/4 for aux_layer=2): decoder outputs before espdnet_ue.py:301-302.
+        pyr: an ImagePyramid of x shared by several models looking at the same batch (the multi-source label pass).
         With x_d the encoder follows espdnet_ue.py:186-270 line by line: depth features come from depth_base_net (its
         DownSamplers get NO image reinforcement, :198,:209,:240), fusion after level1, level2 and after the level3 /
         level4 stacks (after every block with dense_fuse)."""
         _check_input(x)
         if x_d is None:
             # level3[1:] run through depth_base_net's layers (espdnet_ue.py:226) -- reproduced on purpose
-            l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3)
+            l1, l2, l3, l4 = self._encode(x, True, self.depth_base_net.level3, pyr)
             return self._decode(l1, l2, l3, l4, self.aux_layer)
         l1, l2, l3, l4 = self._encode_rgbd(x, x_d)
         return self._decode(l1, l2, l3, l4, self.aux_layer)

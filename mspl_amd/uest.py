@@ -38,8 +38,8 @@ def resolve_thresh(num_data, thresh):
     return num_data // 2 + 1
 
 
-def _lowres(model, image):
-    out = model.forward_lowres(image)
+def _lowres(model, image, pyr=None):
+    out = model.forward_lowres(image, pyr=pyr) if pyr is not None else model.forward_lowres(image)
     return out if isinstance(out, tuple) else (out, None)
 
 
@@ -111,10 +111,13 @@ class PseudoLabelPass:
 
     def _run(self, images):
         maps = []
+        # the average-pool pyramid of the batch (input reinforcement of every DownSampler) does not depend on the model: once per batch
+        shared = all(hasattr(m, 'depth_base_net') and getattr(m.base_net, 'input_reinforcement', False) for m in self.models)
+        pyr = layers.ImagePyramid(images) if shared and len(self.models) > 1 else None
         for m, lut in zip(self.models, self.luts):
             # (sources run one after the other: forking one HIP stream per source model on top of the models' own side
             # streams crashed hipStreamEndCapture on ROCm 7.2 -- nested fork/join graphs are avoided)
-            main, aux = _lowres(m, images)
+            main, aux = _lowres(m, images, pyr)
             maps.append(ops.label_epilogue(main, aux, images.shape[2:], lut=lut)['labels'])
         return ops.merge_labels(maps, self.classes, self.thresh, NO_AGREEMENT_CLASS, self.hist), maps
 
