@@ -343,30 +343,6 @@ def bn_prelu(c, bn, scale, shift, alpha=None, pre_add=None, residual=None):
     return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual, bn.weight, bn.bias, bn.running_mean, frozen_bn_inv(bn))
 
 
-class BNFoldFn(torch.autograd.Function):
-    """(scale, shift) = (gamma*inv, beta - mean*gamma*inv) with inv = rsqrt(running_var + eps) frozen (eval-mode BN):
-    two C-sized kernels forward, two backward."""
-
-    @staticmethod
-    def forward(ctx, gamma, beta, mean, inv):
-        scale = gamma * inv
-        shift = torch.addcmul(beta, mean, scale, value=-1.0)
-        ctx.save_for_backward(mean, inv)
-        return scale, shift
-
-    @staticmethod
-    def backward(ctx, gsc, gsh):
-        mean, inv = ctx.saved_tensors
-        return torch.addcmul(gsc, mean, gsh, value=-1.0).mul_(inv), gsh, None, None
-
-
-def bn_affine(bn):
-    """Differentiable eval-mode BatchNorm fold: (scale, shift) as functions of gamma/beta (C-sized tensors).  The
-    running statistics are frozen on this path (uest_seg_multi_os.py:605-608), so rsqrt(var+eps) is cached on the
-    module and refreshed only when running_var is written."""
-    return BNFoldFn.apply(bn.weight, bn.bias, bn.running_mean, frozen_bn_inv(bn))
-
-
 class BNBatchStatsFn(torch.autograd.Function):
     """Training-mode BatchNorm2d as a differentiable fold: (scale, shift) = (gamma*invstd, beta - mean*gamma*invstd) with
     mean / biased variance taken over (N,H,W) of z (nn.BatchNorm2d.forward in train(); the supervised loop of
