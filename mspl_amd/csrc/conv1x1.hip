@@ -22,6 +22,9 @@
 
 namespace mspl {
 
+int conv1x1_splitk_try(const float* x, const float* w, int N, int Cin, int Cout, int groups, int HW, const Epi& e, float* out,
+                       hipStream_t s);
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct PwGeom {
@@ -912,6 +915,10 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     if ((g.K < 16 || (g.K & 1)) && (size_t)Cout * g.K * 4 <= 48 * 1024) return launch_small(x, w, N, Cin, Cout, groups, HW, e, out, s);
     MSPL_REQUIRE((g.K & 1) == 0, MSPL_ERR_UNSUPPORTED, "conv1x1: odd K=%d per group with %d output channels is not supported", g.K, Cout);
 
+    if (conv1x1_splitk_try(x, w, N, Cin, Cout, groups, HW, e, out, s) == 0) {      // few output channels per group: split-K form
+        MSPL_CHECK_LAUNCH("conv1x1(split-K)");
+        return MSPL_OK;
+    }
     const int K32 = (g.K + 31) & ~31;
     g.KS = K32 | 1;
     g.vecw = ((g.K & 3) == 0) && ((((uintptr_t)w) & 15) == 0);

@@ -52,7 +52,9 @@ def test_eesp_dw_unsupported_dilation_raises():
     (2, 96, 96, 4, 8, 12), (1, 16, 13, 1, 17, 23), (1, 48, 16, 1, 20, 20), (2, 16, 4, 4, 10, 10),
     (1, 128, 512, 4, 6, 6), (1, 160, 640, 4, 5, 9), (1, 3, 128, 1, 12, 16), (1, 512, 64, 1, 4, 8),
     # many pixel tiles: several tiles per wave (the ring runs across tiles), 48 rows in a 64-row weight tile, odd pixel count
-    (1, 32, 16, 1, 288, 720), (1, 64, 96, 2, 160, 320), (3, 24, 8, 1, 191, 201)])
+    (1, 32, 16, 1, 288, 720), (1, 64, 96, 2, 160, 320), (3, 24, 8, 1, 191, 201),
+    # few output channels per group on small maps: the split-K form (EESP reduce projections at levels 3 / 4, pyramid projections)
+    (2, 512, 128, 4, 18, 30), (3, 256, 64, 4, 36, 60), (2, 128, 20, 1, 7, 11)])
 def test_conv1x1_epilogues(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
@@ -63,6 +65,13 @@ def test_conv1x1_epilogues(cfg):
     res = rnd(N, Cout, H, W, seed=6)
     base = F.conv2d(x, w, None, 1, 0, 1, G)
     close(ops.conv1x1(x.to(DEV), w.to(DEV), G), base)
+    # BN + PReLU only, into a channel slice (the epilogue every kernel form supports)
+    dst0 = torch.full((N, Cout + 4, H, W), -3.0, device=DEV)
+    sc0, sh0, al0 = rnd(Cout + 4, seed=21).abs() + 0.5, rnd(Cout + 4, seed=22) * 0.1, rnd(Cout + 4, seed=23).abs() * 0.3
+    ops.conv1x1(x.to(DEV), w.to(DEV), G, Epi(sc0.to(DEV), sh0.to(DEV), al0.to(DEV)), out=(dst0, 2))
+    s0 = slice(2, 2 + Cout)
+    close(dst0[:, s0], F.prelu(base * sc0[s0].view(1, -1, 1, 1) + sh0[s0].view(1, -1, 1, 1), al0[s0]))
+    assert torch.all(dst0[:, :2] == -3.0) and torch.all(dst0[:, 2 + Cout:] == -3.0)
     ref = F.prelu(base * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res, alpha)
     got = ops.conv1x1(x.to(DEV), w.to(DEV), G, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), residual=res.to(DEV)))
     close(got, ref)
