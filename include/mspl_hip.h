@@ -137,6 +137,17 @@ int mspl_fusion_gate_fwd(const float* z, const float* rgb, const float* depth, i
 int mspl_fusion_gate_bwd(const float* z, const float* rgb, const float* depth, const float* gy, int64_t count,
                          float* gz, float* grgb, float* gdepth, void* stream);
 
+/* mspl_avgpool3x3s2_fwd that also leaves partial plane sums of its input: psum (N*C, nblk) with nblk =
+ * mspl_avgpool3x3s2_psum_blocks(H, W) (one partial per workgroup of a plane, every slot written, summed in order by the
+ * consumer: deterministic), and the EfficientPWConv gate computed from them: gate (N,Cout) = sigmoid(W (Cout,Cin) . sum_j psum / HW).
+ * Together they replace mspl_gap_gate_fwd's extra read of the encoder outputs (efficient_pt.py:13-17,26) where a DownSampler
+ * pools the same tensor. */
+int mspl_avgpool3x3s2_psum_blocks(int32_t H, int32_t W);
+int mspl_avgpool3x3s2_psum_fwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, const mspl_epilogue_t* ep, float* out,
+                               float* psum, void* stream);
+int mspl_gate_from_sums_fwd(const float* psum, const float* w, int32_t N, int32_t Cin, int32_t Cout, int32_t nblk, int32_t HW,
+                            float* gate, void* stream);
+
 /* K6 prologue: the low-resolution branches' maps for mspl_pyrpool_fused_fwd in ONE launch (one workgroup per (image,
  *     channel) plane): out[i] (N,P,hs[i],ws[i]) = dw3x3(adaptive_avg_pool2d(x, (hs[i],ws[i]))) with stage_w[i] (P,1,3,3);
  *     nn_layers/efficient_pyramid_pool.py:44-50 for the scales < 1.  A workgroup stages a band of input rows and the

@@ -35,6 +35,9 @@ SIGNATURES = {
     'mspl_avgpool3x3s2_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_bilinear_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_adaptive_avgpool_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_avgpool3x3s2_psum_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_avgpool3x3s2_psum_blocks': [c_i32, c_i32],
+    'mspl_gate_from_sums_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_pointwise_fwd': [c_f32p, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_gap_gate_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_fusion_gate_fwd': [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, ctypes.c_void_p],

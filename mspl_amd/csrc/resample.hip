@@ -53,10 +53,16 @@ __device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n
     }
 }
 
+// PSUM: also accumulate the plane sums of the INPUT (the EfficientPWConv gates need mean_hw of exactly the tensors the three
+// DownSamplers pool: l1, l2, l3 -- reading them again for a plane-mean kernel was 4 % of a pass's HBM traffic).  Every thread owns
+// the 2x8 input block (rows 2y, 2y+1; columns 2*x0 .. 2*x0+7) it loads anyway; one partial per workgroup (one plane per workgroup).
+template <bool PSUM>
 __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restrict__ x, RsGeom g, Epi e,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ psum) {
     int n, c, y, x0;
-    if (!strip_decode(g, n, c, y, x0)) return;
+    const bool live = strip_decode(g, n, c, y, x0);
+    float own = 0.f;
+    if (live) {
     const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // input columns 2*x0-1 .. 2*x0+7; 2*x0 is a multiple of 8, so with Wi % 4 == 0 the 8 interior columns are
@@ -76,6 +82,10 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
             l[ky] = row[x0 > 0 ? -1 : 0];
         }
         const float lm = x0 > 0 ? 1.f : 0.f;
+        if (PSUM) {
+            own = ((a[1].x + a[1].y) + (a[1].z + a[1].w)) + ((b[1].x + b[1].y) + (b[1].z + b[1].w));
+            own += m[2] * (((a[2].x + a[2].y) + (a[2].z + a[2].w)) + ((b[2].x + b[2].y) + (b[2].z + b[2].w)));
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const float w = m[ky];
@@ -98,11 +108,26 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += rv[2 * j] + rv[2 * j + 1] + rv[2 * j + 2];
+            if (PSUM && ky >= 1) {
+#pragma unroll
+                for (int i = 1; i < 9; ++i) own += rv[i];          // columns 2*x0 .. 2*x0+7 (zero outside the image)
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] *= (1.0f / 9.0f);   // count_include_pad=True: divisor is always 9
     strip_store(e, g, n, c, y, x0, acc, out);
+    }
+    if (PSUM) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) own += __shfl_down(own, o, 64);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = own;
+        __syncthreads();
+        const int plane = blockIdx.z * gridDim.y + blockIdx.y;
+        // one slot per (plane, workgroup): the gate sums the slots in order -- deterministic, and nothing to zero
+        if (threadIdx.x == 0 && plane < g.N * g.C) psum[(size_t)plane * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
 }
 
 // The column sources / weights depend on the output column only: a workgroup computes the table of the columns it
@@ -233,18 +258,22 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
 
 // One wave per (n, co): lanes stride over Cin (coalesced weight row), shuffle reduction, sigmoid.
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ mean, const float* __restrict__ w,
-                                                   int N, int Cin, int Cout, float* __restrict__ gate) {
+                                                   int N, int Cin, int Cout, int nblk, float mscale, float* __restrict__ gate) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= N * Cout) return;                      // wave-uniform
     const int lane = threadIdx.x & 63;
     const int n = idx / Cout, co = idx - n * Cout;
-    const float* m = mean + (size_t)n * Cin;
+    const float* m = mean + (size_t)n * Cin * nblk;            // nblk partial sums per channel (1: a finished mean)
     const float* wr = w + (size_t)co * Cin;
     float s = 0.f;
-    for (int k = lane; k < Cin; k += 64) s = fmaf(wr[k], m[k], s);
+    for (int k = lane; k < Cin; k += 64) {
+        float mk = m[(size_t)k * nblk];
+        for (int j = 1; j < nblk; ++j) mk += m[(size_t)k * nblk + j];
+        s = fmaf(wr[k], mk, s);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if (lane == 0) gate[idx] = 1.0f / (1.0f + expf(-s));
+    if (lane == 0) gate[idx] = 1.0f / (1.0f + expf(-(s * mscale)));
 }
 
 static int resample_common(const char* who, const float* x, float* out, int N, int C, int Hi, int Wi, int Ho, int Wo,
@@ -275,8 +304,38 @@ extern "C" int mspl_avgpool3x3s2_fwd(const float* x, int32_t N, int32_t C, int32
     RsGeom g; Epi e; int64_t total;
     const int Ho = H > 0 ? (H - 1) / 2 + 1 : 0, Wo = W > 0 ? (W - 1) / 2 + 1 : 0;
     if (int rc = resample_common("avgpool3x3s2", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
-    hipLaunchKernelGGL(avgpool3x3s2_kernel, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out);
+    hipLaunchKernelGGL(avgpool3x3s2_kernel<false>, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out, nullptr);
     MSPL_CHECK_LAUNCH("avgpool3x3s2");
+    return MSPL_OK;
+}
+
+// Partial plane sums per plane written by mspl_avgpool3x3s2_psum_fwd for an (H, W) input (the psum buffer holds N*C times this).
+extern "C" int mspl_avgpool3x3s2_psum_blocks(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return MSPL_ERR_BAD_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return ceil_div(Ho * ceil_div(Wo, 4), 256);
+}
+
+extern "C" int mspl_avgpool3x3s2_psum_fwd(const float* x, int32_t N, int32_t C, int32_t H, int32_t W,
+                                          const mspl_epilogue_t* ep, float* out, float* psum, void* stream) {
+    MSPL_REQUIRE(psum, MSPL_ERR_NULL_POINTER, "avgpool3x3s2_psum: null pointer");
+    RsGeom g; Epi e; int64_t total;
+    const int Ho = H > 0 ? (H - 1) / 2 + 1 : 0, Wo = W > 0 ? (W - 1) / 2 + 1 : 0;
+    if (int rc = resample_common("avgpool3x3s2_psum", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
+    hipLaunchKernelGGL(avgpool3x3s2_kernel<true>, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out, psum);
+    MSPL_CHECK_LAUNCH("avgpool3x3s2_psum");
+    return MSPL_OK;
+}
+
+// EfficientPWConv gate from plane SUMS (mspl_avgpool3x3s2_psum_fwd): gate = sigmoid(W . sums / HW).
+extern "C" int mspl_gate_from_sums_fwd(const float* psum, const float* w, int32_t N, int32_t Cin, int32_t Cout, int32_t nblk,
+                                       int32_t HW, float* gate, void* stream) {
+    MSPL_REQUIRE(psum && w && gate, MSPL_ERR_NULL_POINTER, "gate_from_sums: null pointer");
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && HW > 0 && nblk > 0, MSPL_ERR_BAD_SHAPE,
+                 "gate_from_sums: bad shape N=%d Cin=%d Cout=%d nblk=%d HW=%d", N, Cin, Cout, nblk, HW);
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 4)), dim3(256), 0, (hipStream_t)stream, psum, w, N, Cin, Cout,
+                       nblk, 1.0f / (float)HW, gate);
+    MSPL_CHECK_LAUNCH("gate_from_sums");
     return MSPL_OK;
 }
 
@@ -335,7 +394,7 @@ extern "C" int mspl_gap_gate_fwd(const float* x, const float* w, int32_t N, int3
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)(N * Cin)), dim3(256), 0, s, x, HW, mean_ws);
     MSPL_CHECK_LAUNCH("gap_gate(mean)");
-    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 4)), dim3(256), 0, s, mean_ws, w, N, Cin, Cout, gate);
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)ceil_div(N * Cout, 4)), dim3(256), 0, s, mean_ws, w, N, Cin, Cout, 1, 1.0f, gate);
     MSPL_CHECK_LAUNCH("gap_gate(gate)");
     return MSPL_OK;
 }

@@ -16,6 +16,7 @@ vectors that are cached until a parameter changes.
 """
 import math
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -492,9 +493,38 @@ class DownSampler(nn.Module):
         join(0, (r,))
         scale, shift, rw = self._epilogue_vectors(r is not None)
         ep = Epi(scale, shift, self.act.weight, reinf_r=r, reinf_w=rw)
-        ops.avgpool3x3s2(input, ep, out=(out, 0))
+        # the pool reads `input` completely: it also leaves the plane sums that the decoder's EfficientPWConv gate over the same
+        # tensor needs (remembered per tensor; consumed -- or dropped with the tensor -- by EfficientPWConv.forward)
+        _, sums = ops.avgpool3x3s2(input, ep, out=(out, 0), plane_sums=True)
+        _remember_plane_sums(input, sums)
         ops.conv1x1(cat, self.eesp.conv_1x1_exp.conv.weight, self.eesp.k, ep, out=(out, self.nin))
         return out
+
+
+# Plane sums of a tensor, left behind by the kernel that pooled it (DownSampler) for the gate that needs its mean
+# (EfficientPWConv).  Keyed by the tensor's identity through a weak reference, so an entry can never outlive or be confused
+# with another tensor; one entry per tensor, overwritten per forward.
+_PLANE_SUMS = weakref.WeakKeyDictionary()
+
+
+class _TensorKey(object):
+    __slots__ = ('__weakref__',)
+
+
+def _remember_plane_sums(t, sums):
+    key = getattr(t, '_mspl_key', None)
+    if key is None:
+        key = _TensorKey()
+        t._mspl_key = key                     # lives exactly as long as the tensor object
+    _PLANE_SUMS[key] = (t.data_ptr(), t._version, sums)
+
+
+def _recall_plane_sums(t):
+    key = getattr(t, '_mspl_key', None)
+    hit = _PLANE_SUMS.get(key) if key is not None else None
+    if hit is None or hit[0] != t.data_ptr() or hit[1] != t._version:
+        return None
+    return hit[2]
 
 
 # ------------------------------------------------------------------ decoder units
@@ -639,7 +669,11 @@ class EfficientPWConv(nn.Module):
         if _training_path():
             gate = ag.gap_gate(x, self.wt_layer[1].weight)
             return ag.channel_scale(self.expansion_layer(x), gate)
-        gate = ops.gap_gate(x, self.wt_layer[1].weight)
+        sums = _recall_plane_sums(x)
+        if sums is not None:
+            gate = ops.gate_from_sums(sums, self.wt_layer[1].weight, x.shape[2] * x.shape[3])
+        else:
+            gate = ops.gap_gate(x, self.wt_layer[1].weight)
         return ops.conv3x3(x, self.expansion_layer.cbr[0].weight, self.groups, ep=self.expansion_layer.epi(gate=gate))
 
     def __repr__(self):

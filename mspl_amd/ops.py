@@ -156,14 +156,37 @@ def dense_conv(x, w_packed, ksize, dilation=1, ep=None, out=None):
     return dst
 
 
-def avgpool3x3s2(x, ep=None, out=None):
+def avgpool3x3s2(x, ep=None, out=None, plane_sums=False):
+    """3x3 / stride 2 / pad 1 average pool (+ epilogue).  plane_sums=True: returns (pooled, partial sums (N*C, nblk) of x per
+    plane) -- for a gate over the same tensor (gate_from_sums) without reading it again."""
     x = _f32(x, 'x')
     N, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     dst, coff = _dest(out, (N, C, Ho, Wo), x)
     s, keep = _build(ep, dst, coff, N, C, Ho * Wo)
-    check(lib.mspl_avgpool3x3s2_fwd(_p(x), N, C, H, W, ctypes.byref(s), _p(dst), _stream()))
-    return dst
+    if not plane_sums:
+        check(lib.mspl_avgpool3x3s2_fwd(_p(x), N, C, H, W, ctypes.byref(s), _p(dst), _stream()))
+        return dst
+    nblk = lib.mspl_avgpool3x3s2_psum_blocks(H, W)
+    if nblk <= 0:
+        check(nblk)
+    sums = torch.empty((N * C, nblk), device=x.device, dtype=torch.float32)
+    check(lib.mspl_avgpool3x3s2_psum_fwd(_p(x), N, C, H, W, ctypes.byref(s), _p(dst), _p(sums), _stream()))
+    return dst, sums
+
+
+def gate_from_sums(plane_sums, w, hw):
+    """sigmoid(W . sum_j plane_sums[:, j] / hw) -> (N, Cout): gap_gate without re-reading the tensor."""
+    w = _f32(w, 'w')
+    Cout = w.shape[0]
+    Cin = w.numel() // Cout
+    planes, nblk = plane_sums.shape
+    N = planes // Cin
+    if planes != N * Cin or plane_sums.dtype != torch.float32 or not plane_sums.is_contiguous():
+        raise RuntimeError('mspl_amd: gate_from_sums: sums %s do not match Cin=%d' % (tuple(plane_sums.shape), Cin))
+    gate = torch.empty((N, Cout), device=w.device, dtype=torch.float32)
+    check(lib.mspl_gate_from_sums_fwd(_p(plane_sums), _p(w), N, Cin, Cout, nblk, int(hw), _p(gate), _stream()))
+    return gate
 
 
 def bilinear(x, size, ep=None, out=None, align_corners=True):

@@ -265,3 +265,21 @@ def test_bilinear_align_corners_false(cfg):
     x = rnd(N, C, Hi, Wi, seed=8)
     close(ops.bilinear(x.to(DEV), (Ho, Wo), align_corners=False), F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False),
           atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 16, 24), (1, 3, 15, 21), (2, 4, 9, 8), (1, 2, 1, 7), (16, 8, 144, 240)])
+def test_avgpool_plane_sums_and_gate_from_sums(shape):
+    """The pool that also leaves its input's plane sums, and the gate computed from them (= gap_gate without the second read)."""
+    from mspl_amd import ops
+    x = rnd(*shape, seed=31)
+    xd = x.to(DEV)
+    y, sums = ops.avgpool3x3s2(xd, plane_sums=True)
+    close(y, F.avg_pool2d(x, 3, 2, 1))
+    assert sums.shape[0] == shape[0] * shape[1]
+    torch.testing.assert_close(sums.sum(1).cpu().view(shape[0], shape[1]), x.double().sum((2, 3)).float(), rtol=1e-5, atol=1e-3)
+    w = rnd(6, shape[1], 1, 1, seed=32)
+    g1 = ops.gate_from_sums(sums, w.to(DEV), shape[2] * shape[3])
+    g0 = ops.gap_gate(xd, w.to(DEV))
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-6)
+    y2, sums2 = ops.avgpool3x3s2(xd, plane_sums=True)                      # deterministic: same bits every time
+    assert torch.equal(sums2, sums) and torch.equal(ops.gate_from_sums(sums2, w.to(DEV), shape[2] * shape[3]), g1)
