@@ -35,6 +35,13 @@ void set_error(const char* fmt, ...);
 
 extern std::atomic<int> g_throughput_mode;     // api.hip: mspl_set_throughput_mode
 
+// XCD-contiguous workgroup order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, and each XCD has its own
+// L2: tiles that share halo rows / low-resolution source maps should sit on ONE XCD.  With the grid padded to 8 * per workgroups,
+// physical id b works on logical tile (b % 8) * per + b / 8, so XCD k walks the contiguous logical range [k*per, (k+1)*per).
+// Logical ids >= total do nothing (the whole workgroup leaves: safe before any barrier).
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned per) { return (b & 7u) * per + (b >> 3); }
+static inline unsigned xcd_per(int64_t total) { return (unsigned)((total + 7) / 8); }
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

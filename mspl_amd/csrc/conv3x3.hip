@@ -21,6 +21,7 @@ struct C3Geom {
     int coblks;        // cout_g / COB
     int nvec;          // 16-byte chunks per staged row
     unsigned mag_nvec, mag_ih;   // ceil(2^32 / d): exact division of small counts by mul-hi
+    unsigned xcd_per, total;     // XCD-contiguous tile order (common.hpp): neighbouring tiles share halo rows
 };
 
 template <int STRIDE, int COB>
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     float* tile = smem;                                         // cin_g * IH * IWS
     float* wl = smem + (size_t)g.cin_g * g.IH * g.IWS;          // cout_g * cin_g * 9
 
-    int bid = blockIdx.x;
+    int bid = (int)xcd_contiguous(blockIdx.x, g.xcd_per);
+    if ((unsigned)bid >= g.total) return;
     const int txi = bid % g.tiles_x;  bid /= g.tiles_x;
     const int tyi = bid % g.tiles_y;  bid /= g.tiles_y;
     const int grp = bid % g.G;
@@ -211,7 +213,8 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     g.tiles_y = ceil_div(g.Ho, th);
     const int64_t blocks = (int64_t)g.N * g.G * g.tiles_y * g.tiles_x;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv3x3: grid too large");
-    dim3 grid((unsigned)blocks), blk(256);
+    g.total = (unsigned)blocks; g.xcd_per = xcd_per(blocks);
+    dim3 grid(8u * g.xcd_per), blk(256);
     const size_t lds = lds_of(th);
     switch (cob) {
         case 8: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 8>), grid, blk, lds, s, x, w, g, e, out); break;

@@ -42,6 +42,7 @@ struct Pyr2Geom {
     int boff, woff, dscoff;
     int CPB, cblocks;
     int stop_after;                 // tuning aid (MSPL_PYR_STOP): skip the phases after k; 0 = run everything
+    unsigned xcd_per, total;        // XCD-contiguous tile order (common.hpp): tiles of a plane share halos and the low-res maps
 };
 
 // Table geometry of an up branch with T taps: a table row holds [ky][KS] floats, KS = 4 (T = 3) or 8 (T = 5).
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
     float* wl = smem + g.woff;                      // [nb][9] stage weights, [nb][9] merge weights, [nb][3] BR consts
     float* B = smem + g.boff;                       // nb x (TH+2) x BW, col q <-> image col x0-1+q
     int* bdesc = reinterpret_cast<int*>(smem + g.dscoff);   // per branch: kind, slot, aoff, coff, doff, eoff
-    int bid = blockIdx.x;
+    int bid = (int)xcd_contiguous(blockIdx.x, g.xcd_per);
+    if ((unsigned)bid >= g.total) return;
     const int txi = bid % g.tiles_x;  bid /= g.tiles_x;
     const int tyi = bid % g.tiles_y;  bid /= g.tiles_y;
     const int cb = bid % g.cblocks;
@@ -550,7 +552,8 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
     g.stop_after = dbg_stop;
     const int64_t blocks = (int64_t)N * g.cblocks * g.tiles_y * g.tiles_x;
     if (blocks >= (1ll << 31)) return 1;
-    const dim3 grid((unsigned)blocks), blk(256);
+    g.total = (unsigned)blocks; g.xcd_per = xcd_per(blocks);
+    const dim3 grid(8u * g.xcd_per), blk(256);
 #define MSPL_P2_LAUNCH(A, B) hipLaunchKernelGGL((pyrpool_sep_kernel<A, B>), grid, blk, lds, stream, x, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out)
     if (taps[0] == 3 && taps[1] == 3) MSPL_P2_LAUNCH(3, 3);
     else if (taps[0] == 3) MSPL_P2_LAUNCH(3, 5);
