@@ -25,6 +25,7 @@ struct PrepGeom {
     int boff;                                     // window-bound tables
     int csoff;                                    // column sums of the large-window branches: [band rows + 2][WS]
     int stop;                                     // tuning aid (MSPL_PREP_STOP): return after phase k
+    unsigned xcd_per, total;                      // XCD-contiguous order (common.hpp): the bands of a plane overlap by their halo rows
 };
 
 __device__ __host__ __forceinline__ int pp_s(int o, int I, int O) { return (int)(((unsigned)o * (unsigned)I) / (unsigned)O); }
@@ -45,8 +46,10 @@ __device__ __host__ __forceinline__ void pp_band_rows(const PrepGeom& g, int ban
 
 __global__ __launch_bounds__(256) void pyr_down_prep_kernel(const float* __restrict__ x, PrepGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int band = blockIdx.x % g.S;
-    const int plane = blockIdx.x / g.S;           // n * P + c
+    const unsigned bid = xcd_contiguous(blockIdx.x, g.xcd_per);
+    if (bid >= g.total) return;
+    const int band = bid % g.S;
+    const int plane = bid / g.S;                  // n * P + c
     const int c = plane % g.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xp = x + (size_t)plane * g.h * g.w;
@@ -268,7 +271,8 @@ extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int3
     MSPL_REQUIRE(lds > 0, MSPL_ERR_UNSUPPORTED, "pyr_down_prep: no row band of a %dx%d map fits LDS (see mspl_pyr_down_prep_lds_bytes)", h, w);
     const int64_t blocks = planes * g.S;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "pyr_down_prep: grid too large");
-    hipLaunchKernelGGL(pyr_down_prep_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, g);
+    g.total = (unsigned)blocks; g.xcd_per = xcd_per(blocks);
+    hipLaunchKernelGGL(pyr_down_prep_kernel, dim3(8u * g.xcd_per), dim3(256), lds, (hipStream_t)stream, x, g);
     MSPL_CHECK_LAUNCH("pyr_down_prep");
     return MSPL_OK;
 }
