@@ -77,7 +77,7 @@ def cpu_baseline(sd, shape, seconds_budget=20.0):
         one()
         n += nb
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 64:
+        if el > seconds_budget or n >= 192:          # ~10 s of wall time on 16 host cores
             break
     return {'value': round(n / el, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': '%d images (batches of %d, %dx%d), torch-CPU oracle, %d threads' % (n, nb, shape[2], shape[3], cores)}
