@@ -393,6 +393,38 @@ def espdnetue_seg2(args, load_entire_weights=False, fix_pyr_plane_proj=False):
     return model
 
 
+def espdnetue_seg(args, load_entire_weights=False):
+    """espdnet_ue.py:384-452, the older loader kept beside espdnetue_seg2: pyr_plane_proj = min(classes//2, 16) (no
+    fix_pyr_plane_proj), load_entire_weights takes every key the model has WITHOUT a shape check (a mismatching checkpoint
+    raises in load_state_dict, like the reference), and the depth refill needs 'level1.conv.weight' (KeyError otherwise)."""
+    model = ESPDNetwithUncertaintyEstimation(args, classes=args.classes, dataset=args.dataset,
+                                             dense_fuse=args.dense_fuse, trainable_fusion=args.trainable_fusion)
+    weights = args.weights
+    if weights:
+        pretrained = _load_file(weights)
+        if load_entire_weights:
+            model_dict = model.state_dict()
+            overlap = {k: v for k, v in pretrained.items() if k in model_dict}
+            if len(overlap) == 0:
+                raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+            model_dict.update(overlap)
+            model.load_state_dict(model_dict)
+        else:
+            base_dict = model.base_net.state_dict()
+            overlap = {k.replace('base_net.', ''): v for k, v in pretrained.items()
+                       if k.replace('base_net.', '') in base_dict}
+            if len(overlap) == 0:
+                raise RuntimeError('No overlaping weights between model file and pretrained weight file. Please check')
+            base_dict.update(overlap)
+            model.base_net.load_state_dict(base_dict)
+        d_dict = model.depth_base_net.state_dict()
+        overlap = {k.lstrip('base_net.'): v for k, v in pretrained.items() if k.lstrip('base_net.') in d_dict}
+        overlap['level1.conv.weight'] = torch.mean(overlap['level1.conv.weight'], dim=1, keepdim=True)
+        d_dict.update(overlap)
+        model.depth_base_net.load_state_dict(d_dict)
+    return model
+
+
 def espnetv2_seg(args):
     """model/segmentation/espnetv2.py:170-198: only base_net.* keys are taken from the file."""
     model = ESPNetv2Segmentation(args, classes=args.classes, dataset=args.dataset)

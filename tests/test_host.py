@@ -148,6 +148,100 @@ def test_dropin_aliases():
     assert NIDLoss(image_bin=16, label_bin=5).K == 16          # constructible without a GPU (uest_seg_multi_os.py:514)
 
 
+def _purge_reference_names():
+    import sys
+    for n in [k for k in sys.modules if k.split('.')[0] in ('nn_layers', 'model', 'loss_fns', 'data_loader', 'utilities',
+                                                             'transforms', '_mspl_reference')]:
+        del sys.modules[n]
+
+
+def test_dropin_overlays_real_modules(tmp_path, monkeypatch):
+    """install_dropin() must not hide the other names of a module it aliases (uest_seg_multi_os.py:377 imports
+    GreenhouseRGBDSegmentation and GREENHOUSE_CLASS_LIST from the module whose LUTs are aliased; :31-46, :556-559).  A
+    throw-away package tree stands in for the reference: its own names pass through, conflicting names lose to the HIP-backed
+    ones, and a real module is not executed until one of its own names is asked for."""
+    import sys
+    tree = {
+        'data_loader/__init__.py': '',
+        'data_loader/segmentation/__init__.py': '',
+        'data_loader/segmentation/greenhouse.py':
+            'import builtins\nbuiltins._mspl_fake_greenhouse_runs = getattr(builtins, "_mspl_fake_greenhouse_runs", 0) + 1\n'
+            'GREENHOUSE_CLASS_LIST = ["a", "b", "c"]\nid_camvid_to_greenhouse = "CONFLICT"\n'
+            'class GreenhouseRGBDSegmentation:\n    tag = "fake dataset"\n',
+        'data_loader/segmentation/camvid.py': 'CAMVID = 1\n',
+        'nn_layers/__init__.py': '',
+        'nn_layers/espnet_utils.py': 'class CDilatedB:\n    pass\nclass CBR:\n    fake = True\n',
+        # a real module that star-imports an aliased one (nn_layers/eesp.py:3 does): sees HIP names and pass-through names
+        'nn_layers/eesp.py': 'from nn_layers.espnet_utils import *\nclass EESP:\n    fake = True\n'
+                             'SEEN = (CBR, CDilatedB)\nOTHER = 7\n',
+        'nn_layers/untouched.py': 'from nn_layers.espnet_utils import CBR, CDilatedB\n',
+        'loss_fns/__init__.py': '',
+        'loss_fns/segmentation_loss.py': 'class SelectiveBCE:\n    pass\nclass SoftArgMax:\n    pass\n',
+    }
+    for rel, src in tree.items():
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(src)
+    import builtins
+    monkeypatch.setattr(builtins, '_mspl_fake_greenhouse_runs', 0, raising=False)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    _purge_reference_names()
+    try:
+        mspl_amd.install_dropin()
+        from data_loader.segmentation.greenhouse import id_camvid_to_greenhouse, id_forest_to_greenhouse
+        assert id_camvid_to_greenhouse is uest.id_camvid_to_greenhouse and id_forest_to_greenhouse is uest.id_forest_to_greenhouse
+        assert builtins._mspl_fake_greenhouse_runs == 0, 'the real module ran although only aliased names were imported'
+        from data_loader.segmentation.greenhouse import GREENHOUSE_CLASS_LIST, GreenhouseRGBDSegmentation   # :377
+        assert GREENHOUSE_CLASS_LIST == ['a', 'b', 'c'] and GreenhouseRGBDSegmentation.tag == 'fake dataset'
+        assert builtins._mspl_fake_greenhouse_runs == 1
+        import data_loader.segmentation.greenhouse as gh
+        assert gh.id_camvid_to_greenhouse is uest.id_camvid_to_greenhouse           # the HIP-side name wins the conflict
+        from data_loader.segmentation.greenhouse import GREENHOUSE_CLASS_LIST as again   # noqa: F401
+        assert builtins._mspl_fake_greenhouse_runs == 1, 'the real module must load once'
+        from data_loader.segmentation.camvid import CAMVID              # sibling modules stay importable
+        assert CAMVID == 1
+        from nn_layers.espnet_utils import CBR, CDilatedB
+        assert CBR is layers.CBR and CDilatedB.__module__ == '_mspl_reference.nn_layers.espnet_utils'
+        import nn_layers.eesp as eesp
+        assert eesp.EESP is layers.EESP and eesp.OTHER == 7
+        assert eesp.SEEN[0] is layers.CBR and eesp.SEEN[1] is CDilatedB   # the real module's star import goes through the alias
+        import nn_layers.untouched                                         # noqa: F401  (a non-aliased real module, same imports)
+        from loss_fns.segmentation_loss import PixelwiseKLD, SelectiveBCE, SoftArgMax   # noqa: F401
+        from mspl_amd import losses
+        assert PixelwiseKLD is losses.PixelwiseKLD
+        with pytest.raises(ImportError):
+            from loss_fns.segmentation_loss import NoSuchLoss              # noqa: F401
+        with pytest.raises(AttributeError):
+            gh.no_such_name
+        from model.segmentation.espdnet_ue import espdnetue_seg            # espdnet_ue.py:384; no real `model` package here
+        assert espdnetue_seg is models.espdnetue_seg
+        with pytest.raises(ImportError):
+            from model.segmentation.espdnet_ue import something_else       # noqa: F401
+    finally:
+        _purge_reference_names()
+        if hasattr(builtins, '_mspl_fake_greenhouse_runs'):
+            monkeypatch.delattr(builtins, '_mspl_fake_greenhouse_runs')
+
+
+def test_espdnetue_seg_loader(tmp_path):
+    """espdnet_ue.py:384-452: the older factory (pyr_plane_proj = min(classes//2, 16); whole-file load without a shape filter)."""
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000, classes=5, dataset='greenhouse', dense_fuse=False,
+                           trainable_fusion=True, weights='')
+    m = models.espdnetue_seg(a)
+    assert m.bu_dec_l1.proj_planes == 2                   # min(5 // 2, 16)
+    sd = synth_state_dict(m.state_dict(), 5)
+    path = str(tmp_path / 'ck.pth')
+    torch.save(sd, path)
+    a.weights = path
+    m2 = models.espdnetue_seg(a, load_entire_weights=True)
+    got = m2.state_dict()
+    assert torch.equal(got['bu_dec_l1.merge_layer.3.weight'], sd['bu_dec_l1.merge_layer.3.weight'])
+    assert torch.equal(got['depth_base_net.level1.conv.weight'], sd['base_net.level1.conv.weight'].mean(1, keepdim=True))
+    torch.save({k: v for k, v in sd.items() if k != 'base_net.level1.conv.weight'}, path)
+    with pytest.raises(KeyError):
+        models.espdnetue_seg(a)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'mspl_amd')
     for dirpath, _, files in os.walk(pkg):
