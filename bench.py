@@ -210,7 +210,47 @@ def loader_io_rate(dev, iters=20):
     return out
 
 
-def train_step_rate(dev, iters=10):
+def three_source_rate(dev, iters=20):
+    """BASELINE configs[2], label half: three ESPDNet-UE source models (13 / 20 / 5 classes: CamVid, Cityscapes, Forest shapes)
+    on the same 16 x 3 x 256 x 480 batch -> id LUTs -> merge_outputs('all') -> 5-bin histogram (uest_seg_multi_os.py:898-921),
+    hipGraph replay, with one and with three batches in flight.  Extra field."""
+    import torch
+    from mspl_amd import models, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    x = torch.randn(BATCH, 3, 256, 480, generator=torch.Generator().manual_seed(21)).to(dev)
+    nets, datas = [], ['camvid', 'cityscapes', 'forest']
+    for i, (C, ds) in enumerate([(13, 'camvid'), (20, 'city'), (5, 'forest')]):
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=C, dataset=ds, fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(m.state_dict(), i))
+        nets.append(m)
+    out = {'workload': 'BASELINE configs[2] label half: 3 ESPDNet-UE s=2.0 sources (C=13/20/5) -> LUT -> merge(all) -> histogram, '
+                       '16 x 3 x 256 x 480 fp32, hipGraph replay', 'unit': 'images/s'}
+    for depth in (1, 3):
+        plp = uest.PipelinedLabelPass(lambda: uest.PseudoLabelPass(nets, datas, merge_label_policy='all', device=dev, use_graph=True),
+                                      depth=depth, device=dev)
+        for _ in range(2 * depth + 2):
+            plp(x)
+        list(plp.flush())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            plp(x)
+        list(plp.flush())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out['in_flight_%d' % depth] = {'value': round(BATCH / dt, 1), 'ms_per_batch': round(dt * 1e3, 3)}
+        hist = plp.hist.cpu().tolist()
+        del plp
+    out['value'] = out['in_flight_3']['value']
+    out['histogram_pixels_per_batch'] = int(sum(hist)) // (iters + 2 * 3 + 2)
+    # SURVEY 8(d): 951 MB of algorithmic activation traffic per image for the three forwards + merge at 256x480
+    out['path_roofline'] = {'algorithmic_bytes_per_image': 951e6, 'achieved': round(951e6 * out['value'] / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                            'unit': 'GB/s', 'frac': round(951e6 * out['value'] / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def train_step_rate(dev, iters=10, world=1, rank=0):
     """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
     KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as one hipGraph replay
     (+ the Adam kernel) per step.  Extra field; `value` stays the label-pass metric."""
@@ -221,21 +261,41 @@ def train_step_rate(dev, iters=10):
     m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
     m.load_state_dict(synth_state_dict(m.state_dict(), 9))
     m = m.to(dev).eval()
-    g = torch.Generator().manual_seed(7)
+    g = torch.Generator().manual_seed(7 + rank)           # every rank trains on its own shard (data parallel)
     x = torch.randn((BATCH, 3, 256, 480), generator=g).to(dev)
     y = torch.randint(0, 5, (BATCH, 256, 480), generator=g).to(dev)
     step = training.GraphedTrainStep(m, x, y, torch.ones(5), ignore_idx=4)
+    import torch.distributed as dist
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
     for _ in range(2):
         step(x, y)
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(iters):
         loss = step(x, y)
-    torch.cuda.synchronize()
+    fence()
     dt = (time.perf_counter() - t0) / iters
-    return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
-            'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16 x 3 x 256 x 480 fp32, hipGraph replay + Adam kernel',
-            'loss_finite': bool(torch.isfinite(loss))}
+    in_sync = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # data-parallel invariant: identical initial weights + averaged gradients => identical weights on every rank
+        chk = step.optimizer.flat_p.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((hi - lo).abs().item() == 0.0)
+    return {'value': round(BATCH * world / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
+            'n_gpus': world, 'global_batch': BATCH * world,
+            'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay + ' +
+                        ('one flat-bucket gradient all-reduce (%d floats, RCCL) + ' % step.optimizer.flat_g.numel() if world > 1 else '') +
+                        'Adam kernel',
+            'weights_identical_across_ranks': in_sync, 'loss_finite': bool(torch.isfinite(loss))}
 
 
 def supervised_step_rate(dev, iters=6):
@@ -275,6 +335,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the extra train-step field')
+    ap.add_argument('--no-three-source', action='store_true', help='skip the extra 3-source label pass field (BASELINE configs[2])')
     ap.add_argument('--no-io', action='store_true', help='skip the extra loader/writer field (SURVEY 8f-1)')
     ap.add_argument('--no-aspp', action='store_true', help='skip the extra ASPP-head field (BASELINE configs[4])')
     ap.add_argument('--no-bs64', action='store_true', help='skip the extra batch-64 K2 field (use for rocprofv3 --stats runs: '
@@ -283,19 +344,39 @@ def main():
     ap.add_argument('--in-flight', type=int, default=3, help='label passes (independent batches) in flight on the GPU; 1 = one '
                     'hipGraph replayed back to back on one stream (use it for rocprofv3 --stats runs: overlapping launches stretch '
                     'each other and the per-kernel averages stop describing the kernels)')
+    ap.add_argument('--profile-pass', action='store_true', help='only the timed label passes: no K2 re-issues, no extra fields '
+                    '(for rocprofv3 --kernel-trace --stats: the CSV then holds in-pass launches only; tools/per_kernel.py)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one fresh process per GPU ourselves (torch.distributed.run, the
+        # driver's own launch line) BEFORE this process touches the GPU, hand its output through and exit with its code.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # "nccl" is RCCL on ROCm.  MSPL_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (the
+    # ranks then share devices round-robin; the numbers mean nothing, the control flow is the same).
+    backend = os.environ.get('MSPL_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1) if (world > 1 and backend != 'nccl') else (local_rank if world > 1 else 0)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL; used for barrier + timing only
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend, rank=rank, world_size=world)   # barrier, max-over-ranks timing, gradient all-reduce
+    dev = torch.device('cuda', dev_index)
     torch.cuda.set_device(dev)
 
     import mspl_amd
@@ -343,6 +424,24 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if args.profile_pass:
+        if rank == 0:
+            print(json.dumps({'metric': 'profile-pass (no roofline / extras)', 'value': round(BATCH * world * args.steps / elapsed, 2),
+                              'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'batches_in_flight': depth}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # N > 1: the data-parallel train step on every rank (configs[3]: the gradient all-reduce over xGMI is the path's only
+    # data collective).  Every rank takes part; a failure is reported in the field instead of costing the label-pass line.
+    train_multi = None
+    if world > 1 and not args.no_train:
+        try:
+            train_multi = train_step_rate(dev, world=world, rank=rank)
+        except Exception as e:      # noqa: BLE001
+            train_multi = {'error': repr(e)[:300]}
 
     # the same K steps with ONE pass in flight (lane 0 alone, back to back): the per-batch latency, reported beside the value
     single = None
@@ -433,16 +532,21 @@ def main():
     # HBM bytes per K2 launch from the PMC counters (FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
     # the MI355X guide prescribes; tools/k2_traffic.py writes the summary).  bench.py cannot run rocprofv3 on itself.
     k2_traffic, k2_traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_k2_hbm_traffic.json')
-    if os.path.exists(tpath):
-        k2_traffic = int(json.load(open(tpath))['avg_traffic_bytes_per_launch'])
-        k2_traffic_src = 'profiles/r01_k2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
+    def newest(names):
+        for n in names:
+            if os.path.exists(os.path.join(ROOT, 'profiles', n)):
+                return n
+        return None
+    tname = newest(['r02_k2_hbm_traffic.json', 'r01_k2_hbm_traffic.json'])
+    if tname:
+        k2_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', tname)))['avg_traffic_bytes_per_launch'])
+        k2_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % tname
     # measured HBM bytes of one whole pass (every kernel; tools/pass_traffic.py, same PMC recipe)
     path_traffic, path_traffic_src = None, None
-    ppath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_m_pass_hbm_traffic.json')
-    if os.path.exists(ppath):
-        path_traffic = int(json.load(open(ppath))['total_MB_per_image'] * 1e6)
-        path_traffic_src = 'profiles/r01_m_pass_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)'
+    pname = newest(['r02_pass_hbm_traffic.json', 'r01_m_pass_hbm_traffic.json'])
+    if pname:
+        path_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', pname)))['total_MB_per_image'] * 1e6)
+        path_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)' % pname
     avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
     achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
 
@@ -485,6 +589,15 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        pk = os.path.join(ROOT, 'profiles', 'r02_per_kernel.json')
+        if os.path.exists(pk):
+            # per-kernel table of one label pass (us, MB, fraction of the HBM roof), from a rocprofv3 --kernel-trace --stats run of
+            # `bench.py --profile-pass --in-flight 1` (no K2 re-issues in it) + the PMC traffic passes; tools/per_kernel.py
+            out['per_kernel'] = json.load(open(pk))
+        if train_multi is not None:
+            out['train_step'] = train_multi
+        if world == 1 and not args.no_three_source:
+            out['three_source'] = three_source_rate(dev)
         if world == 1 and not args.no_train:
             out['train_step'] = train_step_rate(dev)
             out['supervised_step'] = supervised_step_rate(dev)

@@ -189,6 +189,16 @@ int mspl_label_epilogue_fwd(const float* main, const float* aux, int32_t N, int3
                             const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
                             float* main_up, float* aux_up, void* stream);
 
+/* K8+K9 with the class histogram of the labels it writes: the single-source label pass (uest_seg_multi_os.py:785-815,
+ *     one model relabelling its own domain) in ONE launch -- what label_epilogue + merge_labels(S=1, thresh=1) computed in two.
+ *     hist: num_classes (<= 32) uint64 bins, accumulated into (caller zeroes); labels >= num_classes are not counted.
+ *     C <= 24; labels required; kld optional.
+ */
+int mspl_label_epilogue_hist_fwd(const float* main, const float* aux, int32_t N, int32_t C,
+                                 int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                                 const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
+                                 int32_t num_classes, void* stream);
+
 /* K10  cross-source label merge + class histogram.  Replaces uest_seg_multi_os.py:695-718
  *     (merge_outputs) and :919-921.  src[s]: npix uint8 class maps (already in target ids),
  *     S <= 8, num_classes <= 32.  out[p] = first-max argmax_c count_c(p), or `fill` when the

@@ -33,6 +33,14 @@ void set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// In-kernel phase stamps (MSPL_PW_STAMP / MSPL_DW_STAMP) are a tuning aid with a static hipMalloc and a blocking hipMemcpy in
+// the launcher: they would break a stream capture, so release builds compile the switch out (make STAMPS=1 brings it back).
+#ifdef MSPL_DEBUG_STAMPS
+#define MSPL_STAMP_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define MSPL_STAMP_ENV(name) 0
+#endif
+
 extern std::atomic<int> g_throughput_mode;     // api.hip: mspl_set_throughput_mode
 
 // XCD-contiguous workgroup order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, and each XCD has its own

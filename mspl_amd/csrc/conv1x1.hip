@@ -786,7 +786,7 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     const dim3 grid((unsigned)blocks), blk(256);
     {
         static unsigned long long* stamp_buf = nullptr;
-        static const int dbg_stamp = getenv("MSPL_PW_STAMP") ? atoi(getenv("MSPL_PW_STAMP")) : 0;
+        static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_PW_STAMP");
         if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)5 * 65536 * sizeof(unsigned long long));
         g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
     }
@@ -993,7 +993,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     const int64_t blocks = (int64_t)groups * g.mblocks * g.pgroups;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv1x1: grid too large");
     static unsigned long long* stamp_buf = nullptr;
-    static const int dbg_stamp = getenv("MSPL_PW_STAMP") ? atoi(getenv("MSPL_PW_STAMP")) : 0;
+    static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_PW_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)5 * 65536 * sizeof(unsigned long long));
     g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
     dim3 grid((unsigned)blocks), blk(256);

@@ -269,7 +269,7 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
     static const int dbg_cp = getenv("MSPL_DW_CP") ? atoi(getenv("MSPL_DW_CP")) : 0;
     g.nocompute = dbg_nc;
     static unsigned long long* stamp_buf = nullptr;
-    static const int dbg_stamp = getenv("MSPL_DW_STAMP") ? atoi(getenv("MSPL_DW_STAMP")) : 0;
+    static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_DW_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)4 * 65536 * sizeof(unsigned long long));
     // Tile = CP planes x one band.  Small tiles -> many workgroups per CU in different phases.
     const size_t lds_budget = (size_t)(dbg_lds > 0 ? dbg_lds : 24) * 1024;

@@ -105,14 +105,25 @@ __global__ __launch_bounds__(256) void label_epilogue_kernel(const float* __rest
 template <int CMAX>
 __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
                                                                  LeGeom g, const uint8_t* __restrict__ lut,
-                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld) {
+                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld,
+                                                                 unsigned long long* __restrict__ hist, int ncls) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     // XCD-aware row order: workgroups are dealt to the 8 XCDs round-robin by linear id, and neighbouring output rows read the
     // same source rows -- in natural order every source row was fetched into four different L2s (PMC: 189 MB read for 36 MB of
     // logits).  Row slot s = blockIdx.y maps to row (s % 4) * ceil(H/4) + s / 4, so each XCD (pair) walks one contiguous quarter.
     const int rq = (g.H + 3) >> 2;
     const int y = (int)(blockIdx.y & 3) * rq + (int)(blockIdx.y >> 2), n = blockIdx.z;
-    if (x >= g.W || y >= g.H) return;
+    if (y >= g.H) return;                                                    // uniform: the whole workgroup leaves
+    // class histogram of the labels this workgroup writes (the single-source pass: uest_seg_multi_os.py:785-815 counts the
+    // label map it has just produced -- no separate merge launch): one ballot per class and wave, LDS sum, one 64-bit atomic
+    // per non-empty class and workgroup.  Labels >= ncls are not counted.
+    __shared__ unsigned int sh_hist[32];
+    if (hist) {
+        if (threadIdx.x < 32) sh_hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    int my_label = -1;
+    if (x < g.W) {
     int my0, my1, mx0, mx1;  float mwy0, mwy1, mwx0, mwx1;
     bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);                      // uniform
     bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __
         for (int c = 0; c < CMAX; ++c) {
             if (c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
         }
-        labels[pix] = lut ? lut[best] : (uint8_t)best;
+        my_label = lut ? lut[best] : best;
+        labels[pix] = (uint8_t)my_label;
     }
     if (kld) {
         float k = 0.f;
@@ -177,6 +189,15 @@ __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __
             k = T1 / S1 - (M1 + __logf(S1)) + (M2 + __logf(S2));
         }
         kld[pix] = k;
+    }
+    }   // x < W
+    if (hist) {
+        for (int c = 0; c < ncls; ++c) {
+            const unsigned long long b = __ballot(my_label == c);
+            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&sh_hist[c], (unsigned)__popcll(b));
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ncls && sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
     }
 }
 
@@ -318,10 +339,34 @@ __global__ __launch_bounds__(256) void miou_areas_kernel(const float* __restrict
 
 using namespace mspl;
 
+static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, int32_t C,
+                               int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                               const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
+                               float* main_up, float* aux_up, unsigned long long* hist, int32_t ncls, void* stream);
+
 extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
                                        int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
                                        const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
                                        float* main_up, float* aux_up, void* stream) {
+    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, prob, kld, main_up, aux_up, nullptr, 0, stream);
+}
+
+extern "C" int mspl_label_epilogue_hist_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
+                                            int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                                            const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
+                                            int32_t num_classes, void* stream) {
+    MSPL_REQUIRE(labels && hist, MSPL_ERR_NULL_POINTER, "label_epilogue_hist: labels and hist are required");
+    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 32, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d classes (1..32)", num_classes);
+    MSPL_REQUIRE(C <= 24, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d logit channels (the fused form holds <= 24 in registers; "
+                 "use label_epilogue + merge_labels)", C);
+    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, nullptr, kld, nullptr, nullptr, hist, num_classes,
+                               stream);
+}
+
+static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, int32_t C,
+                               int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                               const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
+                               float* main_up, float* aux_up, unsigned long long* hist, int32_t ncls, void* stream) {
     MSPL_REQUIRE(mainp, MSPL_ERR_NULL_POINTER, "label_epilogue: null main logits");
     MSPL_REQUIRE(labels || prob || kld || main_up || aux_up, MSPL_ERR_NULL_POINTER, "label_epilogue: no output requested");
     MSPL_REQUIRE(N > 0 && C > 0 && Hm > 0 && Wm > 0 && H > 0 && W > 0 && (!aux || (Ha > 0 && Wa > 0)),
@@ -337,12 +382,13 @@ extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int
     if (!prob && !main_up && !aux_up && C <= 24 && H <= 65535 && N <= 65535 &&
         (int64_t)N * C * Hm * Wm < (1ll << 31) && (int64_t)N * C * (int64_t)Ha * Wa < (1ll << 31)) {
         const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)(4 * ceil_div(H, 4)), (unsigned)N);     // row slots: see the kernel
-        if (C <= 8) hipLaunchKernelGGL(label_epilogue_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
-        else if (C <= 16) hipLaunchKernelGGL(label_epilogue_reg_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
-        else hipLaunchKernelGGL(label_epilogue_reg_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld);
+        if (C <= 8) hipLaunchKernelGGL(label_epilogue_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
+        else if (C <= 16) hipLaunchKernelGGL(label_epilogue_reg_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
+        else hipLaunchKernelGGL(label_epilogue_reg_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
         MSPL_CHECK_LAUNCH("label_epilogue");
         return MSPL_OK;
     }
+    MSPL_REQUIRE(!hist, MSPL_ERR_BAD_SHAPE, "label_epilogue_hist: shape outside the fused form (N=%d C=%d H=%d)", N, C, H);
     hipLaunchKernelGGL(label_epilogue_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        mainp, aux, g, lut, labels, prob, kld, main_up, aux_up, total);
     MSPL_CHECK_LAUNCH("label_epilogue");

@@ -49,36 +49,60 @@ def gather_lists(local_items):
     return merged
 
 
+def all_reduce_mean(flat):
+    """Average a flat tensor over the ranks in place (sum / world): the train step's only collective, RCCL over xGMI on
+    GPUs.  Equals the reference's mean of per-replica mean losses (utilities/train_eval_seg.py:202) for equal shards."""
+    _, w = world()
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(w)
+    return flat
+
+
+def barrier():
+    if world()[1] > 1:
+        dist.barrier()
+
+
 class GradBucket:
-    """Flat fp32 gradient bucket over the parameters that receive gradients.
+    """Flat fp32 bucket over the parameters that receive gradients -- the ONE implementation of the flat layout: FlatAdam and
+    FlatSGD (mspl_amd/training.py, supervised.py) build their buffers through it.
 
-    Call after the first backward (which reveals the unused parameters, exactly the set torch.optim.Adam skips):
-    `GradBucket(model.parameters())`.  The parameters' .grad tensors become views into one contiguous buffer, so
-    `all_reduce()` is a single collective (RCCL over xGMI on GPUs) and the optimizer can run on the flat views.
-    """
+    Call after the first backward (which reveals the unused parameters, exactly the set torch.optim skips):
+    `GradBucket(model.parameters())`.  The parameters' .grad tensors become views into one contiguous buffer `flat`, so
+    `all_reduce()` is a single collective and the optimizer kernel runs on the flat views.  With `with_params=True` the
+    parameters' .data are re-pointed into a second flat buffer `flat_p` in the same layout (values preserved).  `params`
+    keeps the order given (FlatSGD lays its learning-rate groups out one after the other)."""
 
-    def __init__(self, params):
+    def __init__(self, params, with_params=False):
         self.params = [p for p in params if p.requires_grad and p.grad is not None]
         if not self.params:
             raise RuntimeError('GradBucket: no parameter has a gradient yet (run one backward first)')
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev) if with_params else None
+        self.offsets = []
         off = 0
-        for p in self.params:
-            k = p.numel()
-            view = self.flat[off:off + k].view_as(p)
-            view.copy_(p.grad)
-            p.grad = view
-            off += k
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                view = self.flat[off:off + k].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+                if with_params:
+                    pv = self.flat_p[off:off + k].view_as(p)
+                    pv.copy_(p.data)
+                    p.data = pv
+                self.offsets.append(off)
+                off += k
+
+    def numel(self):
+        return self.flat.numel()
 
     def zero(self):
         self.flat.zero_()
 
     def all_reduce(self):
-        """Average the gradients over the ranks (sum / world): equals the reference's mean of per-replica mean losses."""
-        _, w = world()
-        if w > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(w)
-        return self.flat
+        """Average the gradients over the ranks (sum / world)."""
+        return all_reduce_mean(self.flat)

@@ -346,6 +346,30 @@ def label_epilogue(main, aux, size, lut=None, want_labels=True, want_prob=False,
     return res
 
 
+def label_epilogue_hist(main, aux, size, hist, num_classes, lut=None, want_kld=False):
+    """K8+K9 + class histogram in one launch (single-source pass).  Requires C <= min(24, num_classes) so that every label is a
+    counted class -- then it equals label_epilogue followed by merge_labels(S=1, thresh=1).  Returns dict(labels[, kld])."""
+    main = _f32(main, 'main')
+    N, C, Hm, Wm = main.shape
+    Ha = Wa = 0
+    if aux is not None:
+        aux = _f32(aux, 'aux')
+        if aux.shape[0] != N or aux.shape[1] != C:
+            raise RuntimeError('mspl_amd: aux logits %s do not match main %s' % (tuple(aux.shape), tuple(main.shape)))
+        Ha, Wa = aux.shape[2:]
+    H, W = int(size[0]), int(size[1])
+    if hist.dtype != torch.int64 or not hist.is_cuda or hist.numel() < num_classes:
+        raise RuntimeError('mspl_amd: hist must be a CUDA int64 tensor with >= num_classes entries')
+    if lut is not None and (lut.dtype != torch.uint8 or not lut.is_cuda or lut.numel() < C):
+        raise RuntimeError('mspl_amd: lut must be a CUDA uint8 tensor with >= %d entries' % C)
+    res = {'labels': torch.empty((N, H, W), device=main.device, dtype=torch.uint8)}
+    if want_kld:
+        res['kld'] = torch.empty((N, H, W), device=main.device, dtype=torch.float32)
+    check(lib.mspl_label_epilogue_hist_fwd(_p(main), _p(aux), N, C, Hm, Wm, Ha, Wa, H, W, _p(lut), _p(res['labels']),
+                                           _p(res.get('kld')), _p(hist), int(num_classes), _stream()))
+    return res
+
+
 def merge_labels(sources, num_classes, thresh, fill=4, hist=None):
     """K10.  sources: list of uint8 CUDA tensors of identical shape.  hist: uint64-as-int64 CUDA tensor of
     num_classes entries, accumulated into (caller zeroes), or None."""

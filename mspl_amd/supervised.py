@@ -46,23 +46,14 @@ class FlatSGD:
             flat += ps
         if not flat:
             raise RuntimeError('FlatSGD: run one backward before constructing the optimizer (no parameter has a gradient)')
-        dev = flat[0].device
-        n = sum(p.numel() for p in flat)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
-        self.buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bucket = mdist.GradBucket(flat, with_params=True)            # the flat layout shared with FlatAdam and the all-reduce
+        self.flat_p, self.flat_g = self.bucket.flat_p, self.bucket.flat
+        self.buf = torch.zeros_like(self.flat_p)
         off = 0
-        with torch.no_grad():
-            for g in self.param_groups:
-                g['_lo'] = off
-                for p in g['params']:
-                    k = p.numel()
-                    pv, gv = self.flat_p[off:off + k].view_as(p), self.flat_g[off:off + k].view_as(p)
-                    pv.copy_(p.data)
-                    gv.copy_(p.grad)
-                    p.data, p.grad = pv, gv
-                    off += k
-                g['_hi'] = off
+        for g in self.param_groups:
+            g['_lo'] = off
+            off += sum(p.numel() for p in g['params'])
+            g['_hi'] = off
         self.params = flat
         self.step_count = 0
 
@@ -70,10 +61,7 @@ class FlatSGD:
         self.flat_g.zero_()
 
     def all_reduce_grads(self):
-        _, w = mdist.world()
-        if w > 1:
-            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM)
-            self.flat_g.div_(w)
+        self.bucket.all_reduce()
 
     def step(self):
         first = 1 if self.step_count == 0 else 0

@@ -42,25 +42,14 @@ class FlatAdam:
     .data and .grad are re-pointed to views of the flat buffers (values preserved)."""
 
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params if p.requires_grad and p.grad is not None]
-        if not self.params:
+        try:
+            self.bucket = mdist.GradBucket(params, with_params=True)      # the flat layout shared with FlatSGD and the all-reduce
+        except RuntimeError:
             raise RuntimeError('FlatAdam: run one backward before constructing the optimizer (no parameter has a gradient)')
-        dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.empty(n, dtype=torch.float32, device=dev)
-        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        with torch.no_grad():
-            for p in self.params:
-                k = p.numel()
-                pv, gv = self.flat_p[off:off + k].view_as(p), self.flat_g[off:off + k].view_as(p)
-                pv.copy_(p.data)
-                gv.copy_(p.grad)
-                p.data = pv
-                p.grad = gv
-                off += k
+        self.params = self.bucket.params
+        self.flat_p, self.flat_g = self.bucket.flat_p, self.bucket.flat
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         # torch.optim spelling: the reference's adjust_learning_rate writes optimizer.param_groups[0]['lr'] (:1325-1328)
         self.param_groups = [{'lr': lr, 'params': self.params}]
@@ -79,10 +68,7 @@ class FlatAdam:
 
     def all_reduce_grads(self):
         """Average gradients over the ranks: one collective on the flat bucket (RCCL over xGMI on GPUs)."""
-        _, w = mdist.world()
-        if w > 1:
-            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM)
-            self.flat_g.div_(w)
+        self.bucket.all_reduce()
 
     def step(self):
         self.step_count += 1

@@ -80,7 +80,91 @@ def class_weights_from_histogram(class_array, policy='normal'):
     return np.ones(len(class_array))
 
 
-class PseudoLabelPass:
+class _GraphedPassMixin:
+    """hipGraph capture / replay shared by PseudoLabelPass and SelfLabelPass.
+
+    One captured pass = `_Captured(graph, static_in, static_out, signature)`.  Two hazards are closed here (both seen in
+    round 1, DESIGN.md section 4 "Failures on record"):
+      * lifetime -- a hipGraph bakes in raw pointers: its input buffer, the pass's histogram, the folded-BN / packed-weight
+        caches of every module.  Everything the capture touched that is NOT allocated from the graph's own memory pool is
+        referenced from the graph object itself (`graph._mspl_keep`), so whoever holds the graph (or a `static_input()` view,
+        which carries the graph along) keeps those buffers alive: dropping the pass object can no longer free memory that a
+        live graph replays on (the round-1 fault: a freed `static_in` under a separately held graph, unmapped by the next
+        capture's empty_cache()).
+      * staleness -- the graph is valid for the parameter values it was captured with.  Each graph stores the parameter
+        signature (layers._PARAM_EPOCH, which the raw-pointer optimizer kernels bump, plus (data_ptr, _version) of every
+        parameter and buffer); a replay with a different signature re-captures first (FlatAdam re-points .data, every
+        optimizer step rebuilds the folded caches elsewhere)."""
+
+    def _signature(self):
+        ts = self.__dict__.get('_sig_tensors')
+        if ts is None:
+            ts = []
+            for m in self._graph_models():
+                ts += [t for t in list(m.parameters()) + list(m.buffers()) if t.is_floating_point()]
+            self._sig_tensors = ts
+        return (layers._PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _cache_tensors(self):
+        keep = []
+        for m in self._graph_models():
+            for mod in m.modules():
+                for _, val in mod.__dict__.get('_mspl_cache', {}).values():
+                    keep.append(val)
+        return keep
+
+    def _replay(self, images, copy_always=False):
+        key = tuple(images.shape)
+        sig = self._signature()
+        g = self._graphs.get(key)
+        if g is not None and g.signature != sig:
+            del self._graphs[key]                     # parameters changed since the capture: this graph holds stale values
+            g = None
+        if g is None:
+            static_in = images.clone()
+            hist_before = self.hist.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):             # warm-up: fills the folded-BN caches outside the capture
+                self._run(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            self.hist.copy_(hist_before)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):      # other threads (the PNG writer) keep using HIP
+                static_out = self._graph_outputs(self._run(static_in))
+            self.hist.copy_(hist_before)              # capture does not execute, but keep the invariant explicit
+            graph._mspl_keep = (static_in, self.hist, self._cache_tensors(), list(getattr(self, 'luts', ())))
+            g = self._graphs[key] = _Captured(graph, static_in, static_out, sig)
+        if copy_always or g.static_in.data_ptr() != images.data_ptr():
+            g.static_in.copy_(images)
+        g.graph.replay()
+        return g.static_out
+
+    def static_input(self, shape):
+        """The graph's own input buffer for `shape` (write batches straight into it to skip the copy); None before the first
+        call with that shape.  The returned tensor keeps the graph's buffers alive (`_mspl_graph`)."""
+        g = self._graphs.get(tuple(shape))
+        if g is None:
+            return None
+        view = g.static_in.view(g.static_in.shape)
+        view._mspl_graph = g.graph
+        return view
+
+
+class _Captured(object):
+    __slots__ = ('graph', 'static_in', 'static_out', 'signature')
+
+    def __init__(self, graph, static_in, static_out, signature):
+        self.graph, self.static_in, self.static_out, self.signature = graph, static_in, static_out, signature
+
+    def __iter__(self):                                # (graph, static_in, static_out), the round-1 tuple layout
+        return iter((self.graph, self.static_in, self.static_out))
+
+    def __getitem__(self, i):
+        return (self.graph, self.static_in, self.static_out)[i]
+
+
+class PseudoLabelPass(_GraphedPassMixin):
     """Batched multi-source pseudo-label generation (the loop body of generate_pseudo_label_multi_model).
 
     model_list / os_data_list as in the reference (os_data in {'camvid','cityscapes','forest', other=identity}).
@@ -131,26 +215,14 @@ class PseudoLabelPass:
             images = images.to(self.device)
             if not self.use_graph:
                 return self._run(images)[0]
-            key = tuple(images.shape)
-            g = self._graphs.get(key)
-            if g is None:
-                static_in = images.clone()
-                hist_before = self.hist.clone()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):       # warm-up: fills the folded-BN caches outside the capture
-                    self._run(static_in)
-                torch.cuda.current_stream().wait_stream(side)
-                self.hist.copy_(hist_before)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):      # other threads (the PNG writer) keep using HIP
-                    static_out = self._run(static_in)[0]
-                self.hist.copy_(hist_before)        # capture does not execute, but keep the invariant explicit
-                g = self._graphs[key] = (graph, static_in, static_out)
-            graph, static_in, static_out = g
-            static_in.copy_(images)
-            graph.replay()
-            return static_out
+            return self._replay(images)
+
+    def _graph_models(self):
+        return self.models
+
+    @staticmethod
+    def _graph_outputs(run_result):
+        return run_result[0]
 
     def class_weights(self, policy='normal'):
         return torch.from_numpy(class_weights_from_histogram(self.hist.cpu().numpy(), policy)).float().to(self.device)
@@ -277,35 +349,63 @@ class PipelinedLabelPass:
 
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
-                                      use_graph=True, writer_workers=4, in_flight=3):
+                                      use_graph=True, writer_workers=4, in_flight=3, pre_sharded=False, _label_pass=None):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
 
     testloader yields the reference's tuples `(image, label, name, _)` (or `(image, label, depth, name, _)` with
     use_depth; depth is only used for the list file, like the reference's :936) with any batch size.  The label maps never
     visit the host on the critical path: PseudoLabelPass keeps them on the device, mspl_amd.io.LabelWriter copies and
-    encodes them asynchronously while the next batch runs; `in_flight` batches overlap on the GPU (PipelinedLabelPass)."""
+    encodes them asynchronously while the next batch runs; `in_flight` batches overlap on the GPU (PipelinedLabelPass).
+
+    One process per GPU (torch.distributed initialised): the images are independent (:849 runs them one at a time), so rank r
+    labels the batches b == r (mod world) of the loader and nothing crosses ranks on the data path.  The two pieces of
+    cross-image state are exchanged once at the end: the class histogram (`class_array`, :887,920-921) by one all-reduce,
+    the path lists (:933-940) gathered in loader order; rank 0 writes the list file, every rank returns the same class
+    weights.  pre_sharded=True: the caller's loader already yields this rank's batches only (e.g. a sampler over
+    dist.shard_indices) -- use it when skipping a foreign batch is not free (the loader decodes it first).
+    `_label_pass`: an object with PipelinedLabelPass's interface, for host-logic tests."""
     import os.path as osp
+    from . import dist as mdist
     from .io import LabelWriter, update_image_list
-    p = PipelinedLabelPass(lambda: PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy,
-                                                   device=device, use_graph=use_graph), depth=in_flight, device=device)
+    rank, world = mdist.world()
+    p = _label_pass if _label_pass is not None else PipelinedLabelPass(
+        lambda: PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy,
+                                device=device, use_graph=use_graph), depth=in_flight, device=device)
+    p.reset()
     tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
     writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)
-    names = []
-    for batch in testloader:
+    names, batch_sizes = [], []
+    for b, batch in enumerate(testloader):
+        if world > 1 and not pre_sharded and b % world != rank:
+            continue
         image = batch[0]
         names.append(list(batch[-2]))
-        merged = p(image if image.is_cuda else image.to(device, non_blocking=True))
+        batch_sizes.append(len(names[-1]))
+        merged = p(image if (image.is_cuda or _label_pass is not None) else image.to(device, non_blocking=True))
         if merged is not None:
             writer.submit(names.pop(0), merged)
     for merged in p.flush():
         writer.submit(names.pop(0), merged)
     lists = writer.close()
-    update_image_list(tgt_train_lst, *lists)
-    return tgt_train_lst, p.class_weights(class_weighting)
+    hist = p.hist
+    if world > 1:
+        # per-batch records in this rank's order -> loader order (batch b came from rank b % world), then flattened
+        recs, at = [], 0
+        for n in batch_sizes:
+            recs.append(tuple(l[at:at + n] for l in lists))
+            at += n
+        merged_recs = mdist.gather_lists(recs)
+        lists = tuple([x for r in merged_recs for x in r[k]] for k in range(len(lists)))
+        hist = mdist.reduce_histogram(hist.clone())
+    if rank == 0:
+        update_image_list(tgt_train_lst, *lists)
+    mdist.barrier()                                     # the list file exists before any rank builds its train loader from it
+    weights = torch.from_numpy(class_weights_from_histogram(hist.cpu().numpy(), class_weighting)).float().to(hist.device)
+    return tgt_train_lst, weights
 
 
-class SelfLabelPass:
+class SelfLabelPass(_GraphedPassMixin):
     """Batched single-model relabelling (the loop body of generate_pseudo_label, uest_seg_multi_os.py:730-830):
     forward -> pred + 0.5*aux -> argmax -> class histogram, plus the KL(pred||aux) uncertainty map that
     get_output computes (:691) -- kept on the device for the uncertainty-weighted loss instead of being
@@ -325,8 +425,13 @@ class SelfLabelPass:
 
     def _run(self, images):
         main, aux = _lowres(self.model, images)
+        if main.shape[1] <= min(24, self.classes, 32):
+            # every argmax is a counted class: the epilogue kernel accumulates the histogram itself (one launch; the S = 1 merge
+            # would be the identity on these labels)
+            r = ops.label_epilogue_hist(main, aux, images.shape[2:], self.hist, self.classes, want_kld=self.with_kld)
+            return r['labels'], r.get('kld')
         r = ops.label_epilogue(main, aux, images.shape[2:], want_kld=self.with_kld)
-        # S = 1, threshold 1: the merge kernel is the identity on labels and accumulates the histogram
+        # S = 1, threshold 1: out-of-range classes become NO_AGREEMENT_CLASS, the merge kernel accumulates the histogram
         labels = ops.merge_labels([r['labels']], self.classes, 1, NO_AGREEMENT_CLASS, self.hist)
         return labels, r.get('kld')
 
@@ -335,29 +440,11 @@ class SelfLabelPass:
             images = images.to(self.device)
             if not self.use_graph:
                 return self._run(images)
-            key = tuple(images.shape)
-            g = self._graphs.get(key)
-            if g is None:
-                static_in = images.clone()
-                hist_before = self.hist.clone()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self._run(static_in)
-                torch.cuda.current_stream().wait_stream(side)
-                self.hist.copy_(hist_before)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):      # other threads (the PNG writer) keep using HIP
-                    static_out = self._run(static_in)
-                self.hist.copy_(hist_before)
-                g = self._graphs[key] = (graph, static_in, static_out)
-            graph, static_in, static_out = g
-            if static_in.data_ptr() != images.data_ptr():
-                static_in.copy_(images)
-            graph.replay()
-            return static_out
+            return self._replay(images)
 
-    def static_input(self, shape):
-        """The graph's own input buffer for `shape` (write batches straight into it to skip the copy)."""
-        g = self._graphs.get(tuple(shape))
-        return None if g is None else g[1]
+    def _graph_models(self):
+        return [self.model]
+
+    @staticmethod
+    def _graph_outputs(run_result):
+        return run_result

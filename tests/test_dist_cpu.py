@@ -17,7 +17,108 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _toy(seed):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Tanh(), torch.nn.Linear(4, 2))
+    unused = torch.nn.Parameter(torch.randn(5))           # never receives a gradient: stays out of the bucket (Appendix B-5)
+    return net, unused
+
+
+def _check_flat_optimizers(rank, world):
+    """The all-reduce the PRODUCT uses: FlatAdam.all_reduce_grads (training.py) and FlatSGD.all_reduce_grads (supervised.py)
+    both go through dist.GradBucket.  Per-rank mean gradients of equal shards must average to the full-batch gradient, the
+    flat layout must follow the parameter (group) order, and gradient-less parameters must stay out."""
+    from mspl_amd import supervised, training
+    x = torch.randn(8, 3, generator=torch.Generator().manual_seed(3))
+    for kind in ('adam', 'sgd'):
+        net, unused = _toy(1)
+        ref, _ = _toy(1)
+        net(x[rank::world]).pow(2).mean().backward()
+        ref(x).pow(2).mean().backward()                 # equal shards: mean of the shard means == full-batch mean
+        before = [p.detach().clone() for p in net.parameters()]
+        if kind == 'adam':
+            opt = training.FlatAdam(list(net.parameters()) + [unused], lr=1e-3)
+            order = list(net.parameters())
+        else:
+            groups = [{'params': list(net[2].parameters()), 'lr': 0.1}, {'params': list(net[0].parameters()) + [unused], 'lr': 0.01}]
+            opt = supervised.FlatSGD(groups, lr=0.1, momentum=0.9)
+            order = list(net[2].parameters()) + list(net[0].parameters())
+            assert [(g['_lo'], g['_hi']) for g in opt.param_groups] == [(0, 10), (10, 26)]
+        assert opt.bucket.params == order and unused.grad is None and opt.flat_g is opt.bucket.flat
+        assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))       # values preserved by the re-pointing
+        assert all(p.data_ptr() == opt.flat_p[o:].data_ptr() and p.grad.data_ptr() == opt.flat_g[o:].data_ptr()
+                   for p, o in zip(order, opt.bucket.offsets))
+        opt.all_reduce_grads()
+        for p, r in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, r.grad, atol=1e-6), kind
+        opt.zero_grad()
+        assert float(opt.flat_g.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
+
+
+class _StubPipelinedPass:
+    """PipelinedLabelPass's interface with one batch in flight and no GPU: labels = a deterministic function of the batch."""
+
+    def __init__(self):
+        self.hist = torch.zeros(5, dtype=torch.int64)
+        self._held = None
+
+    def reset(self):
+        self.hist.zero_()
+
+    def _label(self, images):
+        lab = (images.sum(1).round().to(torch.int64) % 5).to(torch.uint8)
+        self.hist += torch.bincount(lab.flatten().to(torch.int64), minlength=5)
+        return lab
+
+    def __call__(self, images):
+        out, self._held = self._held, self._label(images)
+        return out
+
+    def flush(self):
+        if self._held is not None:
+            out, self._held = self._held, None
+            yield out
+
+
+def _check_sharded_label_function(rank, world, tmp):
+    """generate_pseudo_label_multi_model under world 2: every rank labels its own batches, the histogram is all-reduced, the
+    path lists come back in loader order, rank 0 alone writes tgt_train.lst, both ranks return the same class weights."""
+    import numpy as np
+    from mspl_amd import io as mio, uest
+    from oracle import imageio as oio
+    g = torch.Generator().manual_seed(11)
+    sizes = [2, 1, 3, 2, 1]                              # ragged batches, odd count: rank 0 gets 3 batches, rank 1 gets 2
+    batches, k = [], 0
+    for n in sizes:
+        names = ['/data/color/frame_%03d.jpg' % (k + i) for i in range(n)]
+        batches.append((torch.rand(n, 3, 8, 12, generator=g) * 4, None, names, None))
+        k += n
+
+    def loader():
+        for b in batches:
+            yield b
+    save = tmp + '/shared'                               # both ranks write into the same directory tree, like a shared run dir
+    lst, w = uest.generate_pseudo_label_multi_model(None, None, loader(), save, writer_workers=2, _label_pass=_StubPipelinedPass())
+    stub = _StubPipelinedPass()
+    all_labels = [stub._label(b[0]) for b in batches]
+    expect_w = uest.class_weights_from_histogram(stub.hist.numpy(), 'normal')
+    assert np.allclose(w.numpy(), expect_w.astype(np.float32)), (w, expect_w)
+    import os.path as osp
+    assert osp.isfile(lst)                               # visible to every rank after the function's barrier
+    images, masks = mio.read_image_list(lst, check_files=False)[:2]
+    flat_names = [n for b in batches for n in b[2]]
+    assert images == flat_names, images                  # loader order restored across the ranks
+    assert masks == ['%s/pred/frame_%03d.png' % (save, i) for i in range(len(flat_names))]
+    # this rank wrote exactly its own batches' files, with the right pixels
+    mine = [i for i in range(len(batches)) if i % world == rank]
+    at = np.cumsum([0] + sizes)
+    for bi in mine:
+        for j in range(sizes[bi]):
+            arr = oio.png_decode_gray8(open(masks[at[bi] + j], 'rb').read())
+            assert np.array_equal(arr, all_labels[bi][j].numpy())
+
+
+def _worker(rank, world, port, q, tmp):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -51,6 +152,8 @@ def _worker(rank, world, port, q):
         full.backward()
         assert torch.allclose(w1.grad, w1r.grad, atol=1e-6) and torch.allclose(w2.grad, w2r.grad, atol=1e-6)
         assert w1.grad.data_ptr() == b.flat.data_ptr()      # grads are views of the flat bucket
+        _check_flat_optimizers(rank, world)
+        _check_sharded_label_function(rank, world, tmp)
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
@@ -58,14 +161,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_histogram_and_grad_bucket():
+def test_two_rank_sharding_histogram_and_grad_bucket(tmp_path):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res

@@ -112,9 +112,10 @@ def test_config3_train_step_bs16_256x480():
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4)
 
 
-def test_pipelined_label_pass_equals_single_lane():
-    """Two label passes in flight (PipelinedLabelPass, hipGraph lanes on two streams): the same label maps, uncertainty maps and
-    class histogram as one pass at a time, batch by batch, at the BASELINE shape."""
+@pytest.mark.parametrize('depth', [2, 3])
+def test_pipelined_label_pass_equals_single_lane(depth):
+    """`depth` label passes in flight (PipelinedLabelPass, hipGraph lanes on their own streams; 3 = bench.py's default): the same
+    label maps, uncertainty maps and class histogram as one pass at a time, batch by batch, at the BASELINE shape."""
     import argparse
     from mspl_amd import models, uest
     from tests.synth import synth_state_dict
@@ -123,13 +124,13 @@ def test_pipelined_label_pass_equals_single_lane():
     m.load_state_dict(synth_state_dict(m.state_dict(), 3))
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(77)
-    batches = [torch.randn((16, 3, 288, 480), generator=g).cuda() for _ in range(5)]
+    batches = [torch.randn((16, 3, 288, 480), generator=g).cuda() for _ in range(7)]
     ref = uest.SelfLabelPass(m, classes=13, use_graph=True)
     want = []
     for b in batches:
         lab, kld = ref(b)
         want.append((lab.clone(), kld.clone()))
-    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=2)
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=depth)
     got = []
     for b in batches:
         out = plp(b)
@@ -140,4 +141,99 @@ def test_pipelined_label_pass_equals_single_lane():
     assert len(got) == len(want)
     for (l1, k1), (l0, k0) in zip(got, want):
         assert torch.equal(l1, l0) and torch.equal(k1, k0)
-    assert torch.equal(plp.hist, ref.hist) and int(plp.hist.sum()) == 5 * 16 * 288 * 480
+    assert torch.equal(plp.hist, ref.hist) and int(plp.hist.sum()) == 7 * 16 * 288 * 480
+
+
+def test_graphed_pass_follows_parameter_updates():
+    """A captured pass bakes in pointers to the folded-BN / packed-weight caches and to the parameter storages.  The uest loop
+    alternates label passes and train rounds on the SAME model: after a train step (FlatAdam re-points .data, the Adam kernel
+    writes through raw pointers) the graphed pass must re-capture and equal a fresh eager pass, not replay stale weights."""
+    from mspl_amd import training, uest
+    m = _net(5, 'greenhouse', 4)[0].to(DEV).eval()
+    x = synth_input((4, 3, 128, 160), 21).to(DEV)
+    y = synth_labels((4, 128, 160), 5, 21).to(DEV)
+    graphed = uest.SelfLabelPass(m, classes=5, device=DEV, use_graph=True)
+    lab0, kld0 = [t.clone() for t in graphed(x)]
+    g0 = graphed._graphs[tuple(x.shape)].graph
+    assert graphed(x) is not None and graphed._graphs[tuple(x.shape)].graph is g0          # unchanged parameters: same graph
+    opt = None
+    for _ in range(3):
+        _, opt = training.train_step(m, x, y, torch.ones(5), opt, ignore_idx=4, lr=1e-2)
+    lab1, kld1 = [t.clone() for t in graphed(x)]
+    assert graphed._graphs[tuple(x.shape)].graph is not g0                                 # re-captured
+    fresh = uest.SelfLabelPass(m, classes=5, device=DEV, use_graph=False)
+    lab2, kld2 = fresh(x)
+    assert torch.equal(lab1, lab2) and torch.equal(kld1, kld2)
+    assert not torch.equal(kld1, kld0)                                                     # the step really moved the weights
+    # in-place edits through torch (load_state_dict -> copy_) are seen through the version counters
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['bu_dec_l4.merge_layer.3.bias'] += 1.5
+    m.load_state_dict(sd)
+    lab3, _ = graphed(x)
+    assert torch.equal(lab3, uest.SelfLabelPass(m, classes=5, device=DEV, use_graph=False)(x)[0])
+
+
+def test_graph_outlives_its_pass_object():
+    """Round-1 fault on record: a graph replayed after its SelfLabelPass had been collected read a freed
+    input buffer.  Now the graph object itself references every buffer it was captured on: drop the pass, capture another lane
+    (torch.cuda.graph runs gc.collect() + empty_cache()), replay the first graph -- same bits as before."""
+    import gc
+    from mspl_amd import uest
+    m = _net(13, 'camvid', 6)[0].to(DEV).eval()
+    x = synth_input((4, 3, 128, 160), 31).to(DEV)
+    pa = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=True)
+    want = [t.clone() for t in pa(x)]
+    cap = pa._graphs[tuple(x.shape)]
+    graph, out = cap.graph, cap.static_out
+    hist_ref = pa.hist
+    del pa, cap
+    gc.collect()
+    torch.cuda.empty_cache()
+    pb = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=True)                      # capture lane B in the freed space
+    junk = [torch.full((4, 3, 128, 160), float(i), device=DEV) for i in range(8)]           # and recycle whatever is left
+    pb(x * 0.5)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    assert int(hist_ref.sum()) == 2 * 4 * 128 * 160
+    del junk
+    # the handed-out input view carries the graph along
+    pc = uest.SelfLabelPass(m, classes=13, device=DEV, use_graph=True)
+    pc(x)
+    view = pc.static_input(x.shape)
+    assert view is not None and view._mspl_graph is pc._graphs[tuple(x.shape)].graph
+
+
+def test_aspp_dense_conv_full_size_properties():
+    """BASELINE configs[4] at the bench shape 16 x 2048 x 32 x 64 (no oracle run at this size: 29 GMAC per image).  Properties:
+    image i alone gives the same bits (every workgroup tile lies inside one image); writing into a channel slice of a wider
+    destination leaves the guard bands untouched and gives the same bits as a dense destination."""
+    from mspl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((16, 2048, 32, 64), generator=g).to(DEV)
+    w = (torch.randn((256, 2048, 3, 3), generator=g) * 0.01).to(DEV)
+    wp = ops.pack_dense_weight(w)
+    scale = (torch.rand(256, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(256, generator=g).to(DEV)
+    for dil in (6, 18):
+        full = ops.dense_conv(x, wp, 3, dil, ops.Epi(scale, shift, torch.zeros(256, device=DEV)))
+        assert torch.isfinite(full).all()
+        for i in (0, 9, 15):
+            one = ops.dense_conv(x[i:i + 1].contiguous(), wp, 3, dil, ops.Epi(scale, shift, torch.zeros(256, device=DEV)))
+            assert torch.equal(one[0], full[i])
+    wide = torch.full((16, 256 + 64, 32, 64), -7.0, device=DEV)
+    sc = torch.cat([torch.ones(32, device=DEV), scale, torch.ones(32, device=DEV)])
+    sh = torch.cat([torch.zeros(32, device=DEV), shift, torch.zeros(32, device=DEV)])
+    ops.dense_conv(x, wp, 3, 18, ops.Epi(sc, sh, torch.zeros(320, device=DEV)), out=(wide, 32))
+    assert torch.equal(wide[:, 32:288], full)
+    assert (wide[:, :32] == -7.0).all() and (wide[:, 288:] == -7.0).all()
+    # a corner pixel of one image against a direct fp64 evaluation of the definition (dilation 18: 4 of 9 taps inside)
+    ref = 0.0
+    xi = x[2].double()
+    for ky in range(3):
+        for kx in range(3):
+            yy, xx = 0 + (ky - 1) * 18, 0 + (kx - 1) * 18
+            if 0 <= yy < 32 and 0 <= xx < 64:
+                ref = ref + (w[:, :, ky, kx].double() @ xi[:, yy, xx])
+    ref = torch.relu(ref * scale.double() + shift.double())
+    np.testing.assert_allclose(full[2, :, 0, 0].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-4, atol=2e-4)

@@ -185,6 +185,30 @@ def test_label_epilogue_fused_upsample_vs_unfused():
     assert np.array_equal(r['labels'].cpu().numpy()[sure], ref[sure])
 
 
+@pytest.mark.parametrize('cfg', [(2, 13, 64, 96, 13, False), (1, 5, 48, 80, 5, True), (3, 20, 32, 272, 32, False), (1, 13, 16, 16, 16, True)])
+def test_label_epilogue_hist_equals_epilogue_plus_merge(cfg):
+    """The single-source pass's fused form (labels + KL map + class histogram in one launch) against the two-launch form it
+    replaces, bit for bit: label_epilogue, then merge_labels(S=1, thresh=1) as identity + histogram; and against np.bincount."""
+    from mspl_amd import ops
+    N, C, H, W, ncls, use_lut = cfg
+    main = rnd(N, C, H // 2, W // 2, seed=11, scale=2.0).to(DEV)
+    aux = rnd(N, C, H // 4, W // 4, seed=12, scale=2.0).to(DEV)
+    lut = (torch.arange(C) % ncls).to(torch.uint8).to(DEV) if use_lut else None
+    two = ops.label_epilogue(main, aux, (H, W), lut=lut, want_kld=True)
+    h2 = torch.zeros(ncls, dtype=torch.int64, device=DEV)
+    lab2 = ops.merge_labels([two['labels']], ncls, 1, 4, h2)
+    h1 = torch.full((ncls,), 3, dtype=torch.int64, device=DEV)             # accumulates into what is there
+    one = ops.label_epilogue_hist(main, aux, (H, W), h1, ncls, lut=lut, want_kld=True)
+    assert torch.equal(one['labels'], lab2) and torch.equal(one['labels'], two['labels'])
+    assert torch.equal(one['kld'], two['kld'])
+    assert torch.equal(h1 - 3, h2) and int(h2.sum()) == N * H * W
+    np.testing.assert_array_equal(h2.cpu().numpy(), np.bincount(lab2.cpu().numpy().ravel(), minlength=ncls))
+    only = ops.label_epilogue_hist(main, None, (H, W), h1, ncls, lut=lut)                  # single-head nets, no KL map
+    assert torch.equal(only['labels'], ops.label_epilogue(main, None, (H, W), lut=lut)['labels']) and 'kld' not in only
+    with pytest.raises(RuntimeError, match='logit channels'):
+        ops.label_epilogue_hist(torch.zeros(1, 25, 4, 4, device=DEV), None, (8, 8), torch.zeros(32, dtype=torch.int64, device=DEV), 32)
+
+
 def test_bad_arguments_raise():
     from mspl_amd import ops
     with pytest.raises(RuntimeError, match='exceeds the LDS weight tile'):     # K per group > ~700 is not on the path
