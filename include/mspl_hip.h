@@ -190,14 +190,17 @@ int mspl_label_epilogue_fwd(const float* main, const float* aux, int32_t N, int3
                             float* main_up, float* aux_up, void* stream);
 
 /* K8+K9 with the class histogram of the labels it writes: the single-source label pass (uest_seg_multi_os.py:785-815,
- *     one model relabelling its own domain) in ONE launch -- what label_epilogue + merge_labels(S=1, thresh=1) computed in two.
- *     hist: num_classes (<= 32) uint64 bins, accumulated into (caller zeroes); labels >= num_classes are not counted.
- *     C <= 24; labels required; kld optional.
+ *     one model relabelling its own domain) without a separate merge launch -- what label_epilogue + merge_labels(S=1,
+ *     thresh=1) computed.  hist: num_classes (<= 32) uint64 bins, accumulated into (caller zeroes); labels >= num_classes
+ *     are not counted.  C <= 24; labels required; kld optional.  workspace: caller-owned scratch of at least
+ *     mspl_label_epilogue_hist_workspace_bytes(N, H, W) bytes (per-workgroup partial counts, summed by a second tiny launch:
+ *     same-address device atomics from ~10^4 workgroups serialise).
  */
+int64_t mspl_label_epilogue_hist_workspace_bytes(int32_t N, int32_t H, int32_t W);
 int mspl_label_epilogue_hist_fwd(const float* main, const float* aux, int32_t N, int32_t C,
                                  int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
                                  const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
-                                 int32_t num_classes, void* stream);
+                                 int32_t num_classes, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K10  cross-source label merge + class histogram.  Replaces uest_seg_multi_os.py:695-718
  *     (merge_outputs) and :919-921.  src[s]: npix uint8 class maps (already in target ids),

@@ -48,7 +48,9 @@ SIGNATURES = {
     'mspl_label_epilogue_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                 ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_label_epilogue_hist_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                     ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_i32, ctypes.c_void_p],
+                                     ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_i32, ctypes.c_void_p, c_i64,
+                                     ctypes.c_void_p],
+    'mspl_label_epilogue_hist_workspace_bytes': [c_i32, c_i32, c_i32],
     'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
@@ -109,6 +111,7 @@ def _load():
         fn.restype = ctypes.c_int
     lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
     lib.mspl_nid_workspace_floats.restype = ctypes.c_int64
+    lib.mspl_label_epilogue_hist_workspace_bytes.restype = ctypes.c_int64
     lib.mspl_png_writer_create.restype = ctypes.c_void_p          # a handle
     lib.mspl_png_writer_submit.restype = ctypes.c_int64           # a ticket (or a negative status)
     lib.mspl_version.restype = ctypes.c_char_p

@@ -4,21 +4,38 @@
 // (espnet_utils.py:118-142, padding = dilation) of the SAME reduced tensor, out_k += out_{k-1},
 // torch.cat over branches, then br_after_cat (BatchNorm + PReLU, espnet_utils.py:39-60).
 //
-// MI355X design: one pass over HBM.  A workgroup owns a band of output rows of CP (image, channel)
-// planes; it stages the input rows (+ MAXD halo rows, zero-filled borders) into LDS with 16-byte
-// coalesced loads, then every thread produces a 1x4 output strip for all four branches from
-// register-resident row windows (one aligned LDS row window feeds every tap of every branch), applies
-// the prefix sum across branches and the folded BN + PReLU, and writes the four concatenated planes
-// with 16-byte stores.  Algorithmic bytes: 4*n*(H*W + 4*Ho*Wo) per image.
+// MI355X design (round 2): one pass over HBM by PERSISTENT workgroups.  A tile is a band of output rows of CP (image,
+// channel) planes; a workgroup walks tiles t = b, b + G, ... of an XCD-contiguous tile order.  Per tile: the input rows
+// (+ MAXD halo rows) arrive in registers (16-byte coalesced loads issued one tile ahead, so they fly during the previous
+// tile's arithmetic and stores), are written to LDS (zero halo columns are written once per workgroup), and every thread
+// produces 1x4 output strips for all four branches from register-resident row windows:
+//   * stride 1: a row is staged as 4 zero columns + W values; a strip's window is 12 floats = 3 aligned ds_read_b128.
+//   * stride 2: a row is staged DE-INTERLEAVED, E[j] = x[2j] and O[j] = x[2j+1]; output xo reads input column 2xo + dx, i.e.
+//     E[xo + dx/2] or O[xo + (dx-1)/2]: four consecutive outputs again read a contiguous 12-float window, lanes stay 16 bytes
+//     apart (conflict-free ds_read_b128) and write float4 (the round-1 form produced 2 outputs per lane from a 12-float
+//     window: 2.3x the LDS reads per output and 8-byte stores).
+//   * the centre row is read once for all four dilations; a row +-d is read once per distinct dilation; only the float4s
+//     of a window that a dilation touches are read.
+//   * weights and epilogue constants sit in LDS as one float4 per (branch, kernel row) / per branch.
+// The hierarchical sum out_k = conv_k + out_{k-1} is carried in registers, the folded BN + PReLU applied, and the four
+// concatenated planes written with 16-byte stores (8-byte when the row length is only even: the 18x30 level).
+// Algorithmic bytes: 4*n*(H*W + 4*Ho*Wo) per image.
+//
+// What the round-1 timeline (s_memrealtime stamps, profiles/r02_k2_stamps_before.txt) showed and this form answers: at the
+// 18x30 level the 2048 one-shot workgroups of a launch started over 4-7 us, loaded for 2.7 us, then all computed at once for
+// 3 us with 56 % of the lanes idle (144 items on 256 threads) and ~450 vector instructions per item -- the vector pipe, not
+// HBM, was the bound of that phase; at 144x240 (stride 2) a band was 5 output rows (70 % halo rows re-read) in 2.8 rounds.
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include "common.hpp"
 
 namespace mspl {
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // Give each XCD (blocks b, b+8, ... share one) a contiguous chunk of the logical grid so that
-    // neighbouring row bands (which share halo rows) hit the same L2.  Bijective for any nwg.
+    // Give each XCD (ids b, b+8, ... share one) a contiguous chunk of the logical order so that neighbouring row bands
+    // (which share halo rows) hit the same L2.  Bijective for any nwg.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
@@ -29,208 +46,268 @@ struct DilSet {
     static constexpr int d(int k) { return k == 0 ? D0 : k == 1 ? D1 : k == 2 ? D2 : D3; }
     static constexpr int maxd() { return D3 > D2 ? (D3 > D1 ? (D3 > D0 ? D3 : D0) : (D1 > D0 ? D1 : D0))
                                                  : (D2 > D1 ? (D2 > D0 ? D2 : D0) : (D1 > D0 ? D1 : D0)); }
+    static constexpr bool any_odd() { return ((D0 | D1 | D2 | D3) & 1) != 0; }
 };
 
 struct DwGeom {
     int N, n, H, W, Ho, Wo;
     int TH;       // output rows per band
-    int CP;       // planes per workgroup (same image, consecutive channels)
+    int CP;       // planes per tile (same image, consecutive channels)
     int bands;    // ceil(Ho / TH)
     int cgroups;  // n / CP
-    int LS;       // LDS row stride in floats: 4 zero columns + W (rounded to 4) + zero fill; chosen so that lane
-                  // addresses stay linear (mod 64 banks) across row ends -> conflict-free ds_read_b128
-    unsigned mag_xs;   // exact division of an item index by XS: (t * mag) >> 24
+    int ntiles;   // N * cgroups * bands
+    int RS;       // LDS floats per staged input row (stride 2: E part then O part, RS / 2 each)
     int RIN;      // staged input rows per plane
-    int XS;       // output strips per row
-    int nocompute; // tuning aid (MSPL_DW_NOCOMPUTE): skip the stencil, keep loads/stores
-    unsigned long long* stamps;  // tuning aid (MSPL_DW_STAMP): 4 s_memrealtime stamps per workgroup, or null
+    int XS;       // output strips (of 4) per output row
+    int NCH;      // 16-byte chunks per input row: ceil(W / 4)
+    int chunks;   // CP * RIN * NCH  (<= 256 * DW_PF)
+    unsigned mag_xs, mag_nch, mag_rin;   // exact divisions by XS / NCH / RIN: (t * mag) >> 20 (ranges verified on the host)
+    unsigned long long* stamps;  // tuning aid (MSPL_DW_STAMP, STAMPS=1 builds): 4 s_memrealtime stamps per workgroup, or null
 };
 
-// One-shot workgroups, branch-sequential compute, conflict-free LDS addressing.
-//  * A thread owns OW = 4/STRIDE adjacent output pixels, i.e. always a 12-float input window starting at
-//    input column 4*xs - 4 (three ds_read_b128).  Lanes of a wave are exactly 16 bytes apart.
-//  * Staged rows carry the horizontal zero padding (4 zero columns left, zero fill right) and the row stride is
-//    chosen with STRIDE*LS == 4*XS (mod 64 banks): the lane -> address map then stays linear across row ends and
-//    every ds_read_b128 is bank-conflict free (a plain W+8 stride made 60-75% of the LDS cycles conflict cycles).
-//  * The four branches are evaluated one after the other (3 row windows each), carrying the hierarchical sum
-//    out_k = conv_k + out_{k-1} in OW registers and storing each branch as soon as it is final: ~50 VGPRs, so
-//    6-8 waves/SIMD keep loads, LDS reads, FMAs and stores of different tiles overlapped.
-template <int STRIDE, class DS>
-__global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __restrict__ x,
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));     // a float4 that is only known to be 8-byte aligned
+typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int DW_PF = 8;        // float4 prefetch registers per thread: a tile is at most 256 * 8 chunks = 32 KB of input
+
+// 12-float window starting at p (16-byte aligned); only the float4s that hold indices LO..HI are read.
+template <int LO, int HI>
+__device__ __forceinline__ void dw_window(const float* __restrict__ p, float (&v)[12]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (4 * i + 3 >= LO && 4 * i <= HI) {
+            const float4 q = *reinterpret_cast<const float4*>(p + 4 * i);
+            // all four elements count as used: keeps this one ds_read_b128 (hipcc otherwise narrows the read to the
+            // elements this dilation touches and emits more, smaller reads)
+            asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        } else {
+            v[4 * i] = v[4 * i + 1] = v[4 * i + 2] = v[4 * i + 3] = 0.f;
+        }
+    }
+}
+
+// PERSIST: a workgroup walks tiles b, b + G, ... with the next tile's rows prefetched into registers (many tiles per
+// workgroup, 3 workgroups per CU); otherwise one tile per workgroup (the staging registers die before the arithmetic starts:
+// 4-5 workgroups per CU, which is what hides latency when a launch is a single round of small tiles).
+template <int STRIDE, class DS, bool PERSIST>
+__global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw_hff_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ w,
                                                              DwGeom g, Epi e, float* __restrict__ out) {
     constexpr int MAXD = DS::maxd();
-    constexpr int OW = 4 / STRIDE;                        // outputs per thread (4 or 2)
+    constexpr bool ODD = STRIDE == 2 && DS::any_odd();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                   // CP * RIN * LS (+16 floats of tail pad)
-    float* wl = smem + (size_t)g.CP * g.RIN * g.LS + 16;  // CP * 36 (branch, ky, kx)
-    float* el = wl + g.CP * 36;                           // CP * 12 (branch, {scale, shift, alpha})
-
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int band = bid % g.bands;  bid /= g.bands;
-    const int cg = bid % g.cgroups;
-    const int img = bid / g.cgroups;
-    const int c0 = cg * g.CP;
-    const int y0 = band * g.TH;                 // first output row of the band
-    const int iy0 = y0 * STRIDE - MAXD;         // input row of LDS row 0
-    const int tid = threadIdx.x;
+    const int PS = g.RIN * g.RS;                          // floats per staged plane
+    float* tile = smem;                                   // CP * PS (+16 floats of tail pad)
+    float* wl = smem + (size_t)g.CP * PS + 16;            // [CP][branch*3 + ky][4]: (w0, w1, w2, 0)
+    float* el = wl + g.CP * 48;                           // [CP][branch][4]: (scale, shift, alpha, 0)
+    const int tid = threadIdx.x, nthr = blockDim.x;        // 64..256 threads: chosen so that the tile's items fill whole rounds
+    const int OOFF = g.RS >> 1;                           // stride 2: offset of the odd-column array inside a staged row
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (g.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- stage weights and epilogue constants (loads issued before the tile's, written after)
-    float wreg = 0.f, ereg = 0.f;
-    const int nwts = g.CP * 36, neps = g.CP * 12;
-    if (tid < nwts) {
-        const int p = tid / 36, r = tid - p * 36, k = r / 9, t = r - k * 9;
-        wreg = w[((size_t)k * g.n + (c0 + p)) * 9 + t];
-    }
-    if (tid < neps) {
-        const int p = tid / 12, r = tid - p * 12, k = r / 3, f = r - k * 3;
-        const int cabs = e.coff + k * g.n + c0 + p;
-        const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
-        ereg = src ? src[cabs] : (f == 1 ? 0.f : 1.f);
+    // ---- once per workgroup: zero the tile (halo columns / fill stay zero for every tile; data slots are overwritten)
+    {
+        const int tot4 = (g.CP * PS + 16) >> 2;
+        for (int i = tid; i < tot4; i += nthr) *reinterpret_cast<float4*>(tile + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // ---- stage input rows (rows outside the image are zero).  Loads are issued in batches of UL independent
-    // 16-byte loads per thread BEFORE any LDS write, so a workgroup has its whole tile in flight at once.
-    {
-        constexpr int UL = 8;
-        const int nvec = g.LS >> 2;
-        const int total = g.CP * g.RIN * nvec;
-        const bool w4 = (g.W & 3) == 0, w2 = (g.W & 1) == 0;
-        for (int base = 0; base < total; base += 256 * UL) {
-            float4 v[UL];
-            int dsto[UL];
+    // ---- per-thread staging slots: chunk i = tid + nthr*u -> (plane p, staged row r, 16-byte chunk m of the input row)
+    // (fixed for the whole kernel: only the tile's base pointer and first input row change)
+    // packed per slot: bit 31 = no chunk, bit 30 = partial last chunk of its row (W % 4 != 0), p << 24 | r << 12 | m
+    unsigned slot[DW_PF];
 #pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                const int i = base + u * 256 + tid;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dsto[u] = -1;
-                if (i < total) {
-                    const int rr = i / nvec, cv = i - rr * nvec;
-                    const int p = rr / g.RIN, r = rr - p * g.RIN;
-                    const int iy = iy0 + r;
-                    const int col0 = 4 * cv - 4;             // LDS column j <-> input column j - 4
-                    dsto[u] = 4 * i;
-                    if (iy >= 0 && iy < g.H && col0 >= 0 && col0 < g.W) {
-                        const float* src = x + (((size_t)img * g.n + (c0 + p)) * g.H + iy) * (size_t)g.W + col0;
-                        if (w4) {
-                            v[u] = *reinterpret_cast<const float4*>(src);
-                        } else if (w2) {
-                            { const float2 a = *reinterpret_cast<const float2*>(src); v[u].x = a.x; v[u].y = a.y; }
-                            if (col0 + 2 < g.W) { const float2 a = *reinterpret_cast<const float2*>(src + 2); v[u].z = a.x; v[u].w = a.y; }
-                        } else {
-                            v[u].x = src[0];
-                            if (col0 + 1 < g.W) v[u].y = src[1];
-                            if (col0 + 2 < g.W) v[u].z = src[2];
-                            if (col0 + 3 < g.W) v[u].w = src[3];
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UL; ++u)
-                if (dsto[u] >= 0) *reinterpret_cast<float4*>(tile + dsto[u]) = v[u];
+    for (int u = 0; u < DW_PF; ++u) {
+        const int i = tid + nthr * u;
+        slot[u] = 0x80000000u;
+        if (i < g.chunks) {
+            const int rr = (int)(((unsigned)i * g.mag_nch) >> 20), m = i - rr * g.NCH;
+            const int p = (int)(((unsigned)rr * g.mag_rin) >> 20), r = rr - p * g.RIN;
+            slot[u] = ((unsigned)p << 24) | ((unsigned)r << 12) | (unsigned)m | ((4 * m + 4 > g.W) ? 0x40000000u : 0u);
         }
     }
-    if (tid < nwts) wl[tid] = wreg;
-    if (tid < neps) el[tid] = ereg;
-    if (g.stamps) st1 = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
-    if (g.stamps) st2 = __builtin_amdgcn_s_memrealtime();
+    const int wrem = g.W & 3;                              // elements of a row's last chunk (0: all four)
+    const bool al16 = wrem == 0, al8 = (g.W & 1) == 0;
 
-    // ---- compute: item = (plane p, band row ty, strip xs); xs fastest so that lanes are 16 bytes apart
-    const int rows_here = min(g.TH, g.Ho - y0);
-    const int items = g.CP * rows_here * g.XS;
+    float4 pre[DW_PF];
+    auto tile_coords = [&](int t, int& img, int& c0, int& y0) {
+        int L = xcd_remap(t, g.ntiles);
+        const int band = L % g.bands;  L /= g.bands;
+        const int cg = L % g.cgroups;
+        img = L / g.cgroups;  c0 = cg * g.CP;  y0 = band * g.TH;
+    };
+    auto issue_loads = [&](int t) {
+        int img, c0, y0;
+        tile_coords(t, img, c0, y0);
+        const int iy0 = y0 * STRIDE - MAXD;                // input row of staged row 0 (may be negative: offsets stay in range)
+        const float* xb = x + ((size_t)img * g.n + c0) * g.H * (size_t)g.W + (ptrdiff_t)iy0 * g.W;
+#pragma unroll
+        for (int u = 0; u < DW_PF; ++u) {
+            pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sp = (slot[u] >> 24) & 3, sr = (slot[u] >> 12) & 0xfff, sm = slot[u] & 0xfff;
+            const int iy = iy0 + sr;
+            if (!(slot[u] & 0x80000000u) && iy >= 0 && iy < g.H) {
+                const float* src = xb + ((sp * g.H + sr) * g.W + 4 * sm);
+                if (al16) {
+                    pre[u] = *reinterpret_cast<const float4*>(src);
+                } else if (!(slot[u] & 0x40000000u)) {
+                    if (al8) { const f4a8 q = *reinterpret_cast<const f4a8*>(src); pre[u] = make_float4(q.x, q.y, q.z, q.w); }
+                    else { const f4a4 q = *reinterpret_cast<const f4a4*>(src); pre[u] = make_float4(q.x, q.y, q.z, q.w); }
+                } else {
+                    pre[u].x = src[0];
+                    if (wrem > 1) pre[u].y = src[1];
+                    if (wrem > 2) pre[u].z = src[2];
+                }
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < DW_PF; ++u) {
+            if (!(slot[u] & 0x80000000u)) {
+                const int sp = (slot[u] >> 24) & 3, sr = (slot[u] >> 12) & 0xfff, sm = slot[u] & 0xfff;
+                float* d = tile + (sp * PS + sr * g.RS + (STRIDE == 1 ? 4 + 4 * sm : 4 + 2 * sm));
+                if (STRIDE == 1) {
+                    *reinterpret_cast<float4*>(d) = pre[u];
+                } else {
+                    *reinterpret_cast<float2*>(d) = make_float2(pre[u].x, pre[u].z);
+                    *reinterpret_cast<float2*>(d + OOFF) = make_float2(pre[u].y, pre[u].w);
+                }
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < g.ntiles) issue_loads(t);
+    __syncthreads();                                       // zero fill complete before the first data writes
     const int hw = g.Ho * g.Wo;
-    const bool ovec = (g.Wo % OW) == 0;
+    const bool o16 = (g.Wo & 3) == 0, o8 = (g.Wo & 1) == 0;
     const bool has_act = e.alpha != nullptr;
     const size_t kstride = (size_t)g.n * hw * sizeof(float);
-    char* ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
-    const unsigned mag_rows = ((1u << 24) + (unsigned)rows_here - 1) / (unsigned)rows_here;   // uniform
-    for (int it = tid; it < items; it += 256) {
-        const int t2 = (int)(((unsigned)it * g.mag_xs) >> 24);
-        const int xs = it - t2 * g.XS;
-        const int p = (int)(((unsigned)t2 * mag_rows) >> 24);
-        const int ty = t2 - p * rows_here;
-        // window = LDS columns [4*xs, 4*xs + 12) = input columns [4*xs - 4, 4*xs + 8) of staged row ty*STRIDE + MAXD
-        const float* lp = tile + ((size_t)p * g.RIN + ty * STRIDE + MAXD) * g.LS + 4 * xs;
-        const float* wp = wl + p * 36;
-        const float* ep = el + p * 12;
-        const int xb = xs * OW;
-        // ONE 32-bit lane offset; the branch part of the address is uniform and goes in the scalar base
-        const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)(y0 + ty) * g.Wo + xb) * sizeof(float));
-        float prev[OW];
+
+    for (; t < g.ntiles; t += PERSIST ? (int)gridDim.x : g.ntiles) {
+        int img, c0, y0;
+        tile_coords(t, img, c0, y0);
+        // ---- weights / epilogue constants of this tile's planes (tiny, L2 resident), padded to float4 groups
+        float wreg = 0.f, ereg = 0.f;
+        const int nwts = g.CP * 48, neps = g.CP * 16;
+        if (tid < nwts) {
+            const int p = tid / 48, r = tid - p * 48, kq = r >> 2, kx = r & 3, k = kq / 3, ky = kq - 3 * k;
+            if (kx < 3) wreg = w[((size_t)k * g.n + (c0 + p)) * 9 + ky * 3 + kx];
+        }
+        if (tid < neps) {
+            const int p = tid >> 4, r = tid & 15, k = r >> 2, f = r & 3;
+            const int cabs = e.coff + k * g.n + c0 + p;
+            const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
+            ereg = f == 3 ? 0.f : (src ? src[cabs] : (f == 1 ? 0.f : 1.f));
+        }
+        write_tile();
+        if (tid < nwts) wl[tid] = wreg;
+        if (tid < neps) el[tid] = ereg;
+        if (g.stamps && t == (int)blockIdx.x) st1 = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        if (g.stamps && t == (int)blockIdx.x) st2 = __builtin_amdgcn_s_memrealtime();
+        if (PERSIST && t + (int)gridDim.x < g.ntiles) issue_loads(t + gridDim.x);     // next tile's rows fly during this tile's arithmetic
+
+        // ---- compute: item = (plane p, band row ty, strip xs); xs fastest so that lanes are 16 bytes apart
+        const int rows_here = min(g.TH, g.Ho - y0);
+        const int items = g.CP * rows_here * g.XS;
+        char* ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
+        const unsigned mag_rows = ((1u << 20) + (unsigned)rows_here - 1) / (unsigned)rows_here;   // uniform
+        for (int it = tid; it < items; it += nthr) {
+            const int t2 = (int)(((unsigned)it * g.mag_xs) >> 20);
+            const int xs = it - t2 * g.XS;
+            const int p = (int)(((unsigned)t2 * mag_rows) >> 20);
+            const int ty = t2 - p * rows_here;
+            const float* lp = tile + (size_t)p * PS + (ty * STRIDE + MAXD) * g.RS + 4 * xs;   // centre row window (A / E array)
+            const float4* wp = reinterpret_cast<const float4*>(wl) + p * 12;
+            const float4* ep = reinterpret_cast<const float4*>(el) + p * 4;
+            const int xb = xs * 4;
+            // ONE 32-bit lane offset; the branch part of the address is uniform and goes in the scalar base
+            const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)(y0 + ty) * g.Wo + xb) * sizeof(float));
+            float cA[12], cO[12];
+            dw_window<0, 11>(lp, cA);
+            if (ODD) dw_window<2, 8>(lp + OOFF, cO);      // odd taps use indices 4 + j + {-2, -1, 0, 1}, j = 0..3
+            float prev[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < OW; ++j) prev[j] = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                const int d = DS::d(k);
+                if (k > 0 && DS::d(k - 1) == d) continue;       // evaluated together with the first branch of its run
+                int R = 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = DS::d(k);
-            if (k > 0 && DS::d(k - 1) == d) continue;       // evaluated together with the first branch of its run
-            // branches with the same dilation read the same three rows: the run k .. k+R-1 shares one set of row reads
-            // (level 4 uses d = 1,1,2,3: 27 instead of 36 ds_read_b128 per item)
-            int R = 1;
+                for (int q = k + 1; q < 4; ++q) if (DS::d(q) == d && q == k + R) ++R;
+                float a[4][4];
 #pragma unroll
-            for (int q = k + 1; q < 4; ++q) if (DS::d(q) == d && q == k + R) ++R;
-            float a[4][OW];
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < OW; ++j) a[r][j] = 0.f;
-            if (!g.nocompute) {
+                    for (int j = 0; j < 4; ++j) a[r][j] = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const float* row = lp + (ky - 1) * d * g.LS;
-                    float rv[12];
+                    float rA[12], rO[12];
+                    if (ky == 1) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float4 q = *reinterpret_cast<const float4*>(row + 4 * i);
-                        // all four elements count as used: keeps this one ds_read_b128 (hipcc otherwise narrows the
-                        // read to the elements this dilation touches and emits ~2x as many ds_read2_b32)
-                        asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
-                        rv[4 * i] = q.x; rv[4 * i + 1] = q.y; rv[4 * i + 2] = q.z; rv[4 * i + 3] = q.w;
+                        for (int i = 0; i < 12; ++i) { rA[i] = cA[i]; rO[i] = ODD ? cO[i] : 0.f; }
+                    } else {
+                        const float* row = lp + (ky - 1) * d * g.RS;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) rO[i] = 0.f;
+                        if (STRIDE == 1) {
+                            if (d == 1) dw_window<3, 8>(row, rA); else if (d == 2) dw_window<2, 9>(row, rA);
+                            else if (d == 3) dw_window<1, 10>(row, rA); else dw_window<0, 11>(row, rA);
+                        } else if (d & 1) {
+                            dw_window<4, 7>(row, rA);                                   // centre tap only
+                            if (d == 1) dw_window<3, 7>(row + OOFF, rO); else dw_window<2, 8>(row + OOFF, rO);
+                        } else {
+                            if (d == 2) dw_window<3, 8>(row, rA); else dw_window<2, 9>(row, rA);
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (r >= R) break;
-                        const float w0 = wp[(k + r) * 9 + ky * 3], w1 = wp[(k + r) * 9 + ky * 3 + 1], w2 = wp[(k + r) * 9 + ky * 3 + 2];
+                        const float4 w4 = wp[(k + r) * 3 + ky];
 #pragma unroll
-                        for (int j = 0; j < OW; ++j) {
-                            const int ci = 4 + j * STRIDE;
-                            a[r][j] = fmaf(w0, rv[ci - d], a[r][j]);
-                            a[r][j] = fmaf(w1, rv[ci], a[r][j]);
-                            a[r][j] = fmaf(w2, rv[ci + d], a[r][j]);
+                        for (int j = 0; j < 4; ++j) {
+                            float tm, tc, tp;                   // taps at input column offsets -d, 0, +d
+                            if (STRIDE == 1) { tm = rA[4 + j - d]; tc = rA[4 + j]; tp = rA[4 + j + d]; }
+                            else if (d & 1) { tm = rO[4 + j - (d + 1) / 2]; tc = rA[4 + j]; tp = rO[4 + j + (d - 1) / 2]; }
+                            else { tm = rA[4 + j - d / 2]; tc = rA[4 + j]; tp = rA[4 + j + d / 2]; }
+                            a[r][j] = fmaf(w4.x, tm, a[r][j]);
+                            a[r][j] = fmaf(w4.y, tc, a[r][j]);
+                            a[r][j] = fmaf(w4.z, tp, a[r][j]);
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= R) break;
-                const int kk = k + r;
-                // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
-                const float sc = ep[kk * 3], sh = ep[kk * 3 + 1], al = ep[kk * 3 + 2];
-                float v[OW];
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= R) break;
+                    const int kk = k + r;
+                    // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
+                    const float4 ec = ep[kk];
+                    float v[4];
 #pragma unroll
-                for (int j = 0; j < OW; ++j) {
-                    a[r][j] += prev[j];
-                    prev[j] = a[r][j];
-                    float q = fmaf(a[r][j], sc, sh);
-                    if (has_act) q = q > 0.f ? q : al * q;
-                    v[j] = q;
+                    for (int j = 0; j < 4; ++j) {
+                        a[r][j] += prev[j];
+                        prev[j] = a[r][j];
+                        float q = fmaf(a[r][j], ec.x, ec.y);
+                        if (has_act) q = q > 0.f ? q : ec.z * q;
+                        v[j] = q;
+                    }
+                    float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
+                    if (o16) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (o8) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                        if (xb + 2 < g.Wo) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (xb + j < g.Wo) dst[j] = v[j];
+                    }
                 }
-                float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
-                if (ovec) {
-                    if constexpr (OW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < OW; ++j)
-                        if (xb + j < g.Wo) dst[j] = v[j];
-                }
+                __builtin_amdgcn_sched_barrier(0);   // one dilation at a time (keeps the register footprint small)
             }
-            __builtin_amdgcn_sched_barrier(0);   // one branch at a time (keeps the register footprint small)
         }
+        if (PERSIST) __syncthreads();                  // every wave is done reading the tile before the next one is written
     }
     if (g.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -239,68 +316,110 @@ __global__ __launch_bounds__(256, 6) void eesp_dw_hff_kernel(const float* __rest
     }
 }
 
-static int round_up4(int v) { return (v + 3) & ~3; }
+static unsigned magic20(int d) { return ((1u << 20) + (unsigned)d - 1) / (unsigned)d; }
+static bool magic_exact(unsigned mag, int dv, int limit) {
+    for (int i = 0; i < limit; ++i)
+        if ((int)(((unsigned)i * mag) >> 20) != i / dv) return false;
+    return true;
+}
 
 template <int STRIDE, class DS>
 static int launch(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out,
                   hipStream_t s) {
     constexpr int MAXD = DS::maxd();
-    constexpr int OW = 4 / STRIDE;
     DwGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.n = n; g.H = H; g.W = W;
     g.Ho = (H - 1) / STRIDE + 1;
     g.Wo = (W - 1) / STRIDE + 1;
-    g.XS = ceil_div(g.Wo, OW);
-    g.mag_xs = ((1u << 24) + (unsigned)g.XS - 1) / (unsigned)g.XS;
-    // row stride: >= 4 + W4 + 8 (window over-read), multiple of 4, and STRIDE*LS == 4*XS (mod 64 banks)
-    g.LS = round_up4(W) + 12;
-    {   // exact when 4*XS is a multiple of 4*STRIDE; otherwise the closest slip (4 floats) -- bounded search
-        int best_ls = g.LS, best_err = 1 << 30;
-        for (int cand = g.LS; cand < g.LS + 64; cand += 4) {
-            const int err = (STRIDE * cand - 4 * g.XS) & 63;
-            if (err < best_err) { best_err = err; best_ls = cand; }
-            if (err == 0) break;
-        }
-        g.LS = best_ls;
+    g.XS = ceil_div(g.Wo, 4);
+    g.NCH = ceil_div(W, 4);
+    // staged row: stride 1: [4 zero | W values | zero fill] >= 4*XS + 8 floats and RS == 4*XS (mod 64 banks), so that lane
+    // addresses stay linear across row ends; stride 2: E and O arrays of LSH >= 4*XS + 8 floats each, LSH == XS (mod 16)
+    if (STRIDE == 1) {
+        int ls = std::max(4 * g.XS + 8, 4 * g.NCH + 8);
+        while (((ls - 4 * g.XS) & 63) != 0) ls += 4;
+        g.RS = ls;
+    } else {
+        int lsh = (std::max(4 * g.XS + 8, 2 * g.NCH + 8) + 3) & ~3;
+        if ((g.XS & 3) == 0) { while (((lsh - g.XS) & 15) != 0) lsh += 4; }      // (XS % 4 != 0: no exact fit; a few 2-way conflicts)
+        g.RS = 2 * lsh;
     }
-    static const int dbg_nc = getenv("MSPL_DW_NOCOMPUTE") ? atoi(getenv("MSPL_DW_NOCOMPUTE")) : 0;
     static const int dbg_lds = getenv("MSPL_DW_LDS") ? atoi(getenv("MSPL_DW_LDS")) : 0;     // KiB per workgroup
     static const int dbg_cp = getenv("MSPL_DW_CP") ? atoi(getenv("MSPL_DW_CP")) : 0;
-    g.nocompute = dbg_nc;
+    static const int dbg_th = getenv("MSPL_DW_TH") ? atoi(getenv("MSPL_DW_TH")) : 0;
+    static const int dbg_wgs = getenv("MSPL_DW_WGS") ? atoi(getenv("MSPL_DW_WGS")) : 0;     // persistent workgroups per CU
     static unsigned long long* stamp_buf = nullptr;
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_DW_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)4 * 65536 * sizeof(unsigned long long));
-    // Tile = CP planes x one band.  Small tiles -> many workgroups per CU in different phases.
-    const size_t lds_budget = (size_t)(dbg_lds > 0 ? dbg_lds : 24) * 1024;
+    // Tile = CP planes x one band of TH output rows, worked on by T threads.  Constraints: LDS budget; at most T * DW_PF staging
+    // chunks.  Score (lower is better): idle lanes of the item loop (items rarely fill whole rounds of T lanes: 18 x 8 strips
+    // = 144 items leave 44 % of 256 lanes idle, 4 such planes fill 192 lanes three times) x halo rows re-read x a penalty for
+    // fewer tiles than the chip needs to be busy.
+    static const int dbg_thr = getenv("MSPL_DW_THREADS") ? atoi(getenv("MSPL_DW_THREADS")) : 0;
+    static const int dbg_persist = getenv("MSPL_DW_PERSIST") ? atoi(getenv("MSPL_DW_PERSIST")) : -1;
+    const size_t lds_budget = (size_t)(dbg_lds > 0 ? dbg_lds : 38) * 1024;
     auto rin_of = [&](int th) { return (th - 1) * STRIDE + 1 + 2 * MAXD; };
-    int th = g.Ho;
-    while (th > 1 && (size_t)rin_of(th) * g.LS * 4 > lds_budget) th = (th + 1) / 2;
-    MSPL_REQUIRE((size_t)rin_of(th) * g.LS * 4 + 512 <= 64 * 1024, MSPL_ERR_UNSUPPORTED,
-                 "eesp_dw_hff: row of %d floats does not fit the LDS tile", W);
-    const int bands = ceil_div(g.Ho, th);
-    int best_cp = 1;
+    auto lds_of = [&](int th, int cp) { return ((size_t)cp * rin_of(th) * g.RS + 16 + (size_t)cp * 64) * sizeof(float); };
+    int th = 0, cp = 0, T = 0;
     double best = 1e30;
-    for (int cp = 1; cp <= 16; cp *= 2) {
-        if (n % cp || (size_t)rin_of(th) * g.LS * 4 * cp > lds_budget || cp * 36 > 256) break;
-        const int items = cp * th * g.XS;
-        const int64_t tiles = (int64_t)N * (n / cp) * bands;
-        const double waste = (double)(ceil_div(items, 256) * 256) / items;     // idle lanes in the item loop
-        const double starve = tiles >= 2048 ? 1.0 : 2048.0 / (double)tiles;    // too few workgroups to fill the chip
-        const double score = waste * starve;
-        if (score < best - 1e-9) { best = score; best_cp = cp; }
+    for (int c = 1; c <= 4; c *= 2) {
+        if (n % c) break;
+        for (int nb = 1; nb <= g.Ho; ++nb) {
+            const int h = ceil_div(g.Ho, nb);
+            if (nb > 1 && ceil_div(g.Ho, nb - 1) == h) continue;          // same band height as the previous count
+            if (lds_of(h, c) > lds_budget) continue;
+            for (int t = 64; t <= 256; t += 64) {
+                if ((int64_t)c * rin_of(h) * g.NCH > (int64_t)t * DW_PF) continue;
+                const int items = c * h * g.XS;
+                const double waste = (double)(ceil_div(items, t) * t) / items;
+                const double halo = (double)rin_of(h) / (double)((h - 1) * STRIDE + 1);
+                const int64_t tiles = (int64_t)N * (n / c) * ceil_div(g.Ho, h);
+                const double waves = (double)tiles * (t / 64);
+                const double starve = waves >= 2048 ? 1.0 : 2048.0 / waves;        // < 2 waves per SIMD: latency shows
+                const double rounds = items / (double)t;                             // long per-thread chains of tiny launches
+                const double score = waste * (0.5 + 0.5 * halo) * starve * (1.0 + 0.02 * rounds) * (t < 128 ? 1.1 : 1.0);
+                if (score < best - 1e-9) { best = score; th = h; cp = c; T = t; }
+            }
+        }
     }
-    int cp = best_cp;
-    if (dbg_cp > 0 && n % dbg_cp == 0 && dbg_cp * 36 <= 256) cp = dbg_cp;
+    MSPL_REQUIRE(T > 0, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: row of %d floats does not fit the LDS tile", W);
+    if (dbg_th > 0 || dbg_cp > 0 || dbg_thr > 0) {        // tuning overrides (checked against the same constraints)
+        const int h2 = dbg_th > 0 ? std::min(dbg_th, g.Ho) : th, c2 = dbg_cp > 0 ? dbg_cp : cp, t2 = dbg_thr > 0 ? dbg_thr : T;
+        if (c2 <= 4 && n % c2 == 0 && t2 % 64 == 0 && t2 >= 64 && t2 <= (dbg_persist == 1 ? 256 : 1024) && lds_of(h2, c2) <= 64 * 1024 &&
+            (int64_t)c2 * rin_of(h2) * g.NCH <= (int64_t)t2 * DW_PF) { th = h2; cp = c2; T = t2; }
+    }
+    const int bands = ceil_div(g.Ho, th);
     g.TH = th; g.CP = cp;
     g.RIN = rin_of(th);
     g.bands = bands;
     g.cgroups = n / cp;
-    const size_t lds = ((size_t)cp * g.RIN * g.LS + 16 + (size_t)cp * 48) * sizeof(float);
-    const int64_t blocks = (int64_t)N * g.cgroups * g.bands;
-    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_dw_hff: grid too large");
+    g.chunks = cp * g.RIN * g.NCH;
+    const int64_t ntiles = (int64_t)N * g.cgroups * g.bands;
+    MSPL_REQUIRE(ntiles < (1ll << 30), MSPL_ERR_BAD_SHAPE, "eesp_dw_hff: too many tiles");
+    g.ntiles = (int)ntiles;
+    g.mag_xs = magic20(g.XS); g.mag_nch = magic20(g.NCH); g.mag_rin = magic20(g.RIN);
+    bool mag_ok = cp * th * g.XS < 4096 && g.chunks <= 4096 && g.RIN < 4096 && g.NCH < 4096 &&
+                  magic_exact(g.mag_nch, g.NCH, g.chunks) &&
+                  magic_exact(g.mag_rin, g.RIN, cp * g.RIN) && magic_exact(g.mag_xs, g.XS, cp * th * g.XS);
+    for (int rh = 1; rh <= th && mag_ok; ++rh) mag_ok = magic_exact(magic20(rh), rh, cp * rh);     // (the last band may be shorter)
+    MSPL_REQUIRE(mag_ok, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: tile geometry outside the magic-division range (CP=%d TH=%d XS=%d)", cp, th, g.XS);
+    const size_t lds = lds_of(th, cp);
+    MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: tile of %zu bytes exceeds LDS", lds);
+    // one tile per workgroup unless the launch is many rounds deep; then persistent workgroups with register prefetch
+    int per_cu = (int)std::min<size_t>(std::max(1, 3 * 256 / T), (160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (dbg_wgs > 0) per_cu = dbg_wgs;
+    bool persist = T <= 256 && ntiles > (int64_t)256 * per_cu * 3;
+    if (dbg_persist >= 0) persist = dbg_persist != 0 && T <= 256;
+    int64_t blocks = ntiles;
+    if (persist) {
+        blocks = std::min<int64_t>(ntiles, (int64_t)256 * per_cu);
+        if (blocks > 8) blocks -= blocks % 8;             // ids b and b + 8 share an XCD: keep the stride a multiple of 8
+    }
     g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
-    hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS>), dim3((unsigned)blocks), dim3(256), lds, s, x, w, g, e, out);
+    if (persist) hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, true>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
+    else hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, false>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
     MSPL_CHECK_LAUNCH("eesp_dw_hff");
     if (g.stamps) {   // debug only: synchronous dump of the phase timeline (100 MHz ticks)
         (void)hipDeviceSynchronize();
@@ -309,7 +428,15 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
         unsigned long long t0 = ~0ull, t3 = 0; double a = 0, b = 0, c = 0;
         for (int64_t i = 0; i < blocks; ++i) { if (host[4*i] < t0) t0 = host[4*i]; if (host[4*i+3] > t3) t3 = host[4*i+3]; a += host[4*i+1]-host[4*i]; b += host[4*i+2]-host[4*i+1]; c += host[4*i+3]-host[4*i+2]; }
         double late = 0; for (int64_t i = 0; i < blocks; ++i) late += host[4*i] - t0;
-        fprintf(stderr, "[k2 stamp] blocks=%lld span=%.2fus  avg: start-delay=%.2fus load+ldswrite=%.2fus barrier=%.2fus compute+store=%.2fus\n", (long long)blocks, (t3-t0)/100.0, late/blocks/100.0, a/blocks/100.0, b/blocks/100.0, c/blocks/100.0);
+        fprintf(stderr, "[k2 stamp] blocks=%lld tiles=%lld span=%.2fus  avg: start-delay=%.2fus first load+ldswrite=%.2fus barrier=%.2fus compute+store(+more tiles)=%.2fus\n", (long long)blocks, (long long)ntiles, (t3-t0)/100.0, late/blocks/100.0, a/blocks/100.0, b/blocks/100.0, c/blocks/100.0);
+        {   // start / end time distribution (us after the first start), sorted
+            static double st[65536], en[65536];
+            for (int64_t i = 0; i < blocks; ++i) { st[i] = (host[4*i] - t0) / 100.0; en[i] = (host[4*i+3] - t0) / 100.0; }
+            std::sort(st, st + blocks); std::sort(en, en + blocks);
+            auto q = [&](double* v, double f) { return v[(int64_t)(f * (blocks - 1))]; };
+            fprintf(stderr, "[k2 stamp]   start p10/50/75/90/100 = %.2f %.2f %.2f %.2f %.2f us | end p10/50/90/100 = %.2f %.2f %.2f %.2f us | CP=%d TH=%d T=%d persist=%d RS=%d lds=%zu\n",
+                    q(st, .1), q(st, .5), q(st, .75), q(st, .9), q(st, 1.0), q(en, .1), q(en, .5), q(en, .9), q(en, 1.0), g.CP, g.TH, T, (int)persist, g.RS, lds);
+        }
     }
     return MSPL_OK;
 }
@@ -325,6 +452,7 @@ extern "C" int mspl_eesp_dw_hff_fwd(const float* x, const float* w, const int32_
     MSPL_REQUIRE(N > 0 && n > 0 && H > 0 && W > 0, MSPL_ERR_BAD_SHAPE,
                  "eesp_dw_hff: bad shape N=%d n=%d H=%d W=%d", N, n, H, W);
     MSPL_REQUIRE(stride == 1 || stride == 2, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: stride %d (1 or 2)", stride);
+    MSPL_REQUIRE((int64_t)4 * H * W < (1ll << 29), MSPL_ERR_BAD_SHAPE, "eesp_dw_hff: plane %dx%d too large", H, W);
     if (int rc = check_epi(ep, 4 * n, "eesp_dw_hff")) return rc;
     MSPL_REQUIRE(!ep || (!ep->pre_add && !ep->residual && !ep->reinf_r && !ep->gate), MSPL_ERR_UNSUPPORTED,
                  "eesp_dw_hff: only scale/shift/alpha epilogue terms are supported (br_after_cat)");

@@ -6,6 +6,10 @@
 //   Full-resolution logits are never written unless the caller asks for them.
 // merge_labels: uest_seg_multi_os.py:695-718 (merge_outputs) + :919-921 (class histogram).  Pure integer,
 //   S bytes in + 1 byte out per pixel; bit-exact contract.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -105,25 +109,14 @@ __global__ __launch_bounds__(256) void label_epilogue_kernel(const float* __rest
 template <int CMAX>
 __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
                                                                  LeGeom g, const uint8_t* __restrict__ lut,
-                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld,
-                                                                 unsigned long long* __restrict__ hist, int ncls) {
+                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     // XCD-aware row order: workgroups are dealt to the 8 XCDs round-robin by linear id, and neighbouring output rows read the
     // same source rows -- in natural order every source row was fetched into four different L2s (PMC: 189 MB read for 36 MB of
     // logits).  Row slot s = blockIdx.y maps to row (s % 4) * ceil(H/4) + s / 4, so each XCD (pair) walks one contiguous quarter.
     const int rq = (g.H + 3) >> 2;
     const int y = (int)(blockIdx.y & 3) * rq + (int)(blockIdx.y >> 2), n = blockIdx.z;
-    if (y >= g.H) return;                                                    // uniform: the whole workgroup leaves
-    // class histogram of the labels this workgroup writes (the single-source pass: uest_seg_multi_os.py:785-815 counts the
-    // label map it has just produced -- no separate merge launch): one ballot per class and wave, LDS sum, one 64-bit atomic
-    // per non-empty class and workgroup.  Labels >= ncls are not counted.
-    __shared__ unsigned int sh_hist[32];
-    if (hist) {
-        if (threadIdx.x < 32) sh_hist[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    int my_label = -1;
-    if (x < g.W) {
+    if (x >= g.W || y >= g.H) return;
     int my0, my1, mx0, mx1;  float mwy0, mwy1, mwx0, mwx1;
     bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);                      // uniform
     bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
@@ -167,8 +160,7 @@ __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __
         for (int c = 0; c < CMAX; ++c) {
             if (c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
         }
-        my_label = lut ? lut[best] : best;
-        labels[pix] = (uint8_t)my_label;
+        labels[pix] = lut ? lut[best] : (uint8_t)best;
     }
     if (kld) {
         float k = 0.f;
@@ -190,14 +182,262 @@ __global__ __launch_bounds__(256) void label_epilogue_reg_kernel(const float* __
         }
         kld[pix] = k;
     }
-    }   // x < W
-    if (hist) {
-        for (int c = 0; c < ncls; ++c) {
-            const unsigned long long b = __ballot(my_label == c);
-            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&sh_hist[c], (unsigned)__popcll(b));
+}
+
+// Label pass form, LDS staged (the fast path): a workgroup owns LE_RB output rows x 256 output columns of one image.  The
+// source rows those pixels interpolate from (both heads, all classes, the column range of the 256 pixels + one replicated
+// column) are staged once in LDS with coalesced loads; a thread then produces the LE_RB pixels of its column from LDS
+// (2 ds_read2_b32 per class, head and pixel instead of 4 scattered 4-byte global loads: the register form above is bound by the
+// texture-address path, 104 wave-loads per pixel).  Arithmetic and its order are exactly the register form's, so the labels
+// and the KL map are bit-identical.  Optionally the class histogram of the labels written: per-thread compare -> wave ballot
+// -> LDS -> one row of 32 partial counts per workgroup in `hist_ws` (summed by label_hist_reduce_kernel; same-address
+// device atomics from ~10^4 workgroups serialise: 73 us measured for 1.2e5 of them).
+constexpr int LE_RB = 4;
+
+struct LeStage {
+    int nrm, nra;          // staged source rows per band (max over bands), main / aux
+    int wms, was;          // staged columns per row incl. the replicated one (max over column blocks)
+    int ncls;              // histogram bins (0: no histogram)
+    unsigned magc;         // ceil(65536 / C): pair / C == (pair * magc) >> 16 for pair < 4096
+    int vec;               // rows 16-byte aligned: stage with float4 chunks (wms / was are multiples of 4, columns start at a multiple of 4)
+    unsigned magqm, magqa; // exact divisions by wms / 4 and was / 4: (k * mag) >> 20 (verified on the host)
+};
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
+                                                                 LeGeom g, LeStage st, const uint8_t* __restrict__ lut,
+                                                                 uint8_t* __restrict__ labels, float* __restrict__ kld,
+                                                                 unsigned int* __restrict__ hist_ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ml = smem;                                          // [nrm][C][wms]
+    float* al = smem + (size_t)st.nrm * g.C * st.wms;          // [nra][C][was]
+    unsigned int* sh_hist = reinterpret_cast<unsigned int*>(al + (size_t)st.nra * g.C * st.was);   // [32]
+    const int tid = threadIdx.x;
+    const int xb = blockIdx.x * 256;
+    // XCD-aware band order (see the register form): band slot s -> band (s % 4) * ceil(nbands/4) + s / 4
+    const int nbands = (g.H + LE_RB - 1) / LE_RB;
+    const int bq = (nbands + 3) >> 2;
+    const int band = (int)(blockIdx.y & 3) * bq + (int)(blockIdx.y >> 2), n = blockIdx.z;
+    const unsigned blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (band >= nbands) {                                      // uniform: a padding slot of the band order
+        if (hist_ws && tid < 32) hist_ws[(size_t)blk * 32 + tid] = 0u;
+        return;
+    }
+    const int y0 = band * LE_RB;
+    const int ylast = min(y0 + LE_RB, g.H) - 1, xlast = min(xb + 256, g.W) - 1;
+    // uniform source ranges of this tile
+    int rm_lo, rm_hi, cm_lo, cm_hi, t0, t1;  float f0, f1;
+    bilinear_src(g.shm, y0, g.Hm, rm_lo, t1, f0, f1);
+    bilinear_src(g.shm, ylast, g.Hm, t0, rm_hi, f0, f1);
+    bilinear_src(g.swm, xb, g.Wm, cm_lo, t1, f0, f1);
+    bilinear_src(g.swm, xlast, g.Wm, t0, cm_hi, f0, f1);
+    int ra_lo = 0, ra_hi = -1, ca_lo = 0, ca_hi = -1;
+    if (auxp) {
+        bilinear_src(g.sha, y0, g.Ha, ra_lo, t1, f0, f1);
+        bilinear_src(g.sha, ylast, g.Ha, t0, ra_hi, f0, f1);
+        bilinear_src(g.swa, xb, g.Wa, ca_lo, t1, f0, f1);
+        bilinear_src(g.swa, xlast, g.Wa, t0, ca_hi, f0, f1);
+    }
+    if (hist_ws && tid < 32) sh_hist[tid] = 0;
+
+    // ---- stage.  Column j of a staged row <-> source column cmA + j, cmA = cm_lo rounded down to a multiple of 4.
+    const int cmA = st.vec ? (cm_lo & ~3) : cm_lo, caA = st.vec ? (ca_lo & ~3) : ca_lo;
+    {
+        const int mplane = g.Hm * g.Wm, aplane = g.Ha * g.Wa;
+        const float* mb = mainp + (size_t)n * g.C * mplane;
+        const float* ab = auxp ? auxp + (size_t)n * g.C * aplane : nullptr;
+        const int nm = (rm_hi - rm_lo + 1) * g.C, na = auxp ? (ra_hi - ra_lo + 1) * g.C : 0;
+        if (st.vec) {
+            // 16-byte chunks: chunk i -> (pair = i / CPQ, q = i % CPQ) with CPQ = wms / 4 (main) resp. was / 4 (aux); every chunk of
+            // the tile is requested before the first LDS write (one memory round trip per tile)
+            const int cqm = st.wms >> 2, cqa = st.was >> 2;
+            const int nmc = nm * cqm, total = nmc + na * cqa;
+            constexpr int UL = 12;
+            for (int base = 0; base < total; base += 256 * UL) {
+                float4 v[UL];  int dst[UL];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int i = base + u * 256 + tid;
+                    dst[u] = -1;  v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < total) {
+                        const bool ism = i < nmc;
+                        const int k = ism ? i : i - nmc;
+                        const int pair = (int)(((unsigned)k * (ism ? st.magqm : st.magqa)) >> 20), q = k - pair * (ism ? cqm : cqa);
+                        const int row = (int)(((unsigned)pair * st.magc) >> 16), c = pair - row * g.C;
+                        const int col = (ism ? cmA : caA) + 4 * q;
+                        if (col < (ism ? g.Wm : g.Wa) && col <= (ism ? cm_hi : ca_hi)) {
+                            const float* src = ism ? mb + (size_t)c * mplane + (rm_lo + row) * g.Wm + col
+                                                   : ab + (size_t)c * aplane + (ra_lo + row) * g.Wa + col;
+                            v[u] = *reinterpret_cast<const float4*>(src);
+                            dst[u] = ism ? pair * st.wms + 4 * q : (int)(al - ml) + pair * st.was + 4 * q;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UL; ++u)
+                    if (dst[u] >= 0) *reinterpret_cast<float4*>(ml + dst[u]) = v[u];
+            }
+        } else {
+            // 4-byte form (rows not 16-byte aligned): (row, class) pairs round-robin over the two halves of the workgroup; a
+            // half's 128 lanes take the pair's columns j = lane and lane + 128; 8 pairs per thread in flight
+            const int half = __builtin_amdgcn_readfirstlane(tid >> 7), lane = tid & 127;
+            const int wm = cm_hi - cm_lo + 1, wa = ca_hi - ca_lo + 1;
+            constexpr int UL = 8;
+            for (int base = half; base < nm + na; base += 2 * UL) {
+                float v[UL][2];  int dst[UL][2];
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const int it = base + 2 * u;                                   // uniform per half
+                    dst[u][0] = dst[u][1] = -1;  v[u][0] = v[u][1] = 0.f;
+                    if (it < nm + na) {
+                        const bool ism = it < nm;
+                        const int pair = ism ? it : it - nm;
+                        const int row = (int)(((unsigned)pair * st.magc) >> 16), c = pair - row * g.C;
+                        const int w = ism ? wm : wa;
+                        const float* src = ism ? mb + (size_t)c * mplane + (rm_lo + row) * g.Wm + cm_lo
+                                               : ab + (size_t)c * aplane + (ra_lo + row) * g.Wa + ca_lo;
+                        const int d0 = ism ? pair * st.wms : (int)(al - ml) + pair * st.was;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int j = lane + 128 * h2;
+                            if (j < w) { v[u][h2] = src[j];  dst[u][h2] = d0 + j; }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    if (dst[u][0] >= 0) ml[dst[u][0]] = v[u][0];
+                    if (dst[u][1] >= 0) ml[dst[u][1]] = v[u][1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int x = xb + tid;
+    unsigned int cnt_mask_lo = 0;      // labels of this thread's LE_RB pixels, 8 bits each (0xff = none)
+    if (x < g.W) {
+        int mx0, mx1, ax0 = 0, ax1 = 0;  float mwx0, mwx1, awx0 = 0.f, awx1 = 0.f;
+        bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
+        if (auxp) bilinear_src(g.swa, x, g.Wa, ax0, ax1, awx0, awx1);
+        const float* mcol = ml + (mx0 - cmA);
+        const float* acol = al + (ax0 - caA);
+        const int mdx = mx1 - mx0, adx = ax1 - ax0;             // 1, or 0 at the clamped right edge (the reference reads column i1)
+#pragma unroll 1
+        for (int r = 0; r < LE_RB; ++r) {
+            const int y = y0 + r;
+            unsigned lab8 = 0xffu;
+            if (y < g.H) {                                              // uniform
+                int my0, my1;  float mwy0, mwy1;
+                bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);     // uniform
+                const float* mr0 = mcol + (size_t)(my0 - rm_lo) * g.C * st.wms;
+                const float* mr1 = mcol + (size_t)(my1 - rm_lo) * g.C * st.wms;
+                float m[CMAX], a[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    m[c] = -INFINITY;
+                    if (c < g.C) {
+                        const float top = mwx0 * mr0[c * st.wms] + mwx1 * mr0[c * st.wms + mdx];
+                        const float bot = mwx0 * mr1[c * st.wms] + mwx1 * mr1[c * st.wms + mdx];
+                        m[c] = mwy0 * top + mwy1 * bot;
+                    }
+                }
+                if (auxp) {
+                    int ay0, ay1;  float awy0, awy1;
+                    bilinear_src(g.sha, y, g.Ha, ay0, ay1, awy0, awy1);
+                    const float* ar0 = acol + (size_t)(ay0 - ra_lo) * g.C * st.was;
+                    const float* ar1 = acol + (size_t)(ay1 - ra_lo) * g.C * st.was;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        a[c] = -INFINITY;
+                        if (c < g.C) {
+                            const float top = awx0 * ar0[c * st.was] + awx1 * ar0[c * st.was + adx];
+                            const float bot = awx0 * ar1[c * st.was] + awx1 * ar1[c * st.was + adx];
+                            a[c] = awy0 * top + awy1 * bot;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) a[c] = c < g.C ? 0.f : -INFINITY;
+                }
+                const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+                if (labels) {
+                    float omax = -INFINITY;  int best = 0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
+                    }
+                    lab8 = lut ? (unsigned)lut[best] : (unsigned)best;
+                    labels[pix] = (uint8_t)lab8;
+                }
+                if (kld) {
+                    float k = 0.f;
+                    if (auxp) {
+                        float M1 = -INFINITY, M2 = -INFINITY;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) { M1 = fmaxf(M1, m[c]); M2 = fmaxf(M2, a[c]); }
+                        float S1 = 0.f, T1 = 0.f, S2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) {
+                            if (c < g.C) {
+                                const float e1 = __expf(m[c] - M1);
+                                S1 += e1;
+                                T1 = fmaf(e1, m[c] - a[c], T1);
+                                S2 += __expf(a[c] - M2);
+                            }
+                        }
+                        k = T1 / S1 - (M1 + __logf(S1)) + (M2 + __logf(S2));
+                    }
+                    kld[pix] = k;
+                }
+            }
+            cnt_mask_lo |= lab8 << (8 * r);
+        }
+    } else {
+        cnt_mask_lo = 0xffffffffu;
+    }
+    if (hist_ws) {
+        // counts per class over the wave (4 pixels per lane), then LDS, then this workgroup's row of the workspace
+        for (int c = 0; c < st.ncls; ++c) {
+            unsigned cnt = 0;
+#pragma unroll
+            for (int r = 0; r < LE_RB; ++r) cnt += (((cnt_mask_lo >> (8 * r)) & 0xffu) == (unsigned)c);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+            if ((tid & 63) == 0 && cnt) atomicAdd(&sh_hist[c], cnt);
         }
         __syncthreads();
-        if ((int)threadIdx.x < ncls && sh_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
+        if (tid < 32) hist_ws[(size_t)blk * 32 + tid] = tid < st.ncls ? sh_hist[tid] : 0u;
+    }
+}
+
+// Sum the per-workgroup partial histograms (rows of 32 counts) into the caller's 64-bit bins: LE_RED workgroups, each sums a
+// slice of the rows (8 independent coalesced loads per thread in flight) and adds its 32 sums with one atomic per bin.
+constexpr int LE_RED = 16;
+__global__ __launch_bounds__(256) void label_hist_reduce_kernel(const unsigned int* __restrict__ ws, int nrows, int ncls,
+                                                                unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int part[8][32];
+    const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;                 // 8 rows per step and workgroup
+    unsigned int s = 0;
+    const int step = 8 * LE_RED;
+    int r = blockIdx.x * 8 + sub;
+    for (; r + 7 * step < nrows; r += 8 * step) {
+        unsigned int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(r + u * step) * 32 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < nrows; r += step) s += ws[(size_t)r * 32 + c];
+    part[sub][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && (int)threadIdx.x < ncls) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];
+        if (t) atomicAdd(&hist[threadIdx.x], t);
     }
 }
 
@@ -339,34 +579,40 @@ __global__ __launch_bounds__(256) void miou_areas_kernel(const float* __restrict
 
 using namespace mspl;
 
+// Host twin of bilinear_src's index part (same fp32 operations; the build uses -ffp-contract=off).
+static void le_host_idx(float scale, int dst, int in_size, int& i0, int& i1) {
+    const float real = scale * (float)dst;
+    int idx = (int)floorf(real);
+    if (idx > in_size - 1) idx = in_size - 1;
+    i0 = idx;
+    i1 = idx + ((idx < in_size - 1) ? 1 : 0);
+}
+
+// Largest number of source positions any tile of `tile` consecutive output positions touches; with align4 the first position
+// is rounded down to a multiple of 4 and the count up to a multiple of 4 (16-byte staging chunks).
+static int le_span(int in_size, int out_size, int tile, bool align4) {
+    const float sc = bilinear_scale(in_size, out_size);
+    int best = 1;
+    for (int o0 = 0; o0 < out_size; o0 += tile) {
+        const int o1 = std::min(o0 + tile, out_size) - 1;
+        int a0, a1, b0, b1;
+        le_host_idx(sc, o0, in_size, a0, a1);
+        le_host_idx(sc, o1, in_size, b0, b1);
+        if (align4) a0 &= ~3;
+        int cnt = b1 - a0 + 1;
+        if (align4) cnt = (cnt + 3) & ~3;
+        best = std::max(best, cnt);
+    }
+    return best;
+}
+
+static int64_t le_blocks(int N, int H, int W) { return (int64_t)ceil_div(W, 256) * (4 * ceil_div(ceil_div(H, LE_RB), 4)) * N; }
+
 static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, int32_t C,
                                int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
                                const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
-                               float* main_up, float* aux_up, unsigned long long* hist, int32_t ncls, void* stream);
-
-extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
-                                       int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
-                                       const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
-                                       float* main_up, float* aux_up, void* stream) {
-    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, prob, kld, main_up, aux_up, nullptr, 0, stream);
-}
-
-extern "C" int mspl_label_epilogue_hist_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
-                                            int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
-                                            const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
-                                            int32_t num_classes, void* stream) {
-    MSPL_REQUIRE(labels && hist, MSPL_ERR_NULL_POINTER, "label_epilogue_hist: labels and hist are required");
-    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 32, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d classes (1..32)", num_classes);
-    MSPL_REQUIRE(C <= 24, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d logit channels (the fused form holds <= 24 in registers; "
-                 "use label_epilogue + merge_labels)", C);
-    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, nullptr, kld, nullptr, nullptr, hist, num_classes,
-                               stream);
-}
-
-static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, int32_t C,
-                               int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
-                               const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
-                               float* main_up, float* aux_up, unsigned long long* hist, int32_t ncls, void* stream) {
+                               float* main_up, float* aux_up, unsigned long long* hist, int32_t ncls, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
     MSPL_REQUIRE(mainp, MSPL_ERR_NULL_POINTER, "label_epilogue: null main logits");
     MSPL_REQUIRE(labels || prob || kld || main_up || aux_up, MSPL_ERR_NULL_POINTER, "label_epilogue: no output requested");
     MSPL_REQUIRE(N > 0 && C > 0 && Hm > 0 && Wm > 0 && H > 0 && W > 0 && (!aux || (Ha > 0 && Wa > 0)),
@@ -379,20 +625,96 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
     g.sha = aux ? bilinear_scale(Ha, H) : 0.f; g.swa = aux ? bilinear_scale(Wa, W) : 0.f;
     const int64_t total = (int64_t)N * H * W;
     MSPL_REQUIRE(ceil_div64(total, 256) < (1ll << 31), MSPL_ERR_BAD_SHAPE, "label_epilogue: grid too large");
-    if (!prob && !main_up && !aux_up && C <= 24 && H <= 65535 && N <= 65535 &&
-        (int64_t)N * C * Hm * Wm < (1ll << 31) && (int64_t)N * C * (int64_t)Ha * Wa < (1ll << 31)) {
+    hipStream_t st_ = (hipStream_t)stream;
+    const bool label_form = !prob && !main_up && !aux_up && C <= 24 && H <= 65535 * LE_RB / 4 && N <= 65535 &&
+                            (int64_t)N * C * Hm * Wm < (1ll << 31) && (int64_t)N * C * (int64_t)Ha * Wa < (1ll << 31);
+    if (label_form) {
+        // LDS-staged form when the tile's source rows fit (they do for the x2 / x4 heads of the path); else the register form
+        LeStage st;
+        st.vec = (Wm % 4 == 0) && (!aux || Wa % 4 == 0) && (((uintptr_t)mainp) & 15) == 0 && (((uintptr_t)aux) & 15) == 0;
+        st.nrm = le_span(Hm, H, LE_RB, false);  st.wms = le_span(Wm, W, 256, st.vec);
+        st.nra = aux ? le_span(Ha, H, LE_RB, false) : 0;  st.was = aux ? le_span(Wa, W, 256, st.vec) : 4;
+        if (!st.vec) { st.wms = (st.wms + 3) & ~3; st.was = (st.was + 3) & ~3; }      // keep the second head's base 16-byte aligned
+        st.ncls = hist ? ncls : 0;
+        st.magc = (65536u + (unsigned)C - 1) / (unsigned)C;
+        st.magqm = ((1u << 20) + (unsigned)(st.wms >> 2) - 1) / (unsigned)(st.wms >> 2);
+        st.magqa = ((1u << 20) + (unsigned)(st.was >> 2) - 1) / (unsigned)(st.was >> 2);
+        {   // exactness of the two magic divisions over the ranges used (else: 4-byte staging, which needs neither)
+            const int nmc = st.nrm * C * (st.wms >> 2), nac = st.nra * C * (st.was >> 2);
+            bool ok = nmc < 65536 && nac < 65536;
+            for (int k = 0; k < nmc && ok; ++k) ok = (int)(((unsigned)k * st.magqm) >> 20) == k / (st.wms >> 2);
+            for (int k = 0; k < nac && ok; ++k) ok = (int)(((unsigned)k * st.magqa) >> 20) == k / (st.was >> 2);
+            if (!ok) st.vec = 0;
+        }
+        const size_t lds = ((size_t)st.nrm * C * st.wms + (size_t)st.nra * C * st.was + 32) * sizeof(float);
+        static const int dbg_reg = getenv("MSPL_LE_REG") ? atoi(getenv("MSPL_LE_REG")) : 0;     // tuning aid: force the register form
+        if (lds <= 128 * 1024 && (st.nrm + st.nra) * C < 4096 && st.wms <= 256 && st.was <= 256 && !(dbg_reg && !hist)) {
+            const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)(4 * ceil_div(ceil_div(H, LE_RB), 4)), (unsigned)N);
+            unsigned int* ws = nullptr;
+            if (hist) {
+                const int64_t need = le_blocks(N, H, W) * 32 * (int64_t)sizeof(unsigned int);
+                MSPL_REQUIRE(workspace && workspace_bytes >= need, MSPL_ERR_BAD_SHAPE,
+                             "label_epilogue_hist: workspace of %lld bytes, need %lld (mspl_label_epilogue_hist_workspace_bytes)",
+                             (long long)workspace_bytes, (long long)need);
+                ws = (unsigned int*)workspace;
+            }
+            static const bool big_lds = [] {          // C = 24 at 256 columns needs 72 KB (the default cap is 64 KB)
+                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+                return ok;
+            }();
+            MSPL_REQUIRE(big_lds || lds <= 64 * 1024, MSPL_ERR_HIP, "label_epilogue: could not raise the dynamic LDS limit");
+            if (C <= 8) hipLaunchKernelGGL(label_epilogue_lds_kernel<8>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
+            else if (C <= 16) hipLaunchKernelGGL(label_epilogue_lds_kernel<16>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
+            else hipLaunchKernelGGL(label_epilogue_lds_kernel<24>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
+            MSPL_CHECK_LAUNCH("label_epilogue");
+            if (hist) {
+                hipLaunchKernelGGL(label_hist_reduce_kernel, dim3(LE_RED), dim3(256), 0, st_, ws, (int)le_blocks(N, H, W), ncls, hist);
+                MSPL_CHECK_LAUNCH("label_epilogue(histogram)");
+            }
+            return MSPL_OK;
+        }
+        MSPL_REQUIRE(!hist, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: tile does not fit the LDS-staged form (N=%d C=%d %dx%d -> %dx%d)",
+                     N, C, Hm, Wm, H, W);
         const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)(4 * ceil_div(H, 4)), (unsigned)N);     // row slots: see the kernel
-        if (C <= 8) hipLaunchKernelGGL(label_epilogue_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
-        else if (C <= 16) hipLaunchKernelGGL(label_epilogue_reg_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
-        else hipLaunchKernelGGL(label_epilogue_reg_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, mainp, aux, g, lut, labels, kld, hist, ncls);
+        MSPL_REQUIRE(H <= 65535, MSPL_ERR_BAD_SHAPE, "label_epilogue: %d rows", H);
+        if (C <= 8) hipLaunchKernelGGL(label_epilogue_reg_kernel<8>, grid, dim3(256), 0, st_, mainp, aux, g, lut, labels, kld);
+        else if (C <= 16) hipLaunchKernelGGL(label_epilogue_reg_kernel<16>, grid, dim3(256), 0, st_, mainp, aux, g, lut, labels, kld);
+        else hipLaunchKernelGGL(label_epilogue_reg_kernel<24>, grid, dim3(256), 0, st_, mainp, aux, g, lut, labels, kld);
         MSPL_CHECK_LAUNCH("label_epilogue");
         return MSPL_OK;
     }
-    MSPL_REQUIRE(!hist, MSPL_ERR_BAD_SHAPE, "label_epilogue_hist: shape outside the fused form (N=%d C=%d H=%d)", N, C, H);
-    hipLaunchKernelGGL(label_epilogue_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    MSPL_REQUIRE(!hist, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: shape outside the label-pass form (N=%d C=%d H=%d)", N, C, H);
+    hipLaunchKernelGGL(label_epilogue_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st_,
                        mainp, aux, g, lut, labels, prob, kld, main_up, aux_up, total);
     MSPL_CHECK_LAUNCH("label_epilogue");
     return MSPL_OK;
+}
+
+extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
+                                       int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                                       const uint8_t* lut, uint8_t* labels, float* prob, float* kld,
+                                       float* main_up, float* aux_up, void* stream) {
+    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, prob, kld, main_up, aux_up, nullptr, 0, nullptr, 0,
+                               stream);
+}
+
+extern "C" int64_t mspl_label_epilogue_hist_workspace_bytes(int32_t N, int32_t H, int32_t W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return le_blocks(N, H, W) * 32 * (int64_t)sizeof(unsigned int);
+}
+
+extern "C" int mspl_label_epilogue_hist_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,
+                                            int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                                            const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
+                                            int32_t num_classes, void* workspace, int64_t workspace_bytes, void* stream) {
+    MSPL_REQUIRE(labels && hist, MSPL_ERR_NULL_POINTER, "label_epilogue_hist: labels and hist are required");
+    MSPL_REQUIRE(num_classes >= 1 && num_classes <= 32, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d classes (1..32)", num_classes);
+    MSPL_REQUIRE(C <= 24, MSPL_ERR_UNSUPPORTED, "label_epilogue_hist: %d logit channels (the fused form holds <= 24 in registers; "
+                 "use label_epilogue + merge_labels)", C);
+    return label_epilogue_impl(mainp, aux, N, C, Hm, Wm, Ha, Wa, H, W, lut, labels, nullptr, kld, nullptr, nullptr, hist, num_classes,
+                               workspace, workspace_bytes, stream);
 }
 
 extern "C" int mspl_merge_labels_fwd(const uint8_t* const* src, int32_t S, int64_t npix, int32_t num_classes,

@@ -365,8 +365,10 @@ def label_epilogue_hist(main, aux, size, hist, num_classes, lut=None, want_kld=F
     res = {'labels': torch.empty((N, H, W), device=main.device, dtype=torch.uint8)}
     if want_kld:
         res['kld'] = torch.empty((N, H, W), device=main.device, dtype=torch.float32)
+    nbytes = int(lib.mspl_label_epilogue_hist_workspace_bytes(N, H, W))
+    ws = torch.empty(max(nbytes, 4), device=main.device, dtype=torch.uint8)         # per-workgroup partial histograms
     check(lib.mspl_label_epilogue_hist_fwd(_p(main), _p(aux), N, C, Hm, Wm, Ha, Wa, H, W, _p(lut), _p(res['labels']),
-                                           _p(res.get('kld')), _p(hist), int(num_classes), _stream()))
+                                           _p(res.get('kld')), _p(hist), int(num_classes), _p(ws), nbytes, _stream()))
     return res
 
 

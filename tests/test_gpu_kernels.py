@@ -185,7 +185,8 @@ def test_label_epilogue_fused_upsample_vs_unfused():
     assert np.array_equal(r['labels'].cpu().numpy()[sure], ref[sure])
 
 
-@pytest.mark.parametrize('cfg', [(2, 13, 64, 96, 13, False), (1, 5, 48, 80, 5, True), (3, 20, 32, 272, 32, False), (1, 13, 16, 16, 16, True)])
+@pytest.mark.parametrize('cfg', [(2, 13, 64, 96, 13, False), (1, 5, 48, 80, 5, True), (3, 20, 32, 272, 32, False), (1, 13, 16, 16, 16, True),
+                                 (1, 13, 36, 52, 13, False), (2, 7, 20, 26, 8, True), (1, 24, 288, 480, 24, False)])
 def test_label_epilogue_hist_equals_epilogue_plus_merge(cfg):
     """The single-source pass's fused form (labels + KL map + class histogram in one launch) against the two-launch form it
     replaces, bit for bit: label_epilogue, then merge_labels(S=1, thresh=1) as identity + histogram; and against np.bincount."""
@@ -201,6 +202,18 @@ def test_label_epilogue_hist_equals_epilogue_plus_merge(cfg):
     one = ops.label_epilogue_hist(main, aux, (H, W), h1, ncls, lut=lut, want_kld=True)
     assert torch.equal(one['labels'], lab2) and torch.equal(one['labels'], two['labels'])
     assert torch.equal(one['kld'], two['kld'])
+    # the staged form against the definition: upsample both heads (ATen), then argmax / KL on the full-resolution logits
+    mu = F.interpolate(main.cpu(), (H, W), mode='bilinear', align_corners=True)
+    au = F.interpolate(aux.cpu(), (H, W), mode='bilinear', align_corners=True)
+    o = mu + 0.5 * au
+    srt = torch.sort(o, 1, descending=True)[0]
+    sure = ((srt[:, 0] - srt[:, 1]) > 1e-4).numpy()
+    ref = o.argmax(1).numpy()
+    if lut is not None:
+        ref = lut.cpu().numpy()[ref]
+    assert np.array_equal(one['labels'].cpu().numpy()[sure], ref.astype(np.uint8)[sure]) and sure.mean() > 0.99
+    p1, lp1, lp2 = F.softmax(mu, 1), F.log_softmax(mu, 1), F.log_softmax(au, 1)
+    close(one['kld'], (p1 * lp1 - p1 * lp2).sum(1), atol=3e-5, rtol=1e-3)
     assert torch.equal(h1 - 3, h2) and int(h2.sum()) == N * H * W
     np.testing.assert_array_equal(h2.cpu().numpy(), np.bincount(lab2.cpu().numpy().ravel(), minlength=ncls))
     only = ops.label_epilogue_hist(main, None, (H, W), h1, ncls, lut=lut)                  # single-head nets, no KL map

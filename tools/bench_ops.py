@@ -158,3 +158,26 @@ def bench_stream():
 
 if len(sys.argv) > 1 and sys.argv[1] == 'stream':
     bench_stream()
+
+
+def bench_k2x():
+    """Eager launches of the K2 shapes (for a STAMPS=1 build: the launcher prints the phase timeline of every launch)."""
+    N = 16
+    for name, n, h, w, stride, dil in [('L2_0 s2 n=24', 24, 144, 240, 2, [1, 2, 3, 4]), ('L3_0 s2 n=32', 32, 72, 120, 2, [1, 2, 3, 4]),
+                                       ('L3 s1 n=64', 64, 36, 60, 1, [1, 2, 3, 4]), ('L4_0 s2 n=64', 64, 36, 60, 2, [1, 2, 3, 4]),
+                                       ('L4 s1 n=128', 128, 18, 30, 1, [1, 1, 2, 3])]:
+        x = torch.randn(N, n, h, w, device=DEV)
+        w4 = torch.randn(4, n, 3, 3, device=DEV) * 0.2
+        sc, sh, al = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        out = torch.empty(N, 4 * n, ho, wo, device=DEV)
+        ep = Epi(sc, sh, al)
+        sys.stderr.write('--- %s\n' % name)
+        sys.stderr.flush()
+        for _ in range(3):
+            ops.eesp_dw_hff(x, w4, dil, stride, ep, out=(out, 0))
+            torch.cuda.synchronize()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'k2x':
+    bench_k2x()
