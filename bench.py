@@ -346,7 +346,12 @@ def main():
                     'each other and the per-kernel averages stop describing the kernels)')
     ap.add_argument('--profile-pass', action='store_true', help='only the timed label passes: no K2 re-issues, no extra fields '
                     '(for rocprofv3 --kernel-trace --stats: the CSV then holds in-pass launches only; tools/per_kernel.py)')
+    ap.add_argument('--profile-batch', type=int, default=0, help='with --profile-pass only: images per launch (kernel scaling study; '
+                    'the metric itself is always batch 16)')
     args = ap.parse_args()
+    global BATCH
+    if args.profile_pass and args.profile_batch > 0:
+        BATCH = args.profile_batch
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one fresh process per GPU ourselves (torch.distributed.run, the

@@ -355,6 +355,10 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
                     const float* const* stage_w, const float* const* down_e, const float* br_scale,
                     const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
                     hipStream_t stream);       // pyrpool_sep.hip
+int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
+                       const float* const* stage_w, const float* const* down_e, const float* br_scale,
+                       const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
+                       hipStream_t stream);    // pyrpool_stream.hip
 
 }  // namespace mspl
 
@@ -373,6 +377,10 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
     {   // stencil form first (pyrpool_sep.hip); shapes it does not cover fall through to the table-driven kernel
         static const int force_tables = getenv("MSPL_PYR_TABLES") ? atoi(getenv("MSPL_PYR_TABLES")) : 0;
         if (!force_tables) {
+            // register-streaming form first (the standard five-branch pyramid), then the LDS-tiled stencil form
+            const int rc3 = pyrpool_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
+                                               make_epi(ep, P, h * w), out, (hipStream_t)stream);
+            if (rc3 <= 0) return rc3;
             const int rc = pyrpool_sep_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
                                            make_epi(ep, P, h * w), out, (hipStream_t)stream);
             if (rc <= 0) return rc;

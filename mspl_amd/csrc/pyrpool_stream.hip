@@ -1,0 +1,438 @@
+// K6, third form -- the fused EfficientPyrPool body as a register-streaming kernel (no LDS traffic in the inner loop).
+//
+// Same arithmetic as pyrpool_sep.hip (nn_layers/efficient_pyramid_pool.py:36-61; the up-sampled branches collapsed into
+// position-dependent separable stencils on x), same order of floating-point operations, different machine mapping.  The
+// stencil form in pyrpool_sep.hip turned out to be LDS-bound: per 1x4 strip it issues ~107 LDS reads (x patch, per-row and
+// per-column coefficient tables, low-resolution maps, branch tiles for the merge convolution) for ~430 FMAs, and a CU's four
+// SIMDs share one LDS pipe (PMC / MSPL_PYR_STOP timings).  Here nothing in the inner loop goes through LDS:
+//   * a WAVE owns one (image, plane), one block of columns and one segment of rows; lane = PXL adjacent columns; the wave
+//     walks DOWN the rows.  The 5-row window of x and the 3-row window of the five branch maps live in registers and slide.
+//   * row-dependent coefficients (A tables) are wave-uniform: computed once per wave into a small LDS table, read back with
+//     broadcast reads (3-6 per row); column-dependent coefficients (C tables, bilinear sources of the low-resolution maps) are
+//     per-lane constants computed once per wave and kept in registers; weights / BN constants of the plane are wave-uniform
+//     (scalar loads).
+//   * the merge convolution needs the branch values of the two neighbouring columns: v_mov_dpp wave_shr / wave_shl from the
+//     neighbouring lanes; lanes 0 and 63 are halo lanes (they compute branch values but write no output), so waves never
+//     exchange data and there is no barrier in the kernel.
+//   * x rows and low-resolution rows are read straight from global memory (coalesced 4/8-byte accesses, L1/L2 hits for the
+//     overlaps), the next row's loads are issued one row ahead.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace mspl {
+
+constexpr int P3_MAXB = 5;
+constexpr int P3_SEGMAX = 19;       // (SEG + 2) * 3 table entries are computed by the 64 lanes in one step
+
+struct Pyr3Geom {
+    int N, P, h, w;
+    int hs[P3_MAXB], ws[P3_MAXB];
+    float sh[P3_MAXB], sw[P3_MAXB];  // up branches: x -> U grid; down branches: E grid -> output grid
+    int SEG, nseg, ncb, CBW;         // output rows per segment, segments per plane, column blocks, output columns per block
+    unsigned total;                  // waves
+};
+
+__device__ __forceinline__ int p3_ada_s(int o, int I, int O) { return (int)(((unsigned)o * (unsigned)I) / (unsigned)O); }
+__device__ __forceinline__ int p3_ada_e(int o, int I, int O) { return (int)((((unsigned)(o + 1)) * (unsigned)I + O - 1) / (unsigned)O); }
+
+// Stencil coefficients of one output position p (row or column) and one kernel offset k of an up branch with T taps:
+// acc[q] multiplies x[p - R + q], R = (T - 1) / 2.  Identical to p2_fill_up_tables (pyrpool_sep.hip).
+template <int T>
+__device__ __forceinline__ void p3_coeffs(int p, int k, int I, int S, float sc, float (&acc)[5]) {
+    constexpr int R = (T - 1) / 2;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = 0.f;
+    if (p < 0 || p >= I) return;
+    const int us = p3_ada_s(p, S, I), ue = p3_ada_e(p, S, I);
+    const float inv = 1.0f / (float)(ue - us);
+    for (int uu = us; uu < ue; ++uu) {
+        const int v = uu + k - 1;
+        if (v < 0 || v >= S) continue;          // zero padding of the 3x3 on the up-sampled grid
+        int ia, ib;  float w0, w1;
+        bilinear_src(sc, v, I, ia, ib, w0, w1);
+        const int ta = ia - (p - R), tb = ib - (p - R);
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            if (q == ta) acc[q] += w0 * inv;
+            if (q == tb) acc[q] += w1 * inv;
+        }
+    }
+}
+
+__device__ __forceinline__ float p3_from_left(float v) {    // value of lane - 1 (0 for lane 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float p3_from_right(float v) {   // value of lane + 1 (0 for lane 63)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// One up branch for the lane's PXL columns at one row.  xw[rr][j]: image row br-2+rr, column px0-2+j.
+// Arow: this row's [ky][8] coefficients in LDS (same address for every lane: broadcast read).  Same evaluation order as
+// up_branch_strip (pyrpool_sep.hip): per kernel row ky the vertical stencil first, then the horizontal one, accumulated over ky.
+template <int T, int PXL>
+__device__ __forceinline__ void p3_up_branch(const float (&xw)[5][PXL + 4], const float* __restrict__ Arow,
+                                             const float (&C)[3][PXL][5], float (&b)[PXL]) {
+    constexpr int R0 = (5 - T) / 2;
+    constexpr int NCOL = PXL + T - 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float a[5];
+        {
+            const float4 t4 = *reinterpret_cast<const float4*>(Arow + ky * 8);
+            a[0] = t4.x; a[1] = t4.y; a[2] = t4.z; a[3] = t4.w;
+            a[4] = T > 4 ? Arow[ky * 8 + 4] : 0.f;
+        }
+        float cs[NCOL];
+#pragma unroll
+        for (int s = 0; s < NCOL; ++s) {
+            float v = a[0] * xw[R0][R0 + s];
+#pragma unroll
+            for (int rr = 1; rr < T; ++rr) v = fmaf(a[rr], xw[R0 + rr][R0 + s], v);
+            cs[s] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            float v = b[j];
+#pragma unroll
+            for (int s = 0; s < T; ++s) v = fmaf(C[ky][j][s], cs[j + s], v);
+            b[j] = v;
+        }
+    }
+}
+
+template <int PXL> struct P3Vec;
+template <> struct P3Vec<1> { typedef float T; };
+template <> struct P3Vec<2> { typedef float2 T; };
+
+// Branch layout handled here (the reference's scales sorted descending: 2.0, 1.5, 1.0, 0.5, 0.1):
+//   branch 0: up (T0 taps), 1: up (T1 taps), 2: same, 3: down, 4: down.
+// Every read-only operand is a `const float* __restrict__` kernel argument of its own: only then does hipcc turn the
+// wave-uniform reads of the plane's weights into scalar loads (pointers inside the geometry struct are not known to be
+// unaliased with `out`, and the per-row constants came back as 13 global_load_dwordx4 per lane and row).
+template <int T0, int T1, int PXL>
+__global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __restrict__ x, const float* __restrict__ sw0,
+                                                                const float* __restrict__ sw1, const float* __restrict__ sw2,
+                                                                const float* __restrict__ de3, const float* __restrict__ de4,
+                                                                const float* __restrict__ br_scale, const float* __restrict__ br_shift,
+                                                                const float* __restrict__ br_alpha, const float* __restrict__ merge_w,
+                                                                const float* __restrict__ ep_scale,
+                                                                const float* __restrict__ ep_shift,
+                                                                const float* __restrict__ ep_alpha, int ep_ctot, int ep_coff,
+                                                                Pyr3Geom g, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float At[4][2][(P3_SEGMAX + 2) * 24];     // [wave][up branch][row][ky][8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned wid = blockIdx.x * 4u + (unsigned)wave;
+    wid = __builtin_amdgcn_readfirstlane(wid);
+    if (wid >= g.total) return;                                        // wave-uniform; the kernel has no barrier
+    const int sgi = wid % g.nseg;  wid /= g.nseg;
+    const int cb = wid % g.ncb;  wid /= g.ncb;
+    const int c = wid % g.P;
+    const int n = wid / g.P;
+    const int h = g.h, w = g.w;
+    const int ys = sgi * g.SEG, ye = min(ys + g.SEG, h);
+    const int px0 = cb * g.CBW + (lane - 1) * PXL;                      // lane 0 / 63: halo columns of the block
+    const bool writer = lane >= 1 && lane <= 62 && px0 < w && px0 < (cb + 1) * g.CBW;
+
+    // ---- per-wave setup
+    // (1) row tables of the two up branches: entry = lane -> (row index = lane / 3, ky = lane % 3), rows ys-1 .. ye
+    {
+        const int ri = lane / 3, ky = lane - 3 * ri;
+        if (ri < g.SEG + 2) {
+            float acc[5];
+            p3_coeffs<T0>(ys - 1 + ri, ky, h, g.hs[0], g.sh[0], acc);
+            float* d = &At[wave][0][ri * 24 + ky * 8];
+            d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3]; d[4] = acc[4];
+            p3_coeffs<T1>(ys - 1 + ri, ky, h, g.hs[1], g.sh[1], acc);
+            d = &At[wave][1][ri * 24 + ky * 8];
+            d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3]; d[4] = acc[4];
+        }
+    }
+    // (2) per-lane column tables C_ky[j][s] = sum_kx w[ky][kx] * G_kx[j][s] of the two up branches (this plane's weights)
+    float C0[3][PXL][5], C1[3][PXL][5];
+    {
+        const float* w0p = sw0 + (size_t)c * 9;
+        const float* w1p = sw1 + (size_t)c * 9;
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            float g0[5], g1[5], g2[5];
+            p3_coeffs<T0>(px0 + j, 0, w, g.ws[0], g.sw[0], g0);
+            p3_coeffs<T0>(px0 + j, 1, w, g.ws[0], g.sw[0], g1);
+            p3_coeffs<T0>(px0 + j, 2, w, g.ws[0], g.sw[0], g2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int s = 0; s < 5; ++s) C0[ky][j][s] = fmaf(w0p[ky * 3 + 2], g2[s], fmaf(w0p[ky * 3 + 1], g1[s], w0p[ky * 3] * g0[s]));
+            p3_coeffs<T1>(px0 + j, 0, w, g.ws[1], g.sw[1], g0);
+            p3_coeffs<T1>(px0 + j, 1, w, g.ws[1], g.sw[1], g1);
+            p3_coeffs<T1>(px0 + j, 2, w, g.ws[1], g.sw[1], g2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int s = 0; s < 5; ++s) C1[ky][j][s] = fmaf(w1p[ky * 3 + 2], g2[s], fmaf(w1p[ky * 3 + 1], g1[s], w1p[ky * 3] * g0[s]));
+        }
+    }
+    // (3) per-lane bilinear column sources of the two low-resolution maps
+    int dxa[2][PXL], dxb[2][PXL];  float dw0[2][PXL], dw1[2][PXL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+            const int px = min(max(px0 + j, 0), w - 1);
+            bilinear_src(g.sw[3 + i], px, g.ws[3 + i], dxa[i][j], dxb[i][j], dw0[i][j], dw1[i][j]);
+        }
+    // (4) wave-uniform constants of this plane (scalar loads)
+    const float* wsame = sw2 + (size_t)c * 9;
+    const float* wm = merge_w + (size_t)c * 45;
+    float bsc[5], bsh[5], bal[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { bsc[i] = br_scale[i * g.P + c]; bsh[i] = br_shift[i * g.P + c]; bal[i] = br_alpha[i * g.P + c]; }
+    const int cabs = ep_coff + c;
+    const float esc = ep_scale ? ep_scale[cabs] : 1.f, esh = ep_shift ? ep_shift[cabs] : 0.f, eal = ep_alpha ? ep_alpha[cabs] : 1.f;
+    const float* xpl = x + ((size_t)n * g.P + c) * (size_t)h * w;
+    const float* e3 = de3 + ((size_t)n * g.P + c) * (size_t)g.hs[3] * g.ws[3];
+    const float* e4 = de4 + ((size_t)n * g.P + c) * (size_t)g.hs[4] * g.ws[4];
+    float* opl = out + ((size_t)n * ep_ctot + cabs) * (size_t)h * w;
+    bool colin[PXL];
+#pragma unroll
+    for (int j = 0; j < PXL; ++j) colin[j] = px0 + j >= 0 && px0 + j < w;
+
+    // x row loader: columns px0-2 .. px0+PXL+1 of row r (zero outside the image)
+    auto load_row = [&](int r, float (&v)[PXL + 4]) {
+        const bool rin = r >= 0 && r < h;
+        const float* row = xpl + (size_t)min(max(r, 0), h - 1) * w;
+#pragma unroll
+        for (int j = 0; j < PXL + 4; ++j) {
+            const int cx = px0 - 2 + j;
+            v[j] = (rin && cx >= 0 && cx < w) ? row[cx] : 0.f;
+        }
+    };
+
+    float xw[5][PXL + 4];
+    // rows br-2 .. br+2 for the first branch row br = ys - 1: rows ys-3 .. ys+1; row ys+2 is prefetched as "next"
+#pragma unroll
+    for (int rr = 0; rr < 5; ++rr) load_row(ys - 3 + rr, xw[rr]);
+    float xn[PXL + 4];
+    load_row(ys + 2, xn);
+    // low-resolution values of the NEXT branch row, requested one row ahead: [map][column][ya/xa, ya/xb, yb/xa, yb/xb]
+    float en[2][PXL][4];
+    float enwy0[2], enwy1[2];
+    auto load_e = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ya, yb;
+            bilinear_src(g.sh[3 + i], min(max(r, 0), h - 1), g.hs[3 + i], ya, yb, enwy0[i], enwy1[i]);       // uniform
+            const float* ra = (i == 0 ? e3 : e4) + ya * g.ws[3 + i];
+            const float* rb = (i == 0 ? e3 : e4) + yb * g.ws[3 + i];
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) {
+                en[i][j][0] = ra[dxa[i][j]]; en[i][j][1] = ra[dxb[i][j]];
+                en[i][j][2] = rb[dxa[i][j]]; en[i][j][3] = rb[dxb[i][j]];
+            }
+        }
+    };
+    load_e(ys - 1);
+    // Merge convolution, accumulated as the branch rows arrive: branch row br contributes kernel row 2 of output row br-1, kernel
+    // row 1 of output row br and kernel row 0 of output row br+1.  acc[0]: output row br-1 (complete after this row), acc[1]: row
+    // br, acc[2]: row br+1.  (Summation order over (branch, kernel row) differs from pyrpool_sep's branch-major order: fp32
+    // rounding-level differences, covered by the tests' tolerance against the oracle.)
+    float acc[3][PXL];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) acc[r][j] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's table writes are visible to its own reads (one wave, in order)
+
+#pragma unroll 1
+    for (int br = ys - 1; br <= ye; ++br) {
+        // ---- branch maps of row br
+        float bv[5][PXL];
+        const bool rowin = br >= 0 && br < h;
+        float ecur[2][PXL][4], wy0c[2], wy1c[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wy0c[i] = enwy0[i]; wy1c[i] = enwy1[i];
+#pragma unroll
+            for (int j = 0; j < PXL; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ecur[i][j][q] = en[i][j][q];
+        }
+        if (br < ye) load_e(br + 1);                       // next row's low-resolution values fly during this row's arithmetic
+        if (rowin) {
+            const float* A0 = &At[wave][0][(br - (ys - 1)) * 24];
+            const float* A1 = &At[wave][1][(br - (ys - 1)) * 24];
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) { bv[0][j] = 0.f; bv[1][j] = 0.f; bv[2][j] = 0.f; }
+            p3_up_branch<T0, PXL>(xw, A0, C0, bv[0]);
+            p3_up_branch<T1, PXL>(xw, A1, C1, bv[1]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float w0 = wsame[ky * 3], w1 = wsame[ky * 3 + 1], w2 = wsame[ky * 3 + 2];
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) {
+                    bv[2][j] = fmaf(w0, xw[1 + ky][j + 1], bv[2][j]);
+                    bv[2][j] = fmaf(w1, xw[1 + ky][j + 2], bv[2][j]);
+                    bv[2][j] = fmaf(w2, xw[1 + ky][j + 3], bv[2][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) {
+                    const float top = dw0[i][j] * ecur[i][j][0] + dw1[i][j] * ecur[i][j][1];
+                    const float bot = dw0[i][j] * ecur[i][j][2] + dw1[i][j] * ecur[i][j][3];
+                    bv[3 + i][j] = wy0c[i] * top + wy1c[i] * bot;
+                }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) {
+                    float v = fmaf(bv[i][j], bsc[i], bsh[i]);
+                    v = v > 0.f ? v : bal[i] * v;
+                    bv[i][j] = colin[j] ? v : 0.f;           // zero outside the image: the merge convolution's padding
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) bv[i][j] = 0.f;
+        }
+        // ---- this row's contributions to the three output rows it touches; neighbouring columns come from the neighbouring lanes
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            float bx[PXL + 2];
+            bx[0] = p3_from_left(bv[i][PXL - 1]);
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) bx[1 + j] = bv[i][j];
+            bx[PXL + 1] = p3_from_right(bv[i][0]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {                   // acc[r] <-> output row br-1+r <-> kernel row ky = 2 - r
+                const int ky = 2 - r;
+                const float w0 = wm[i * 9 + ky * 3], w1 = wm[i * 9 + ky * 3 + 1], w2 = wm[i * 9 + ky * 3 + 2];
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) {
+                    acc[r][j] = fmaf(w0, bx[j], acc[r][j]);
+                    acc[r][j] = fmaf(w1, bx[j + 1], acc[r][j]);
+                    acc[r][j] = fmaf(w2, bx[j + 2], acc[r][j]);
+                }
+            }
+        }
+        // ---- slide the x window (row br+3 becomes the prefetched one)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int j = 0; j < PXL + 4; ++j) xw[rr][j] = xw[rr + 1][j];
+#pragma unroll
+        for (int j = 0; j < PXL + 4; ++j) xw[4][j] = xn[j];
+        if (br + 1 <= ye) load_row(br + 4, xn);           // for branch row br+2 (its window ends at br+4)
+        // ---- output row y = br - 1 is complete
+        const int y = br - 1;
+        if (y >= ys) {
+            float v[PXL];
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) {
+                v[j] = fmaf(acc[0][j], esc, esh);
+                v[j] = (ep_alpha && v[j] <= 0.f) ? eal * v[j] : v[j];
+            }
+            if (writer) {
+                float* dst = opl + (size_t)y * w + px0;
+                if (PXL == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[PXL - 1]);
+                else dst[0] = v[0];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = 0.f; }
+    }
+}
+
+// Host twin of bilinear_src's index part (same fp32 operations; -ffp-contract=off).
+static void p3_host_bilinear_idx(float scale, int dst, int in_size, int& i0, int& i1) {
+    const float real = scale * (float)dst;
+    int idx = (int)floorf(real);
+    if (idx > in_size - 1) idx = in_size - 1;
+    i0 = idx;
+    i1 = idx + ((idx < in_size - 1) ? 1 : 0);
+}
+
+// Smallest R such that every source of output p lies in [p-R, p+R] (one dimension); large when unsupported.
+static int p3_stencil_radius(int I, int S) {
+    const float sc = bilinear_scale(I, S);
+    int R = 0;
+    for (int p = 0; p < I; ++p) {
+        const int us = (int)(((int64_t)p * S) / I), ue = (int)((((int64_t)p + 1) * S + I - 1) / I);
+        for (int v = std::max(us - 1, 0); v <= std::min(ue, S - 1); ++v) {
+            int a, b;
+            p3_host_bilinear_idx(sc, v, I, a, b);
+            R = std::max(R, std::max(p - a, b - p));
+        }
+    }
+    return R;
+}
+
+// Returns MSPL_OK when launched, 1 when the shape is left to the LDS-tiled kernels, < 0 on error.
+int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
+                       const float* const* stage_w, const float* const* down_e, const float* br_scale,
+                       const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
+                       hipStream_t stream) {
+    static const int off = getenv("MSPL_PYR_STREAM") ? atoi(getenv("MSPL_PYR_STREAM")) == 0 : 0;
+    // maps narrower than ~half a wave leave most lanes idle: the LDS-tiled form is faster there (18x30: 12 vs 17 us)
+    static const int min_w = getenv("MSPL_PYR_STREAM_MINW") ? atoi(getenv("MSPL_PYR_STREAM_MINW")) : 40;
+    if (off || nb != 5 || w < min_w) return 1;
+    if (e.pre_add || e.residual || e.reinf_r || e.gate) return 1;    // only the scale/shift/PReLU epilogue
+    // branch pattern: up, up, same, down, down (strictly)
+    for (int i = 0; i < 5; ++i) if (hs[i] <= 0 || ws[i] <= 0) return 1;
+    if (!(hs[0] > h && ws[0] > w && hs[1] > h && ws[1] > w)) return 1;
+    if (!(hs[2] == h && ws[2] == w)) return 1;
+    if (!(hs[3] <= h && ws[3] <= w && hs[4] <= h && ws[4] <= w && (hs[3] < h || ws[3] < w) && (hs[4] < h || ws[4] < w))) return 1;
+    if (!stage_w[0] || !stage_w[1] || !stage_w[2] || !down_e[3] || !down_e[4]) return 1;
+    int taps[2];
+    for (int i = 0; i < 2; ++i) {
+        const int R = std::max(p3_stencil_radius(h, hs[i]), p3_stencil_radius(w, ws[i]));
+        if (R > 2) return 1;
+        taps[i] = R <= 1 ? 3 : 5;
+    }
+    const int PXL = w <= 62 ? 1 : 2;
+    if (PXL == 2 && ((w & 1) || (((uintptr_t)out) & 7))) return 1;     // 8-byte stores
+    Pyr3Geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.P = P; g.h = h; g.w = w;
+    for (int i = 0; i < 5; ++i) {
+        g.hs[i] = hs[i]; g.ws[i] = ws[i];
+        if (i < 2) { g.sh[i] = bilinear_scale(h, hs[i]); g.sw[i] = bilinear_scale(w, ws[i]); }
+        if (i > 2) { g.sh[i] = bilinear_scale(hs[i], h); g.sw[i] = bilinear_scale(ws[i], w); }
+    }
+    g.CBW = 62 * PXL;
+    g.ncb = ceil_div(w, g.CBW);
+    // rows per segment: enough waves to put >= 2 on every SIMD when the maps allow, halo rows (2 of SEG + 2 branch rows, 6 of
+    // SEG + 6 x rows) kept small otherwise
+    static const int dbg_seg = getenv("MSPL_PYR_SEG") ? atoi(getenv("MSPL_PYR_SEG")) : 0;
+    int seg = std::min(h, P3_SEGMAX);
+    while (seg > 6 && (int64_t)N * P * g.ncb * ceil_div(h, seg) < 2048) --seg;
+    seg = ceil_div(h, ceil_div(h, seg));
+    if (dbg_seg > 0 && dbg_seg <= P3_SEGMAX) seg = std::min(dbg_seg, h);
+    g.SEG = seg;
+    g.nseg = ceil_div(h, seg);
+    const int64_t waves = (int64_t)N * P * g.ncb * g.nseg;
+    if (waves >= (1ll << 31)) return 1;
+    g.total = (unsigned)waves;
+    const dim3 grid((unsigned)ceil_div64(waves, 4)), blk(256);
+#define MSPL_P3_LAUNCH(A, B, L) hipLaunchKernelGGL((pyrpool_stream_kernel<A, B, L>), grid, blk, 0, stream, x, stage_w[0], stage_w[1], stage_w[2], down_e[3], down_e[4], br_scale, br_shift, br_alpha, merge_w, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out)
+    if (PXL == 1) {
+        if (taps[0] == 3 && taps[1] == 3) MSPL_P3_LAUNCH(3, 3, 1);
+        else if (taps[0] == 3) MSPL_P3_LAUNCH(3, 5, 1);
+        else if (taps[1] == 3) MSPL_P3_LAUNCH(5, 3, 1);
+        else MSPL_P3_LAUNCH(5, 5, 1);
+    } else {
+        if (taps[0] == 3 && taps[1] == 3) MSPL_P3_LAUNCH(3, 3, 2);
+        else if (taps[0] == 3) MSPL_P3_LAUNCH(3, 5, 2);
+        else if (taps[1] == 3) MSPL_P3_LAUNCH(5, 3, 2);
+        else MSPL_P3_LAUNCH(5, 5, 2);
+    }
+#undef MSPL_P3_LAUNCH
+    MSPL_CHECK_LAUNCH("pyrpool_fused(streaming form)");
+    return MSPL_OK;
+}
+
+}  // namespace mspl

@@ -65,7 +65,7 @@ def bench_conv1x1():
 
 
 def bench_k2():
-    N = 16
+    N = int(os.environ.get('K2_N', '16'))
     for name, n, h, w, stride, dil in [('L2_0 s2 n=24', 24, 144, 240, 2, [1, 2, 3, 4]), ('L3_0 s2 n=32', 32, 72, 120, 2, [1, 2, 3, 4]),
                                        ('L3 s1 n=64', 64, 36, 60, 1, [1, 2, 3, 4]), ('L4_0 s2 n=64', 64, 36, 60, 2, [1, 2, 3, 4]),
                                        ('L4 s1 n=128', 128, 18, 30, 1, [1, 1, 2, 3])]:
@@ -162,7 +162,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'stream':
 
 def bench_k2x():
     """Eager launches of the K2 shapes (for a STAMPS=1 build: the launcher prints the phase timeline of every launch)."""
-    N = 16
+    N = int(os.environ.get('K2_N', '16'))
     for name, n, h, w, stride, dil in [('L2_0 s2 n=24', 24, 144, 240, 2, [1, 2, 3, 4]), ('L3_0 s2 n=32', 32, 72, 120, 2, [1, 2, 3, 4]),
                                        ('L3 s1 n=64', 64, 36, 60, 1, [1, 2, 3, 4]), ('L4_0 s2 n=64', 64, 36, 60, 2, [1, 2, 3, 4]),
                                        ('L4 s1 n=128', 128, 18, 30, 1, [1, 1, 2, 3])]:
