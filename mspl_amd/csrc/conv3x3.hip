@@ -8,6 +8,8 @@
 // A workgroup stages the cin_g input planes of one (image, group, spatial tile) in LDS (coalesced rows,
 // zero-filled halo); a thread produces a 1x4 output strip for COB output channels, so every LDS row
 // window is reused COB*3 times from registers.  Weight reads are LDS broadcasts.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -172,6 +174,107 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------ depthwise 3x3, stride 1: register-streaming form
+// (EfficientPWConv's expansion over the 32-channel level-1 map, nn_layers/efficient_pt.py:21 with groups = gcd(nin, nout) =
+// channels.)  The LDS-tiled kernel above spends ~85 vector instructions per output pixel on a depthwise plane (staging and
+// index arithmetic for 9 FMAs); the whole label pass is bound by vector-instruction issue, not by HBM (344 M wave-instructions
+// per pass).  Here a wave owns a column block and a row segment of one plane and walks down the rows: lane
+// = 4 adjacent columns (one 16-byte load per row), the left / right neighbour columns come from the neighbouring lanes
+// (v_mov_dpp wave_shr / wave_shl; lanes 0 and 63 are halo lanes), the 3-row window lives in registers, the next row is
+// requested one row ahead.  ~20 vector instructions per pixel, no LDS, no barrier.
+struct DwsGeom {
+    int N, C, H, W;
+    int SEG, nseg, ncb;
+    unsigned total;      // waves
+};
+
+__device__ __forceinline__ float dws_from_left(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dws_from_right(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               DwsGeom g, Epi e, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wid >= g.total) return;                              // wave-uniform; no barrier in this kernel
+    const int sgi = wid % g.nseg;  wid /= g.nseg;
+    const int cb = wid % g.ncb;  wid /= g.ncb;
+    const int c = wid % g.C;
+    const int n = wid / g.C;
+    const int H = g.H, W = g.W;
+    const int ys = sgi * g.SEG, ye = min(ys + g.SEG, H);
+    const int c0 = cb * 248 + (lane - 1) * 4;
+    const bool colin = c0 >= 0 && c0 < W;                    // W % 4 == 0: all four columns in or out
+    const bool writer = lane >= 1 && lane <= 62 && colin;
+    const float* xp = x + ((size_t)n * g.C + c) * (size_t)H * W;
+    const float* wp = w + (size_t)c * 9;
+    const float w00 = wp[0], w01 = wp[1], w02 = wp[2], w10 = wp[3], w11 = wp[4], w12 = wp[5], w20 = wp[6], w21 = wp[7], w22 = wp[8];
+    const int cabs = e.coff + c;
+    const EpiCh ec = epi_channel(e, cabs);
+    auto load_row = [&](int r) -> float4 {
+        if (!colin || r < 0 || r >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(xp + (size_t)r * W + c0);
+    };
+    // rows y-1, y, y+1 as six-column windows (columns c0-1 .. c0+4)
+    float r0[6], r1[6], r2[6];
+    auto widen = [&](const float4& v, float (&r)[6]) {
+        r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w;
+        r[0] = dws_from_left(v.w);
+        r[5] = dws_from_right(v.x);
+    };
+    widen(load_row(ys - 1), r0);
+    widen(load_row(ys), r1);
+    float4 nxt = load_row(ys + 1);
+    float* op = out + ((size_t)n * e.ctot + cabs) * (size_t)e.hw;
+#pragma unroll 1
+    for (int y = ys; y < ye; ++y) {
+        widen(nxt, r2);
+        nxt = load_row(y + 2);
+        float acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+            a = fmaf(w00, r0[j], a); a = fmaf(w01, r0[j + 1], a); a = fmaf(w02, r0[j + 2], a);
+            a = fmaf(w10, r1[j], a); a = fmaf(w11, r1[j + 1], a); a = fmaf(w12, r1[j + 2], a);
+            a = fmaf(w20, r2[j], a); a = fmaf(w21, r2[j + 1], a); a = fmaf(w22, r2[j + 2], a);
+            acc[j] = a;
+        }
+        if (writer) {
+            const int pix = y * W + c0;
+            *reinterpret_cast<float4*>(op + pix) = epi_apply4(e, ec, acc, n, cabs, pix);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+    }
+}
+
+static bool dwconv3x3_stream_ok(const C3Geom& g, const float* x, const float* out, const Epi& e) {
+    auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+    return g.cin_g == 1 && g.cout_g == 1 && g.sg == 0 && (g.W & 3) == 0 && g.W >= 64 && g.H >= 8 && al16(x) && al16(out) &&
+           al16(e.pre_add) && al16(e.residual) && al16(e.reinf_r) && (int64_t)g.H * g.W < (1ll << 29);
+}
+
+static int launch_dws(const float* x, const float* w, const C3Geom& g3, const Epi& e, float* out, hipStream_t s) {
+    DwsGeom g;
+    g.N = g3.N; g.C = g3.Cin; g.H = g3.H; g.W = g3.W;
+    g.ncb = ceil_div(g.W, 248);
+    int seg = g.H < 32 ? g.H : 32;
+    while (seg > 8 && (int64_t)g.N * g.C * g.ncb * ceil_div(g.H, seg) < 4096) --seg;
+    seg = ceil_div(g.H, ceil_div(g.H, seg));
+    g.SEG = seg;
+    g.nseg = ceil_div(g.H, seg);
+    const int64_t waves = (int64_t)g.N * g.C * g.ncb * g.nseg;
+    MSPL_REQUIRE(waves < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv3x3(depthwise): grid too large");
+    g.total = (unsigned)waves;
+    hipLaunchKernelGGL(dwconv3x3_stream_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, s, x, w, g, e, out);
+    MSPL_CHECK_LAUNCH("conv3x3(depthwise, streaming)");
+    return MSPL_OK;
+}
+
 template <int STRIDE>
 static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float* out, hipStream_t s) {
     int cob = 1;
@@ -251,5 +354,7 @@ extern "C" int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32
     g.Wo = (W - 1) / stride + 1;
     const Epi e = make_epi(ep, Cout, g.Ho * g.Wo);
     hipStream_t s = (hipStream_t)stream;
+    static const int no_dws = getenv("MSPL_DWS") ? atoi(getenv("MSPL_DWS")) == 0 : 0;       // tuning aid: 0 = LDS-tiled form only
+    if (stride == 1 && !no_dws && dwconv3x3_stream_ok(g, x, out, e)) return launch_dws(x, w, g, e, out, s);
     return stride == 1 ? launch3<1>(x, w, g, e, out, s) : launch3<2>(x, w, g, e, out, s);
 }

@@ -203,7 +203,9 @@ struct LeStage {
     unsigned magqm, magqa; // exact divisions by wms / 4 and was / 4: (k * mag) >> 20 (verified on the host)
 };
 
-template <int CMAX>
+// EXACT: the class count equals CMAX (5 / 13 / 20, the path's heads): the per-class predicates `c < C` fold away (they were two
+// thirds of this kernel's 950 vector instructions per pixel).
+template <int CMAX, bool EXACT>
 __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
                                                                  LeGeom g, LeStage st, const uint8_t* __restrict__ lut,
                                                                  uint8_t* __restrict__ labels, float* __restrict__ kld,
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
                     m[c] = -INFINITY;
-                    if (c < g.C) {
+                    if (EXACT || c < g.C) {
                         const float top = mwx0 * mr0[c * st.wms] + mwx1 * mr0[c * st.wms + mdx];
                         const float bot = mwx0 * mr1[c * st.wms] + mwx1 * mr1[c * st.wms + mdx];
                         m[c] = mwy0 * top + mwy1 * bot;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
                         a[c] = -INFINITY;
-                        if (c < g.C) {
+                        if (EXACT || c < g.C) {
                             const float top = awx0 * ar0[c * st.was] + awx1 * ar0[c * st.was + adx];
                             const float bot = awx0 * ar1[c * st.was] + awx1 * ar1[c * st.was + adx];
                             a[c] = awy0 * top + awy1 * bot;
@@ -360,14 +362,14 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) a[c] = c < g.C ? 0.f : -INFINITY;
+                    for (int c = 0; c < CMAX; ++c) a[c] = (EXACT || c < g.C) ? 0.f : -INFINITY;
                 }
                 const size_t pix = ((size_t)n * g.H + y) * g.W + x;
                 if (labels) {
                     float omax = -INFINITY;  int best = 0;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
-                        if (c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
+                        if (EXACT || c < g.C) { const float o = m[c] + 0.5f * a[c]; if (o > omax) { omax = o; best = c; } }   // first maximum wins
                     }
                     lab8 = lut ? (unsigned)lut[best] : (unsigned)best;
                     labels[pix] = (uint8_t)lab8;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
                         float S1 = 0.f, T1 = 0.f, S2 = 0.f;
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) {
-                            if (c < g.C) {
+                            if (EXACT || c < g.C) {
                                 const float e1 = __expf(m[c] - M1);
                                 S1 += e1;
                                 T1 = fmaf(e1, m[c] - a[c], T1);
@@ -659,15 +661,19 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
                 ws = (unsigned int*)workspace;
             }
             static const bool big_lds = [] {          // C = 24 at 256 columns needs 72 KB (the default cap is 64 KB)
-                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
-                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
                 return ok;
             }();
             MSPL_REQUIRE(big_lds || lds <= 64 * 1024, MSPL_ERR_HIP, "label_epilogue: could not raise the dynamic LDS limit");
-            if (C <= 8) hipLaunchKernelGGL(label_epilogue_lds_kernel<8>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
-            else if (C <= 16) hipLaunchKernelGGL(label_epilogue_lds_kernel<16>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
-            else hipLaunchKernelGGL(label_epilogue_lds_kernel<24>, grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
+#define MSPL_LE_LAUNCH(CM, EX) hipLaunchKernelGGL((label_epilogue_lds_kernel<CM, EX>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws)
+            if (C == 5) MSPL_LE_LAUNCH(5, true);
+            else if (C == 13) MSPL_LE_LAUNCH(13, true);
+            else if (C == 20) MSPL_LE_LAUNCH(20, true);
+            else if (C <= 8) MSPL_LE_LAUNCH(8, false);
+            else if (C <= 16) MSPL_LE_LAUNCH(16, false);
+            else MSPL_LE_LAUNCH(24, false);
+#undef MSPL_LE_LAUNCH
             MSPL_CHECK_LAUNCH("label_epilogue");
             if (hist) {
                 hipLaunchKernelGGL(label_hist_reduce_kernel, dim3(LE_RED), dim3(256), 0, st_, ws, (int)le_blocks(N, H, W), ncls, hist);

@@ -7,6 +7,8 @@
 //   gap_gate          EfficientPWConv.wt_layer: efficient_pt.py:13-17
 // All are streaming kernels: one thread per 4 consecutive output pixels of a row (16-byte stores when the
 // row length allows), source reads served by L1/L2 (every source line is touched by neighbouring lanes).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -161,6 +163,84 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
         acc[j] = wy0 * top + wy1 * bot;
     }
     strip_store(e, g, n, c, y, x0, acc, out);
+}
+
+
+// Bilinear, register-streaming form (the decoder's up-merge: bu_br(pw + upsample2(bu)), model/segmentation/espdnet_ue.py:276-280).
+// The strip kernel above issues 16 scattered 4-byte loads and ~36 vector instructions per output pixel; the label pass is bound
+// by vector-instruction issue.  Here a wave owns PW planes x one segment of output rows and walks DOWN the rows: lane = (plane,
+// 4 adjacent output columns); the column sources / weights of its 4 pixels are per-lane constants; the row sources are
+// wave-uniform.  A source row is fetched and interpolated horizontally ONCE (top = wx0*p[xa] + wx1*p[xb], the reference's own
+// expression) and serves every output row that uses it (two for the x2 merge); per output row only the vertical blend, the
+// epilogue and one 16-byte store remain.  ~12 vector instructions per pixel, no LDS, no barrier.
+struct BsGeom {
+    int N, C, Hi, Wi, Ho, Wo, XS, PW;   // PW: planes side by side in one wave (64 / XS)
+    int SEG, nseg, pgroups;             // output rows per segment, segments per plane, ceil(N*C / PW)
+    unsigned total;                     // waves
+    float sh, sw;
+    int half_pixel;
+};
+
+__global__ __launch_bounds__(256) void bilinear_stream_kernel(const float* __restrict__ x, BsGeom g, Epi e, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wid >= g.total) return;                              // wave-uniform; no barrier in this kernel
+    const int sgi = wid % g.nseg;
+    const int pg = wid / g.nseg;
+    const int pl = lane / g.XS, xs = lane - pl * g.XS;       // plane slot and strip of this lane
+    const int plane = pg * g.PW + pl;
+    const bool live = pl < g.PW && plane < g.N * g.C;
+    const int n = live ? plane / g.C : 0, c = live ? plane - n * g.C : 0;
+    const int x0 = xs * 4;
+    const float* src = x + (size_t)(live ? plane : 0) * (size_t)g.Hi * g.Wi;
+    int xa[4], xb[4];  float wx0[4], wx1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = min(x0 + j, g.Wo - 1);
+        if (g.half_pixel) bilinear_src_hp(g.sw, xx, g.Wi, xa[j], xb[j], wx0[j], wx1[j]);
+        else bilinear_src(g.sw, xx, g.Wi, xa[j], xb[j], wx0[j], wx1[j]);
+    }
+    const int cabs = e.coff + c;
+    const EpiCh ec = epi_channel(e, cabs);
+    const int ys = sgi * g.SEG, ye = min(ys + g.SEG, g.Ho);
+    float ha[4] = {0.f, 0.f, 0.f, 0.f}, hb[4] = {0.f, 0.f, 0.f, 0.f};      // horizontally interpolated source rows ia / ib
+    int ia = -1, ib = -1;
+    auto hrow = [&](int r, float (&h)[4]) {
+        const float* row = src + (size_t)r * g.Wi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = wx0[j] * row[xa[j]] + wx1[j] * row[xb[j]];
+    };
+#pragma unroll 1
+    for (int y = ys; y < ye; ++y) {
+        int y0i, y1i;  float wy0, wy1;
+        if (g.half_pixel) bilinear_src_hp(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);
+        else bilinear_src(g.sh, y, g.Hi, y0i, y1i, wy0, wy1);            // uniform
+        if (y0i != ia) {                                                   // uniform branches
+            if (y0i == ib) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ha[j] = hb[j];
+            } else {
+                hrow(y0i, ha);
+            }
+            ia = y0i;
+        }
+        if (y1i != ib) {
+            if (y1i == ia) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hb[j] = ha[j];
+            } else {
+                hrow(y1i, hb);
+            }
+            ib = y1i;
+        }
+        if (live) {
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = wy0 * ha[j] + wy1 * hb[j];
+            const int pix = y * g.Wo + x0;
+            *reinterpret_cast<float4*>(out + epi_offset(e, n, cabs, pix)) = epi_apply4(e, ec, acc, n, cabs, pix);
+        }
+    }
 }
 
 __device__ __forceinline__ int ada_start(int o, int I, int O) { return (int)(((int64_t)o * I) / O); }
@@ -347,6 +427,28 @@ extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t H
     if (g.half_pixel) {        // ATen area_pixel_compute_scale(align_corners=False, no scale factor): in / out
         g.sh = (float)Hi / (float)Ho;
         g.sw = (float)Wi / (float)Wo;
+    }
+    {   // register-streaming form: rows of whole 16-byte strips, at most one wave wide, enough rows to walk
+        auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+        static const int no_stream = getenv("MSPL_BILINEAR_STREAM") ? atoi(getenv("MSPL_BILINEAR_STREAM")) == 0 : 0;
+        if (!no_stream && (Wo & 3) == 0 && g.XS <= 64 && Ho >= 8 && al16(out) && al16(e.pre_add) && al16(e.residual) && al16(e.reinf_r) &&
+            (int64_t)Hi * Wi < (1ll << 29) && (int64_t)Ho * Wo < (1ll << 29)) {
+            BsGeom b;
+            b.N = N; b.C = C; b.Hi = Hi; b.Wi = Wi; b.Ho = Ho; b.Wo = Wo; b.XS = g.XS; b.PW = 64 / g.XS;
+            b.sh = g.sh; b.sw = g.sw; b.half_pixel = g.half_pixel;
+            b.pgroups = ceil_div(N * C, b.PW);
+            int seg = Ho < 32 ? Ho : 32;
+            while (seg > 6 && (int64_t)b.pgroups * ceil_div(Ho, seg) < 4096) --seg;
+            seg = ceil_div(Ho, ceil_div(Ho, seg));
+            b.SEG = seg; b.nseg = ceil_div(Ho, seg);
+            const int64_t waves = (int64_t)b.pgroups * b.nseg;
+            if (waves < (1ll << 31)) {
+                b.total = (unsigned)waves;
+                hipLaunchKernelGGL(bilinear_stream_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, (hipStream_t)stream, x, b, e, out);
+                MSPL_CHECK_LAUNCH("bilinear(streaming)");
+                return MSPL_OK;
+            }
+        }
     }
     const size_t lds = (size_t)16 * g.XS * sizeof(float);
     MSPL_REQUIRE(lds <= 64 * 1024 && (int64_t)Hi * Wi < (1ll << 31), MSPL_ERR_UNSUPPORTED, "bilinear: output rows of %d pixels do not fit the column table", Wo);

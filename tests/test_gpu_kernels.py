@@ -97,7 +97,9 @@ def test_conv1x1_epilogues(cfg):
     # (N, Cin, Cout, groups, H, W, stride, shuffle_groups)
     (2, 3, 32, 1, 32, 48, 2, 0), (1, 3, 3, 1, 9, 15, 1, 0), (2, 16, 16, 16, 17, 29, 1, 0), (1, 80, 16, 16, 16, 30, 1, 5),
     (1, 128, 48, 16, 12, 20, 1, 0), (1, 256, 64, 64, 8, 15, 1, 0), (1, 4, 4, 4, 256, 480, 1, 0), (1, 3, 32, 1, 31, 45, 2, 0),
-    (1, 20, 4, 4, 5, 5, 1, 5)])
+    (1, 20, 4, 4, 5, 5, 1, 5),
+    # depthwise maps wide enough for the register-streaming form: odd height, exactly one column block, a 4-column second block
+    (2, 6, 6, 6, 37, 64, 1, 0), (1, 5, 5, 5, 9, 248, 1, 0), (1, 2, 2, 2, 40, 252, 1, 0)])
 def test_conv3x3(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
