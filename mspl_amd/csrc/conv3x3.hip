@@ -26,7 +26,10 @@ struct C3Geom {
     unsigned xcd_per, total;     // XCD-contiguous tile order (common.hpp): neighbouring tiles share halo rows
 };
 
-template <int STRIDE, int COB>
+// UNIW: one output-channel block per group (cout_g == COB): the weights a thread needs are the same for the whole workgroup, so
+// they are read through a uniform address (scalar loads, SGPR operands of the FMAs) instead of 27 LDS broadcasts per input
+// channel and strip -- for the 8 -> 3 grouped expansion that was 216 ds_read_b32 per 864 FMAs.
+template <int STRIDE, int COB, bool UNIW>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       C3Geom g, Epi e, float* __restrict__ out) {
     constexpr int NR = (STRIDE == 1) ? 6 : 9;
@@ -144,7 +147,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
                 if (STRIDE == 2) rv[8] = row[8];
 #pragma unroll
                 for (int c = 0; c < COB; ++c) {
-                    const float* wp = wl + ((size_t)(cb * COB + c) * g.cin_g + ci) * 9 + ky * 3;
+                    const float* wp = UNIW ? wg + ((size_t)c * g.cin_g + ci) * 9 + ky * 3
+                                           : wl + ((size_t)(cb * COB + c) * g.cin_g + ci) * 9 + ky * 3;
                     const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -319,13 +323,18 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     g.total = (unsigned)blocks; g.xcd_per = xcd_per(blocks);
     dim3 grid(8u * g.xcd_per), blk(256);
     const size_t lds = lds_of(th);
+    static const int no_uniw = getenv("MSPL_C3_UNIW") ? atoi(getenv("MSPL_C3_UNIW")) == 0 : 0;
+    const bool uniw = g.coblks == 1 && !no_uniw;
+#define MSPL_C3(CB) do { if (uniw) hipLaunchKernelGGL((conv3x3_kernel<STRIDE, CB, true>), grid, blk, lds, s, x, w, g, e, out); \
+                         else hipLaunchKernelGGL((conv3x3_kernel<STRIDE, CB, false>), grid, blk, lds, s, x, w, g, e, out); } while (0)
     switch (cob) {
-        case 8: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 8>), grid, blk, lds, s, x, w, g, e, out); break;
-        case 4: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 4>), grid, blk, lds, s, x, w, g, e, out); break;
-        case 3: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 3>), grid, blk, lds, s, x, w, g, e, out); break;
-        case 2: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 2>), grid, blk, lds, s, x, w, g, e, out); break;
-        default: hipLaunchKernelGGL((conv3x3_kernel<STRIDE, 1>), grid, blk, lds, s, x, w, g, e, out); break;
+        case 8: MSPL_C3(8); break;
+        case 4: MSPL_C3(4); break;
+        case 3: MSPL_C3(3); break;
+        case 2: MSPL_C3(2); break;
+        default: MSPL_C3(1); break;
     }
+#undef MSPL_C3
     MSPL_CHECK_LAUNCH("conv3x3");
     return MSPL_OK;
 }

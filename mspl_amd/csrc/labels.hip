@@ -205,7 +205,10 @@ struct LeStage {
 
 // EXACT: the class count equals CMAX (5 / 13 / 20, the path's heads): the per-class predicates `c < C` fold away (they were two
 // thirds of this kernel's 950 vector instructions per pixel).
-template <int CMAX, bool EXACT>
+// WMS / WAS > 0: the staged row strides are these compile-time constants (480-pixel-wide outputs: 132 / 68), so the per-class LDS
+// offsets c * stride become immediate offsets of the ds_read instructions instead of one v_add_u32 per read (100 of the 590
+// vector instructions per pixel).
+template <int CMAX, bool EXACT, int WMS, int WAS>
 __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __restrict__ mainp, const float* __restrict__ auxp,
                                                                  LeGeom g, LeStage st, const uint8_t* __restrict__ lut,
                                                                  uint8_t* __restrict__ labels, float* __restrict__ kld,
@@ -250,35 +253,41 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
         const float* ab = auxp ? auxp + (size_t)n * g.C * aplane : nullptr;
         const int nm = (rm_hi - rm_lo + 1) * g.C, na = auxp ? (ra_hi - ra_lo + 1) * g.C : 0;
         if (st.vec) {
-            // 16-byte chunks: chunk i -> (pair = i / CPQ, q = i % CPQ) with CPQ = wms / 4 (main) resp. was / 4 (aux); every chunk of
-            // the tile is requested before the first LDS write (one memory round trip per tile)
-            const int cqm = st.wms >> 2, cqa = st.was >> 2;
-            const int nmc = nm * cqm, total = nmc + na * cqa;
-            constexpr int UL = 12;
-            for (int base = 0; base < total; base += 256 * UL) {
-                float4 v[UL];  int dst[UL];
+            // 16-byte chunks.  A wave stages PPW (row, class) pairs per step: lane -> (pair slot = lane / CPQ, chunk q = lane % CPQ)
+            // is computed ONCE (CPQ = chunks per pair: wms / 4 resp. was / 4), the step loop then costs one magic division of a
+            // uniform pair index per pair -- the flat per-chunk decode this replaces was ~700 of the kernel's 3300 vector
+            // instructions per thread.  Four steps' loads are requested before their LDS writes.
+            const int wavei = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #pragma unroll
-                for (int u = 0; u < UL; ++u) {
-                    const int i = base + u * 256 + tid;
-                    dst[u] = -1;  v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < total) {
-                        const bool ism = i < nmc;
-                        const int k = ism ? i : i - nmc;
-                        const int pair = (int)(((unsigned)k * (ism ? st.magqm : st.magqa)) >> 20), q = k - pair * (ism ? cqm : cqa);
-                        const int row = (int)(((unsigned)pair * st.magc) >> 16), c = pair - row * g.C;
-                        const int col = (ism ? cmA : caA) + 4 * q;
-                        if (col < (ism ? g.Wm : g.Wa) && col <= (ism ? cm_hi : ca_hi)) {
-                            const float* src = ism ? mb + (size_t)c * mplane + (rm_lo + row) * g.Wm + col
-                                                   : ab + (size_t)c * aplane + (ra_lo + row) * g.Wa + col;
-                            v[u] = *reinterpret_cast<const float4*>(src);
-                            dst[u] = ism ? pair * st.wms + 4 * q : (int)(al - ml) + pair * st.was + 4 * q;
+            for (int head = 0; head < 2; ++head) {
+                const bool ism = head == 0;
+                const int cq = ism ? (st.wms >> 2) : (st.was >> 2), npair = ism ? nm : na;
+                if (npair == 0) continue;
+                const int ppw = cq <= 64 ? 64 / cq : 1;                    // pairs per wave step (cq <= 64: checked by the launcher)
+                const int slot = (int)(((unsigned)lane * (ism ? st.magqm : st.magqa)) >> 20), q = lane - slot * cq;
+                const int col = (ism ? cmA : caA) + 4 * q;
+                const bool lane_ok = slot < ppw && col < (ism ? g.Wm : g.Wa) && col <= (ism ? cm_hi : ca_hi);
+                const float* base = ism ? mb + (size_t)rm_lo * g.Wm + col : ab + (size_t)ra_lo * g.Wa + col;
+                const int plane = ism ? mplane : aplane, rowlen = ism ? g.Wm : g.Wa, wst = ism ? st.wms : st.was;
+                float* dbase = (ism ? ml : al) + 4 * q;
+                constexpr int UL = 4;
+                for (int p0 = wavei * ppw + slot; p0 - slot < npair; p0 += 4 * ppw * UL) {
+                    float4 v[UL];  int dst[UL];
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) {
+                        const int pair = p0 + u * 4 * ppw;
+                        dst[u] = -1;  v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (lane_ok && pair < npair) {
+                            const int row = (int)(((unsigned)pair * st.magc) >> 16), cc = pair - row * g.C;
+                            v[u] = *reinterpret_cast<const float4*>(base + (size_t)cc * plane + row * rowlen);
+                            dst[u] = pair * wst;
                         }
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < UL; ++u)
-                    if (dst[u] >= 0) *reinterpret_cast<float4*>(ml + dst[u]) = v[u];
+                    for (int u = 0; u < UL; ++u)
+                        if (dst[u] >= 0) *reinterpret_cast<float4*>(dbase + dst[u]) = v[u];
+                }
             }
         } else {
             // 4-byte form (rows not 16-byte aligned): (row, class) pairs round-robin over the two halves of the workgroup; a
@@ -318,9 +327,15 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
     }
     __syncthreads();
 
+    const int wms_c = WMS > 0 ? WMS : st.wms, was_c = WAS > 0 ? WAS : st.was;
+    // From here on a*b + c may contract to one fused multiply-add (the library is otherwise built with -ffp-contract=off): the
+    // interpolation and the exp-sum arithmetic lose a third of their vector instructions; results move by one rounding of the
+    // product (the reference's own ATen kernels are built with contraction on), labels are decided exactly as before wherever the
+    // top-2 margin exceeds rounding level.
     const int x = xb + tid;
     unsigned int cnt_mask_lo = 0;      // labels of this thread's LE_RB pixels, 8 bits each (0xff = none)
     if (x < g.W) {
+#pragma clang fp contract(fast)
         int mx0, mx1, ax0 = 0, ax1 = 0;  float mwx0, mwx1, awx0 = 0.f, awx1 = 0.f;
         bilinear_src(g.swm, x, g.Wm, mx0, mx1, mwx0, mwx1);
         if (auxp) bilinear_src(g.swa, x, g.Wa, ax0, ax1, awx0, awx1);
@@ -334,29 +349,31 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
             if (y < g.H) {                                              // uniform
                 int my0, my1;  float mwy0, mwy1;
                 bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);     // uniform
-                const float* mr0 = mcol + (size_t)(my0 - rm_lo) * g.C * st.wms;
-                const float* mr1 = mcol + (size_t)(my1 - rm_lo) * g.C * st.wms;
+                const float* mr0 = mcol + (my0 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
+                const float* mr1 = mcol + (my1 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
+                const float* mr0b = mr0 + mdx;  const float* mr1b = mr1 + mdx;      // second source column (the same at the clamped edge)
                 float m[CMAX], a[CMAX];
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
                     m[c] = -INFINITY;
                     if (EXACT || c < g.C) {
-                        const float top = mwx0 * mr0[c * st.wms] + mwx1 * mr0[c * st.wms + mdx];
-                        const float bot = mwx0 * mr1[c * st.wms] + mwx1 * mr1[c * st.wms + mdx];
+                        const float top = mwx0 * mr0[c * wms_c] + mwx1 * mr0b[c * wms_c];
+                        const float bot = mwx0 * mr1[c * wms_c] + mwx1 * mr1b[c * wms_c];
                         m[c] = mwy0 * top + mwy1 * bot;
                     }
                 }
                 if (auxp) {
                     int ay0, ay1;  float awy0, awy1;
                     bilinear_src(g.sha, y, g.Ha, ay0, ay1, awy0, awy1);
-                    const float* ar0 = acol + (size_t)(ay0 - ra_lo) * g.C * st.was;
-                    const float* ar1 = acol + (size_t)(ay1 - ra_lo) * g.C * st.was;
+                    const float* ar0 = acol + (ay0 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
+                    const float* ar1 = acol + (ay1 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
+                    const float* ar0b = ar0 + adx;  const float* ar1b = ar1 + adx;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
                         a[c] = -INFINITY;
                         if (EXACT || c < g.C) {
-                            const float top = awx0 * ar0[c * st.was] + awx1 * ar0[c * st.was + adx];
-                            const float bot = awx0 * ar1[c * st.was] + awx1 * ar1[c * st.was + adx];
+                            const float top = awx0 * ar0[c * was_c] + awx1 * ar0b[c * was_c];
+                            const float bot = awx0 * ar1[c * was_c] + awx1 * ar1b[c * was_c];
                             a[c] = awy0 * top + awy1 * bot;
                         }
                     }
@@ -642,15 +659,14 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
         st.magqm = ((1u << 20) + (unsigned)(st.wms >> 2) - 1) / (unsigned)(st.wms >> 2);
         st.magqa = ((1u << 20) + (unsigned)(st.was >> 2) - 1) / (unsigned)(st.was >> 2);
         {   // exactness of the two magic divisions over the ranges used (else: 4-byte staging, which needs neither)
-            const int nmc = st.nrm * C * (st.wms >> 2), nac = st.nra * C * (st.was >> 2);
-            bool ok = nmc < 65536 && nac < 65536;
-            for (int k = 0; k < nmc && ok; ++k) ok = (int)(((unsigned)k * st.magqm) >> 20) == k / (st.wms >> 2);
-            for (int k = 0; k < nac && ok; ++k) ok = (int)(((unsigned)k * st.magqa) >> 20) == k / (st.was >> 2);
+            bool ok = true;                                        // lane / (chunks per pair) for lane < 64
+            for (int k = 0; k < 64 && ok; ++k) ok = (int)(((unsigned)k * st.magqm) >> 20) == k / (st.wms >> 2);
+            for (int k = 0; k < 64 && ok; ++k) ok = (int)(((unsigned)k * st.magqa) >> 20) == k / (st.was >> 2);
             if (!ok) st.vec = 0;
         }
         const size_t lds = ((size_t)st.nrm * C * st.wms + (size_t)st.nra * C * st.was + 32) * sizeof(float);
         static const int dbg_reg = getenv("MSPL_LE_REG") ? atoi(getenv("MSPL_LE_REG")) : 0;     // tuning aid: force the register form
-        if (lds <= 128 * 1024 && (st.nrm + st.nra) * C < 4096 && st.wms <= 256 && st.was <= 256 && !(dbg_reg && !hist)) {
+        if (lds <= 128 * 1024 && (st.nrm + st.nra) * C < 4096 && st.wms <= 256 && st.was <= 256 && (!st.vec || (st.wms <= 256 && st.was <= 256)) && !(dbg_reg && !hist)) {
             const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)(4 * ceil_div(ceil_div(H, LE_RB), 4)), (unsigned)N);
             unsigned int* ws = nullptr;
             if (hist) {
@@ -661,18 +677,21 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
                 ws = (unsigned int*)workspace;
             }
             static const bool big_lds = [] {          // C = 24 at 256 columns needs 72 KB (the default cap is 64 KB)
-                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24, false, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true, 132, 68>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
                 return ok;
             }();
             MSPL_REQUIRE(big_lds || lds <= 64 * 1024, MSPL_ERR_HIP, "label_epilogue: could not raise the dynamic LDS limit");
-#define MSPL_LE_LAUNCH(CM, EX) hipLaunchKernelGGL((label_epilogue_lds_kernel<CM, EX>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws)
+#define MSPL_LE_LAUNCH(CM, EX) do { if (wide480) hipLaunchKernelGGL((label_epilogue_lds_kernel<CM, EX, 132, 68>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws); \
+                                   else hipLaunchKernelGGL((label_epilogue_lds_kernel<CM, EX, 0, 0>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws); } while (0)
+            const bool wide480 = (C == 5 || C == 13 || C == 20) && st.wms == 132 && (!aux || st.was == 68);     // the x2 / x4 heads of 480-pixel-wide images
             if (C == 5) MSPL_LE_LAUNCH(5, true);
             else if (C == 13) MSPL_LE_LAUNCH(13, true);
             else if (C == 20) MSPL_LE_LAUNCH(20, true);
-            else if (C <= 8) MSPL_LE_LAUNCH(8, false);
-            else if (C <= 16) MSPL_LE_LAUNCH(16, false);
-            else MSPL_LE_LAUNCH(24, false);
+            else if (C <= 8) { if (wide480) return MSPL_ERR_UNSUPPORTED; hipLaunchKernelGGL((label_epilogue_lds_kernel<8, false, 0, 0>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws); }
+            else if (C <= 16) hipLaunchKernelGGL((label_epilogue_lds_kernel<16, false, 0, 0>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
+            else hipLaunchKernelGGL((label_epilogue_lds_kernel<24, false, 0, 0>), grid, dim3(256), lds, st_, mainp, aux, g, st, lut, labels, kld, ws);
 #undef MSPL_LE_LAUNCH
             MSPL_CHECK_LAUNCH("label_epilogue");
             if (hist) {

@@ -122,66 +122,76 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                                                                 const float* __restrict__ ep_shift,
                                                                 const float* __restrict__ ep_alpha, int ep_ctot, int ep_coff,
                                                                 Pyr3Geom g, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float At[4][2][(P3_SEGMAX + 2) * 24];     // [wave][up branch][row][ky][8]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned wid = blockIdx.x * 4u + (unsigned)wave;
-    wid = __builtin_amdgcn_readfirstlane(wid);
-    if (wid >= g.total) return;                                        // wave-uniform; the kernel has no barrier
-    const int sgi = wid % g.nseg;  wid /= g.nseg;
-    const int cb = wid % g.ncb;  wid /= g.ncb;
-    const int c = wid % g.P;
-    const int n = wid / g.P;
+    // The four waves of a workgroup take four consecutive planes of the SAME column block and row segment: the row tables (A) and
+    // the channel-independent column tables (G) are identical for them, so they are computed once per workgroup (a quarter of
+    // the column tasks per wave) into LDS; after the one barrier every wave folds its own plane's 3x3 weights into its
+    // per-lane C tables and never touches LDS tables of columns again.
+    __shared__ __attribute__((aligned(16))) float At[2][(P3_SEGMAX + 2) * 24];        // [up branch][row][ky][8]
+    __shared__ float Gt[2][3][PXL][5][64];                                             // [up branch][kx][column][tap][lane]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned bid = blockIdx.x;
+    const int sgi = bid % g.nseg;  bid /= g.nseg;
+    const int cb = bid % g.ncb;  bid /= g.ncb;
+    const int plane = (int)bid * 4 + wave;                                 // (N * P) % 4 == 0 (checked by the launcher)
+    const int n = plane / g.P, c = plane - n * g.P;
     const int h = g.h, w = g.w;
     const int ys = sgi * g.SEG, ye = min(ys + g.SEG, h);
     const int px0 = cb * g.CBW + (lane - 1) * PXL;                      // lane 0 / 63: halo columns of the block
-    const bool writer = lane >= 1 && lane <= 62 && px0 < w && px0 < (cb + 1) * g.CBW;
+    const bool writer = lane >= 1 && lane <= 62 && px0 < w;
 
-    // ---- per-wave setup
-    // (1) row tables of the two up branches: entry = lane -> (row index = lane / 3, ky = lane % 3), rows ys-1 .. ye
-    {
+    // ---- per-workgroup setup
+    // (1) row tables of the two up branches (wave 0: branch 0, wave 1: branch 1): entry = lane -> (row index, ky), rows ys-1 .. ye
+    if (wave < 2) {
         const int ri = lane / 3, ky = lane - 3 * ri;
         if (ri < g.SEG + 2) {
             float acc[5];
-            p3_coeffs<T0>(ys - 1 + ri, ky, h, g.hs[0], g.sh[0], acc);
-            float* d = &At[wave][0][ri * 24 + ky * 8];
-            d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3]; d[4] = acc[4];
-            p3_coeffs<T1>(ys - 1 + ri, ky, h, g.hs[1], g.sh[1], acc);
-            d = &At[wave][1][ri * 24 + ky * 8];
+            if (wave == 0) p3_coeffs<T0>(ys - 1 + ri, ky, h, g.hs[0], g.sh[0], acc);
+            else p3_coeffs<T1>(ys - 1 + ri, ky, h, g.hs[1], g.sh[1], acc);
+            float* d = &At[wave][ri * 24 + ky * 8];
             d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2]; d[3] = acc[3]; d[4] = acc[4];
         }
     }
-    // (2) per-lane column tables C_ky[j][s] = sum_kx w[ky][kx] * G_kx[j][s] of the two up branches (this plane's weights)
+    // (2) column tables G_kx[column][tap]: 6 * PXL tasks (branch, kx, column) per lane, task t goes to wave t % 4
+#pragma unroll
+    for (int t = 0; t < 6 * PXL; ++t) {
+        if ((t & 3) == wave) {                                          // uniform
+            const int ub = t / (3 * PXL), r = t - ub * 3 * PXL, kx = r / PXL, j = r - kx * PXL;     // compile-time
+            float acc[5];
+            if (ub == 0) p3_coeffs<T0>(px0 + j, kx, w, g.ws[0], g.sw[0], acc);
+            else p3_coeffs<T1>(px0 + j, kx, w, g.ws[1], g.sw[1], acc);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) Gt[ub][kx][j][q][lane] = acc[q];
+        }
+    }
+    __syncthreads();
+    // (2b) per-lane C_ky[j][s] = sum_kx w[ky][kx] * G_kx[j][s] with this wave's plane's weights
     float C0[3][PXL][5], C1[3][PXL][5];
     {
         const float* w0p = sw0 + (size_t)c * 9;
         const float* w1p = sw1 + (size_t)c * 9;
 #pragma unroll
-        for (int j = 0; j < PXL; ++j) {
-            float g0[5], g1[5], g2[5];
-            p3_coeffs<T0>(px0 + j, 0, w, g.ws[0], g.sw[0], g0);
-            p3_coeffs<T0>(px0 + j, 1, w, g.ws[0], g.sw[0], g1);
-            p3_coeffs<T0>(px0 + j, 2, w, g.ws[0], g.sw[0], g2);
+        for (int j = 0; j < PXL; ++j)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int s2 = 0; s2 < 5; ++s2) {
+                const float a0 = Gt[0][0][j][s2][lane], a1 = Gt[0][1][j][s2][lane], a2 = Gt[0][2][j][s2][lane];
+                const float b0 = Gt[1][0][j][s2][lane], b1 = Gt[1][1][j][s2][lane], b2 = Gt[1][2][j][s2][lane];
 #pragma unroll
-                for (int s = 0; s < 5; ++s) C0[ky][j][s] = fmaf(w0p[ky * 3 + 2], g2[s], fmaf(w0p[ky * 3 + 1], g1[s], w0p[ky * 3] * g0[s]));
-            p3_coeffs<T1>(px0 + j, 0, w, g.ws[1], g.sw[1], g0);
-            p3_coeffs<T1>(px0 + j, 1, w, g.ws[1], g.sw[1], g1);
-            p3_coeffs<T1>(px0 + j, 2, w, g.ws[1], g.sw[1], g2);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int s = 0; s < 5; ++s) C1[ky][j][s] = fmaf(w1p[ky * 3 + 2], g2[s], fmaf(w1p[ky * 3 + 1], g1[s], w1p[ky * 3] * g0[s]));
-        }
+                for (int ky = 0; ky < 3; ++ky) {
+                    C0[ky][j][s2] = fmaf(w0p[ky * 3 + 2], a2, fmaf(w0p[ky * 3 + 1], a1, w0p[ky * 3] * a0));
+                    C1[ky][j][s2] = fmaf(w1p[ky * 3 + 2], b2, fmaf(w1p[ky * 3 + 1], b1, w1p[ky * 3] * b0));
+                }
+            }
     }
     // (3) per-lane bilinear column sources of the two low-resolution maps
-    int dxa[2][PXL], dxb[2][PXL];  float dw0[2][PXL], dw1[2][PXL];
+    unsigned dxa[2][PXL], dxb[2][PXL];  float dw0[2][PXL], dw1[2][PXL];        // byte offsets inside a low-resolution row
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
             const int px = min(max(px0 + j, 0), w - 1);
-            bilinear_src(g.sw[3 + i], px, g.ws[3 + i], dxa[i][j], dxb[i][j], dw0[i][j], dw1[i][j]);
+            int xa, xb;
+            bilinear_src(g.sw[3 + i], px, g.ws[3 + i], xa, xb, dw0[i][j], dw1[i][j]);
+            dxa[i][j] = (unsigned)xa * 4u;  dxb[i][j] = (unsigned)xb * 4u;
         }
     // (4) wave-uniform constants of this plane (scalar loads)
     const float* wsame = sw2 + (size_t)c * 9;
@@ -199,14 +209,22 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < PXL; ++j) colin[j] = px0 + j >= 0 && px0 + j < w;
 
-    // x row loader: columns px0-2 .. px0+PXL+1 of row r (zero outside the image)
+    // x row loader: columns px0-2 .. px0+PXL+1 of row r (zero outside the image).  Addresses = uniform row base (scalar
+    // arithmetic) + a per-lane 32-bit byte offset that never changes: no vector instruction goes into addressing.
+    unsigned xoff[PXL + 4];  bool xin[PXL + 4];
+#pragma unroll
+    for (int j = 0; j < PXL + 4; ++j) {
+        const int cx = px0 - 2 + j;
+        xin[j] = cx >= 0 && cx < w;
+        xoff[j] = (unsigned)min(max(cx, 0), w - 1) * 4u;
+    }
     auto load_row = [&](int r, float (&v)[PXL + 4]) {
-        const bool rin = r >= 0 && r < h;
-        const float* row = xpl + (size_t)min(max(r, 0), h - 1) * w;
+        const bool rin = r >= 0 && r < h;                                                   // uniform
+        const char* row = reinterpret_cast<const char*>(xpl + (size_t)min(max(r, 0), h - 1) * w);
 #pragma unroll
         for (int j = 0; j < PXL + 4; ++j) {
-            const int cx = px0 - 2 + j;
-            v[j] = (rin && cx >= 0 && cx < w) ? row[cx] : 0.f;
+            const float t = *reinterpret_cast<const float*>(row + xoff[j]);
+            v[j] = (rin && xin[j]) ? t : 0.f;
         }
     };
 
@@ -224,12 +242,12 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         for (int i = 0; i < 2; ++i) {
             int ya, yb;
             bilinear_src(g.sh[3 + i], min(max(r, 0), h - 1), g.hs[3 + i], ya, yb, enwy0[i], enwy1[i]);       // uniform
-            const float* ra = (i == 0 ? e3 : e4) + ya * g.ws[3 + i];
-            const float* rb = (i == 0 ? e3 : e4) + yb * g.ws[3 + i];
+            const char* ra = reinterpret_cast<const char*>((i == 0 ? e3 : e4) + ya * g.ws[3 + i]);
+            const char* rb = reinterpret_cast<const char*>((i == 0 ? e3 : e4) + yb * g.ws[3 + i]);
 #pragma unroll
             for (int j = 0; j < PXL; ++j) {
-                en[i][j][0] = ra[dxa[i][j]]; en[i][j][1] = ra[dxb[i][j]];
-                en[i][j][2] = rb[dxa[i][j]]; en[i][j][3] = rb[dxb[i][j]];
+                en[i][j][0] = *reinterpret_cast<const float*>(ra + dxa[i][j]); en[i][j][1] = *reinterpret_cast<const float*>(ra + dxb[i][j]);
+                en[i][j][2] = *reinterpret_cast<const float*>(rb + dxa[i][j]); en[i][j][3] = *reinterpret_cast<const float*>(rb + dxb[i][j]);
             }
         }
     };
@@ -243,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int j = 0; j < PXL; ++j) acc[r][j] = 0.f;
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's table writes are visible to its own reads (one wave, in order)
 
 #pragma unroll 1
     for (int br = ys - 1; br <= ye; ++br) {
@@ -261,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         }
         if (br < ye) load_e(br + 1);                       // next row's low-resolution values fly during this row's arithmetic
         if (rowin) {
-            const float* A0 = &At[wave][0][(br - (ys - 1)) * 24];
-            const float* A1 = &At[wave][1][(br - (ys - 1)) * 24];
+            const float* A0 = &At[0][(br - (ys - 1)) * 24];
+            const float* A1 = &At[1][(br - (ys - 1)) * 24];
 #pragma unroll
             for (int j = 0; j < PXL; ++j) { bv[0][j] = 0.f; bv[1][j] = 0.f; bv[2][j] = 0.f; }
             p3_up_branch<T0, PXL>(xw, A0, C0, bv[0]);
@@ -379,7 +396,7 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
     static const int off = getenv("MSPL_PYR_STREAM") ? atoi(getenv("MSPL_PYR_STREAM")) == 0 : 0;
     // maps narrower than ~half a wave leave most lanes idle: the LDS-tiled form is faster there (18x30: 12 vs 17 us)
     static const int min_w = getenv("MSPL_PYR_STREAM_MINW") ? atoi(getenv("MSPL_PYR_STREAM_MINW")) : 40;
-    if (off || nb != 5 || w < min_w) return 1;
+    if (off || nb != 5 || w < min_w || ((int64_t)N * P) % 4 != 0) return 1;
     if (e.pre_add || e.residual || e.reinf_r || e.gate) return 1;    // only the scale/shift/PReLU epilogue
     // branch pattern: up, up, same, down, down (strictly)
     for (int i = 0; i < 5; ++i) if (hs[i] <= 0 || ws[i] <= 0) return 1;
@@ -417,7 +434,7 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
     const int64_t waves = (int64_t)N * P * g.ncb * g.nseg;
     if (waves >= (1ll << 31)) return 1;
     g.total = (unsigned)waves;
-    const dim3 grid((unsigned)ceil_div64(waves, 4)), blk(256);
+    const dim3 grid((unsigned)(waves / 4)), blk(256);          // workgroup = 4 consecutive planes of one (column block, segment)
 #define MSPL_P3_LAUNCH(A, B, L) hipLaunchKernelGGL((pyrpool_stream_kernel<A, B, L>), grid, blk, 0, stream, x, stage_w[0], stage_w[1], stage_w[2], down_e[3], down_e[4], br_scale, br_shift, br_alpha, merge_w, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out)
     if (PXL == 1) {
         if (taps[0] == 3 && taps[1] == 3) MSPL_P3_LAUNCH(3, 3, 1);
