@@ -41,6 +41,34 @@ void set_error(const char* fmt, ...);
 #define MSPL_STAMP_ENV(name) 0
 #endif
 
+// Write-through (sc1) 16- and 8-byte stores for kernel OUTPUTS.  A plain store leaves its line dirty in the XCD's L2 and the
+// whole of a kernel's output is written back at the kernel boundary (+ bytes / 6 TB/s before the successor starts: 3 us behind
+// 17.7 MB, MI355X_MICROARCH.md "boundary" row; measured here: K2 at 36x60 15.6 -> 12.3 us).  With sc1 the bytes leave L2 while the
+// kernel still computes.  Only for data nobody in the same launch reads back.  The asm string ends in s_nop 1 (hipcc does not
+// know the store still reads its data registers: cdna_hip_programming.md section 5.7).
+// Measured on the whole label pass (bench.py, round 2): write-through in K2 alone is neutral for the pass (14 767 vs 14 755
+// images/s) and lifts K2 itself from 0.285 to 0.332 of the HBM roof; write-through in EVERY kernel costs 3 % (14 330): the 1x1
+// kernels' 8-byte sc1 stores are slower than plain ones and their consumers lose the same-XCD L2 hits.  So these helpers are
+// plain stores unless the library is built with WT=1 (-DMSPL_WT_STORES); K2 has its own switch (MSPL_DW_WT, default on).
+typedef float mspl_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mspl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_out4(float* p, const float4& v) {
+#ifndef MSPL_WT_STORES
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    const mspl_f32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+#endif
+}
+__device__ __forceinline__ void store_out2(float* p, const float2& v) {
+#ifndef MSPL_WT_STORES
+    *reinterpret_cast<float2*>(p) = v;
+#else
+    const mspl_f32x2 d = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+#endif
+}
+
 extern std::atomic<int> g_throughput_mode;     // api.hip: mspl_set_throughput_mode
 
 // XCD-contiguous workgroup order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, and each XCD has its own

@@ -92,8 +92,8 @@ __device__ __forceinline__ void vec_load(const void* p, float (&v)[NSUB]) {
 }
 template <int NSUB>
 __device__ __forceinline__ void vec_store(void* p, const float (&v)[NSUB]) {
-    if constexpr (NSUB == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    else if constexpr (NSUB == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    if constexpr (NSUB == 4) store_out4(reinterpret_cast<float*>(p), make_float4(v[0], v[1], v[2], v[3]));        // write-through (common.hpp)
+    else if constexpr (NSUB == 2) store_out2(reinterpret_cast<float*>(p), make_float2(v[0], v[1]));
     else *reinterpret_cast<float*>(p) = v[0];
 }
 
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
         const EpiCh ec = epi_channel(e, cabs);
         float* dst = out + epi_offset(e, img, cabs, p0);
         if (v4) {
-            *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc[m], img, cabs, p0);
+            store_out4(dst, epi_apply4(e, ec, acc[m], img, cabs, p0));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

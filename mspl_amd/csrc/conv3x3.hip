@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             const EpiCh ec = {cc[0], cc[1], cc[2], cc[3], cc[4], cc[5]};
             float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
             if (((g.Wo & 3) == 0)) {
-                *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc[c], img, cabs, pix);
+                store_out4(dst, epi_apply4(e, ec, acc[c], img, cabs, pix));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_stream_kernel(const float* __re
         }
         if (writer) {
             const int pix = y * W + c0;
-            *reinterpret_cast<float4*>(op + pix) = epi_apply4(e, ec, acc, n, cabs, pix);
+            store_out4(op + pix, epi_apply4(e, ec, acc, n, cabs, pix));
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }

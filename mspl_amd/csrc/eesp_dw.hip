@@ -62,6 +62,7 @@ struct DwGeom {
     int NCH;      // 16-byte chunks per input row: ceil(W / 4)
     int chunks;   // CP * RIN * NCH  (<= 256 * DW_PF)
     unsigned mag_xs, mag_nch, mag_rin;   // exact divisions by XS / NCH / RIN: (t * mag) >> 20 (ranges verified on the host)
+    int wt;       // 1: write-through (sc1) stores -- the outputs leave L2 while the kernel runs instead of at its end
     unsigned long long* stamps;  // tuning aid (MSPL_DW_STAMP, STAMPS=1 builds): 4 s_memrealtime stamps per workgroup, or null
 };
 
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw
     if (t < g.ntiles) issue_loads(t);
     __syncthreads();                                       // zero fill complete before the first data writes
     const int hw = g.Ho * g.Wo;
+    // write-through stores go through a buffer descriptor over the whole destination tensor (uniform base, 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)g.N * e.ctot * hw * sizeof(float)), 0x00020000);
     const bool o16 = (g.Wo & 3) == 0, o8 = (g.Wo & 1) == 0;
     const bool has_act = e.alpha != nullptr;
     const size_t kstride = (size_t)g.n * hw * sizeof(float);
@@ -293,7 +296,25 @@ __global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw
                         v[j] = q;
                     }
                     float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
-                    if (o16) {
+                    if (o16 && g.wt) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
+                        __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);          // aux 16 = sc1
+                    } else if (o8 && g.wt) {
+                        // rows of an even number of floats: the strip starts 8-byte aligned; a 16-byte buffer store needs dword
+                        // alignment only.  The row's last strip may hold two pixels.
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
+                        if (xb + 2 < g.Wo) {
+                            const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);
+                        } else {
+                            const u32x2 d0 = {__float_as_uint(v[0]), __float_as_uint(v[1])};
+                            __builtin_amdgcn_raw_buffer_store_b64(d0, orsrc, boff, 0, 16);
+                        }
+                    } else if (o16) {
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (o8) {
                         *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
@@ -418,6 +439,8 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
         if (blocks > 8) blocks -= blocks % 8;             // ids b and b + 8 share an XCD: keep the stride a multiple of 8
     }
     g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
+    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;     // 0: plain stores (A/B aid)
+    g.wt = dbg_wt && (size_t)N * e.ctot * g.Ho * g.Wo * sizeof(float) < (1ull << 31);
     if (persist) hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, true>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
     else hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, false>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
     MSPL_CHECK_LAUNCH("eesp_dw_hff");

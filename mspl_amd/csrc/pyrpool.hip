@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
         const int pix = y * wl_ + xb;
         float* dst = out + epi_offset(e, n, cabs, pix);
         if ((wl_ & 3) == 0) {
-            *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc, n, cabs, pix);
+            store_out4(dst, epi_apply4(e, ec, acc, n, cabs, pix));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

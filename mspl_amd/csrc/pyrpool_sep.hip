@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void pyrpool_sep_kernel(const float* __rest
                 v.z = fmaf(acc[2], esc, esh);  v.z = (ep_alpha && v.z <= 0.f) ? eal * v.z : v.z;
                 v.w = fmaf(acc[3], esc, esh);  v.w = (ep_alpha && v.w <= 0.f) ? eal * v.w : v.w;
                 if (w4) {
-                    *reinterpret_cast<float4*>(dst) = v;
+                    store_out4(dst, v);
                 } else {
                     dst[0] = v.x;
                     if (xb + 1 < wl_) dst[1] = v.y;

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
             }
             if (writer) {
                 float* dst = opl + (size_t)y * w + px0;
-                if (PXL == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[PXL - 1]);
+                if (PXL == 2) store_out2(dst, make_float2(v[0], v[PXL - 1]));
                 else dst[0] = v[0];
             }
         }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void strip_store(const Epi& e, const RsGeom& g, int n
     const int pix = y * g.Wo + x0;
     float* dst = out + epi_offset(e, n, cabs, pix);
     if ((g.Wo & 3) == 0) {
-        *reinterpret_cast<float4*>(dst) = epi_apply4(e, ec, acc, n, cabs, pix);
+        store_out4(dst, epi_apply4(e, ec, acc, n, cabs, pix));
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void bilinear_stream_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = wy0 * ha[j] + wy1 * hb[j];
             const int pix = y * g.Wo + x0;
-            *reinterpret_cast<float4*>(out + epi_offset(e, n, cabs, pix)) = epi_apply4(e, ec, acc, n, cabs, pix);
+            store_out4(out + epi_offset(e, n, cabs, pix), epi_apply4(e, ec, acc, n, cabs, pix));
         }
     }
 }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict_
     if ((e.hw & 3) == 0) {
         const float4 v = *reinterpret_cast<const float4*>(x + off);
         const float a4[4] = {v.x, v.y, v.z, v.w};
-        *reinterpret_cast<float4*>(out + off) = epi_apply4(e, ec, a4, n, cabs, p0);
+        store_out4(out + off, epi_apply4(e, ec, a4, n, cabs, p0));
     } else {
         for (int j = 0; j < 4 && p0 + j < e.hw; ++j) out[off + j] = epi_apply(e, ec, x[off + j], n, cabs, p0 + j);
     }
