@@ -3,11 +3,13 @@
     PixelwiseKLD()(d1, d2)                                            :177-189
     UncertaintyWeightedSegmentationLoss(num_classes, class_weights=None, ignore_idx=None, device='cuda')(pred, target, u_weight)   :146-175
     SegmentationLoss(n_classes, loss_type='ce', device, ignore_idx, class_weights)(inputs, target)   :11-52
+    NIDLoss(image_bin=16, label_bin=4, bw_camera=0.005, bw_label=0.001)(camera, label)   :54-121
 
 Both weight arguments also accept the alias `class_wts` the reference's callers use (uest_seg_multi_os.py:509).  The uest
 training step composes the first two as criterion(pred + 0.5*aux, labels, kld) * 20 + kld.mean(); mspl_amd.training.uest_loss
-is that composition as ONE fused kernel (K11) and is what train_step uses.  NIDLoss / SelectiveBCE / the 'bce' loss type are
-out of scope and raise.
+is that composition as ONE fused kernel (K11) and is what train_step uses.  SelectiveBCE / SoftArgMax as a public class / the 'bce' loss type
+are out of scope: 'bce' raises here, the two classes resolve to the reference's own through the overlay of
+mspl_amd.dropin.
 """
 import torch
 from torch import nn
