@@ -7,6 +7,12 @@ mirroring the reference's failure mode (a RuntimeError from ATen on a shape mism
 import ctypes
 import os
 
+# torch first, always: torch carries its own copy of the HIP runtime and this library binds /opt/rocm's.  The two coexist in
+# one process only when torch's is loaded first (the order every test and bench.py use); with this library first, the first
+# launch from it fails with hipErrorNoDevice (seen with `python __graft_entry__.py smoke`, where build() imports the package
+# before anything imported torch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmspl_hip.so')
 
