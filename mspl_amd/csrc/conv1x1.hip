@@ -545,16 +545,15 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (g.stamps) st0 = __builtin_amdgcn_s_memrealtime();
-    // first tile's operands go out before the weights are staged
+    // Order of the first memory operations (vector loads return in order, so what a wave waits for includes everything it
+    // issued earlier): the workgroup's weights first (L2 hits, needed before the barrier), then the first tile's B ring, and
+    // the residual rows only AFTER the barrier -- they are not needed before the epilogue and fly during the K loop.  With the
+    // residual first (round 1) the barrier waited for all of it: 7 us of the 28 us of the 512->512 expansion at 18x30
+    // (s_memrealtime stamps), 2 us with this order.
     int gp = 0, img = 0, p = 0;  bool pok = false;
     bool have = active && tile_px(0, gp, pok, img, p);
     const char* xb = x_base(img, p);
     unsigned ooff = (unsigned)((((size_t)img * e.ctot + cbase + mlh) * (size_t)e.hw + p) * sizeof(float));
-    if (have) {
-        if (e.residual) load_residual(ooff);
-#pragma unroll
-        for (int i = 0; i < RING; ++i) load_group(xb, b[i], i);
-    }
     {   // weights (coalesced 16-byte loads, all in flight) and per-row constants -> LDS
         const int kv = g.K >> 2, total = g.AR * kv;
         const float* wg = w + ((size_t)grp * g.M + m0) * g.K;
@@ -567,6 +566,10 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
                 const int m = i / kv, k = (i - m * kv) << 2;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < total && m < mrem) v[u] = *reinterpret_cast<const float4*>(wg + (size_t)m * g.K + k);
+            }
+            if (base == 0 && have) {
+#pragma unroll
+                for (int i = 0; i < RING; ++i) load_group(xb, b[i], i);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
     }
     __syncthreads();
     if (!have) return;                                        // (no barrier follows)
+    if (e.residual) load_residual(ooff);
     if (g.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     // rows beyond the staged ones (M < 32: the 16-row decoder projections) read the last staged row; their results are
     // computed and dropped (stores are masked by ml < mrem)
@@ -758,7 +762,8 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     g.KS = g.K | 1;
     int mbr = ((g.M + 31) / 32) * 32;
     if (mbr > 128) mbr = 128;
-    while (mbr > 32 && (size_t)mbr * (g.KS + ROWC) * 4 > 40 * 1024) mbr -= 32;
+    static const int dbg_plds = getenv("MSPL_PW_PIPE_LDS") ? atoi(getenv("MSPL_PW_PIPE_LDS")) : 40;     // KiB of weights per workgroup
+    while (mbr > 32 && (size_t)mbr * (g.KS + ROWC) * 4 > (size_t)dbg_plds * 1024) mbr -= 32;
     if (mbr == 96) mbr = 64;
     g.MB = mbr;
     g.mblocks = ceil_div(g.M, mbr);
@@ -792,7 +797,14 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     }
     g.AR = g.M < g.MB ? g.M : g.MB;
     const size_t lds = ((size_t)g.MB * ROWC + (size_t)g.AR * g.KS) * sizeof(float);
-    MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "conv1x1: weight tile of %zu B exceeds LDS", lds);
+    MSPL_REQUIRE(lds <= 96 * 1024, MSPL_ERR_UNSUPPORTED, "conv1x1: weight tile of %zu B exceeds LDS", lds);
+    if (lds > 64 * 1024) {
+#define MSPL_PIPE_ATTR(NG) do { (void)hipFuncSetAttribute((const void*)conv1x1_pipe_kernel<2, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                                (void)hipFuncSetAttribute((const void*)conv1x1_pipe_kernel<1, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); } while (0)
+        static bool attr_done = false;
+        if (!attr_done) { MSPL_PIPE_ATTR(8); MSPL_PIPE_ATTR(12); MSPL_PIPE_ATTR(16); (void)hipGetLastError(); attr_done = true; }
+#undef MSPL_PIPE_ATTR
+    }
 #define MSPL_PIPE(NG) do { if (nsub == 2) hipLaunchKernelGGL((conv1x1_pipe_kernel<2, NG>), grid, blk, lds, s, x, w, g, e, out); \
                            else hipLaunchKernelGGL((conv1x1_pipe_kernel<1, NG>), grid, blk, lds, s, x, w, g, e, out); } while (0)
     switch (g.K >> 3) {
