@@ -344,10 +344,270 @@ static bool magic_exact(unsigned mag, int dv, int limit) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Direct form: no LDS tile, no staging phase.  A pure data-movement kernel of K2's bytes runs in 3-6 us at the 18x30 / 36x60
+// levels (tools/ubench/floor.hip: 4.0 us for the 22 MB of a 18x30 launch) where the tiled kernel above takes 11-12 us: its
+// load -> LDS -> barrier -> arithmetic -> store phases run one after the other in every workgroup of a one-round launch.  Here
+// a lane owns RV vertically adjacent 1x4 output strips of one plane and reads the input rows it needs straight from
+// global memory (the rows of a plane are L1 / L2 hits after their first use; each row is read once per output row that uses it)
+// with 16-byte BUFFER loads whose out-of-range lanes (rows above / below the plane, the float4 left of column 0 or right of
+// the row end) are given an offset beyond the descriptor's range and come back as zeros: the zero padding costs no
+// arithmetic.  All loads of an item are issued before the first FMA; contributions are accumulated input row by input row,
+// which visits (branch, kernel row) in the same order per accumulator as the tiled kernel: results are bit-identical.
+// Weights / epilogue constants of the workgroup's planes still sit in LDS (48 + 16 floats per plane, staged while the loads fly).
+struct DdGeom {
+    int N, n, H, W, Ho, Wo;
+    int CP, TH, bands, cgroups, ntiles;
+    int XS;                   // strips of 4 outputs per output row
+    unsigned mag_xs;          // exact it / XS for it < CP * TH * XS (verified on the host)
+    int wt;
+    unsigned in_bytes;        // bytes of x: range of the load descriptor
+};
+
+typedef unsigned int dd_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int STRIDE, class DS, int RV, bool PARTIAL>
+__global__ __launch_bounds__(512, 2) void eesp_dw_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 DdGeom g, Epi e, float* __restrict__ out) {
+    constexpr int MAXD = DS::maxd();
+    constexpr int NF = STRIDE == 1 ? 3 : 4;                      // float4s of an input row that a strip's taps touch
+    constexpr int NRO = (RV - 1) * STRIDE + 2 * MAXD + 1;         // input rows of an item
+    __shared__ __attribute__((aligned(16))) float wl[4 * 48];     // [CP <= 4][branch * 3 + ky][4]
+    __shared__ __attribute__((aligned(16))) float el[4 * 16];     // [CP][branch][4]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int L = xcd_remap(blockIdx.x, g.ntiles);
+    const int band = L % g.bands;  L /= g.bands;
+    const int cg = L % g.cgroups;
+    const int img = L / g.cgroups, c0 = cg * g.CP, y0b = band * g.TH;
+    const int rows_here = min(g.TH, g.Ho - y0b);
+    const int rgs = (rows_here + RV - 1) / RV;                    // row groups of this band
+    const int items = g.CP * rgs * g.XS;
+    const unsigned mag_rg = ((1u << 20) + (unsigned)rgs - 1) / (unsigned)rgs;
+    const int hw = g.Ho * g.Wo;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)g.N * e.ctot * hw * sizeof(float)), 0x00020000);
+    const bool o16 = (g.Wo & 3) == 0;
+    const bool has_act = e.alpha != nullptr;
+    const size_t kstride = (size_t)g.n * hw * sizeof(float);
+    char* ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
+    const unsigned pbase = (unsigned)((((size_t)img * g.n + c0) * g.H) * (size_t)g.W * sizeof(float));   // < 2^31 (host)
+    const unsigned plane_bytes = (unsigned)((size_t)g.H * g.W * sizeof(float));
+    const unsigned row_bytes = (unsigned)(g.W * sizeof(float));
+
+    // constants of this workgroup's planes: loads go out first, the LDS writes wait for them while the first item's rows fly
+    float wreg = 0.f, ereg = 0.f;
+    const int nwts = g.CP * 48, neps = g.CP * 16;
+    if (tid < nwts) {
+        const int p = tid / 48, r = tid - p * 48, kq = r >> 2, kx = r & 3, k = kq / 3, ky = kq - 3 * k;
+        if (kx < 3) wreg = w[((size_t)k * g.n + (c0 + p)) * 9 + ky * 3 + kx];
+    }
+    if (tid < neps) {
+        const int p = tid >> 4, r = tid & 15, k = r >> 2, f = r & 3;
+        const int cabs = e.coff + k * g.n + c0 + p;
+        const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
+        ereg = f == 3 ? 0.f : (src ? src[cabs] : (f == 1 ? 0.f : 1.f));
+    }
+
+    for (int it0 = 0; it0 < items; it0 += nthr) {                 // uniform trip count (the barrier sits in the first trip)
+        const bool act = it0 + tid < items;
+        const int it = act ? it0 + tid : 0;
+        const int t2 = (int)(((unsigned)it * g.mag_xs) >> 20);
+        const int xs = it - t2 * g.XS;
+        const int p = (int)(((unsigned)t2 * mag_rg) >> 20);
+        const int rg = t2 - p * rgs;
+        const int yo = y0b + rg * RV;                             // first output row of the item
+        const int cc0 = xs * 4 * STRIDE - 4;                      // input column of window element 0
+        const int rbase = yo * STRIDE - MAXD;                     // input row of window row 0
+        const unsigned off0 = pbase + (unsigned)p * plane_bytes + (unsigned)(rbase * (int)row_bytes + cc0 * 4);   // wraps only where invalid
+        bool cv[NF], part[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int c = cc0 + 4 * i;
+            cv[i] = c >= 0 && c < g.W;
+            part[i] = PARTIAL && (c + 2 == g.W);                  // W % 4 == 2: the float4 that straddles the row end
+        }
+        // ---- all loads of the item
+        float win[NRO][NF * 4];
+#pragma unroll
+        for (int ro = 0; ro < NRO; ++ro) {
+            const int r = rbase + ro;
+            const bool rv = r >= 0 && r < g.H;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const unsigned off = (rv && cv[i]) ? off0 + (unsigned)ro * row_bytes + 16u * i : 0x80000000u;
+                const dd_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(irsrc, (int)off, 0, 0);
+                win[ro][4 * i] = __uint_as_float(q.x); win[ro][4 * i + 1] = __uint_as_float(q.y);
+                win[ro][4 * i + 2] = __uint_as_float(q.z); win[ro][4 * i + 3] = __uint_as_float(q.w);
+            }
+        }
+        if (it0 == 0) {
+            if (tid < nwts) wl[tid] = wreg;
+            if (tid < neps) el[tid] = ereg;
+            __syncthreads();
+        }
+        if (PARTIAL) {
+#pragma unroll
+            for (int ro = 0; ro < NRO; ++ro)
+#pragma unroll
+                for (int i = 1; i < NF; ++i) {
+                    win[ro][4 * i + 2] = part[i] ? 0.f : win[ro][4 * i + 2];
+                    win[ro][4 * i + 3] = part[i] ? 0.f : win[ro][4 * i + 3];
+                }
+        }
+        // ---- arithmetic, input row by input row
+        const float4* wp = reinterpret_cast<const float4*>(wl) + p * 12;
+        const float4* ep = reinterpret_cast<const float4*>(el) + p * 4;
+        float a[RV][4][4];
+#pragma unroll
+        for (int ry = 0; ry < RV; ++ry)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[ry][k][j] = 0.f;
+#pragma unroll
+        for (int ro = 0; ro < NRO; ++ro) {
+#pragma unroll
+            for (int ry = 0; ry < RV; ++ry)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int d = DS::d(k);
+                        if (ry * STRIDE + (ky - 1) * d + MAXD != ro) continue;       // compile time
+                        const float4 w4 = wp[k * 3 + ky];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int cj = 4 + j * STRIDE;                           // window index of the centre tap
+                            a[ry][k][j] = fmaf(w4.x, win[ro][cj - d], a[ry][k][j]);
+                            a[ry][k][j] = fmaf(w4.y, win[ro][cj], a[ry][k][j]);
+                            a[ry][k][j] = fmaf(w4.z, win[ro][cj + d], a[ry][k][j]);
+                        }
+                    }
+        }
+        // ---- hierarchical feature fusion, folded BN + PReLU, stores
+#pragma unroll
+        for (int ry = 0; ry < RV; ++ry) {
+            const int y = yo + ry;
+            const bool yok = act && y < y0b + rows_here;
+            const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)y * g.Wo + xs * 4) * sizeof(float));
+            float prev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 ec = ep[k];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[ry][k][j] += prev[j];
+                    prev[j] = a[ry][k][j];
+                    float q = fmaf(a[ry][k][j], ec.x, ec.y);
+                    if (has_act) q = q > 0.f ? q : ec.z * q;
+                    v[j] = q;
+                }
+                if (!yok) continue;
+                float* dst = reinterpret_cast<float*>(ob + k * kstride + voff);
+                const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
+                const dd_u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                if (o16 || xs * 4 + 2 < g.Wo) {                   // (Wo % 4 == 2: the row's last strip holds two pixels)
+                    if (g.wt) __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);
+                    else __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 0);
+                } else {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 d0 = {dv.x, dv.y};
+                    if (g.wt) __builtin_amdgcn_raw_buffer_store_b64(d0, orsrc, boff, 0, 16);
+                    else __builtin_amdgcn_raw_buffer_store_b64(d0, orsrc, boff, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// Returns MSPL_OK when launched, 1 when the shape is left to the tiled kernel.
+template <int STRIDE, class DS>
+static int launch_direct(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out, hipStream_t s) {
+    static const int dbg = getenv("MSPL_DW_DIRECT") ? atoi(getenv("MSPL_DW_DIRECT")) : 1;
+    static const int dbg_rv = getenv("MSPL_DW_RV") ? atoi(getenv("MSPL_DW_RV")) : 0;
+    static const int dbg_cp = getenv("MSPL_DW_DCP") ? atoi(getenv("MSPL_DW_DCP")) : 0;
+    static const int dbg_th = getenv("MSPL_DW_DTH") ? atoi(getenv("MSPL_DW_DTH")) : 0;
+    static const int dbg_t = getenv("MSPL_DW_DT") ? atoi(getenv("MSPL_DW_DT")) : 0;
+    // Measured (tools/bench_ops.py k2, batch 16): stride 2 -- 72x120 -> 36x60: 13.6 -> 10.5 us, 36x60 -> 18x30: 9.1 -> 7.4 us,
+    // 144x240 -> 72x120: 32.3 -> 30.9 us.  Stride 1 (18x30: 12.0 vs 11.3 us, 36x60: 15.6 vs 12.6 us) stays with the tiled kernel:
+    // there every input row is read by 7-9 output rows and the 16-byte loads of all those lanes go through the CU's one
+    // 64 B/clk L1 path, which is slower than the tiled kernel's LDS reads (MSPL_DW_DIRECT=2 forces the direct form).
+    if (!dbg) return 1;
+    if (STRIDE == 1 && dbg < 2) return 1;
+    DdGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.n = n; g.H = H; g.W = W;
+    g.Ho = (H - 1) / STRIDE + 1;  g.Wo = (W - 1) / STRIDE + 1;
+    const bool partial = (W & 3) == 2;
+    if ((W & 3) != 0 && !partial) return 1;                       // odd row lengths: tiled kernel
+    if ((g.Wo & 1) != 0) return 1;
+    const size_t in_bytes = (size_t)N * n * H * W * sizeof(float), out_bytes = (size_t)N * e.ctot * g.Ho * g.Wo * sizeof(float);
+    if (in_bytes >= (1ull << 31) || out_bytes >= (1ull << 31)) return 1;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 15)) return 1;
+    g.in_bytes = (unsigned)in_bytes;
+    g.XS = ceil_div(g.Wo, 4);
+    const int RV = dbg_rv > 0 ? dbg_rv : (STRIDE == 2 && g.Ho >= 36 ? 2 : 1);
+    // tile = CP planes x TH output rows with CP * ceil(TH / RV) * XS items, ideally one per thread of a block of T <= 512 threads
+    int cp = 0, th = 0, T = 0;
+    double best = 1e30;
+    for (int c = 1; c <= 4; ++c) {
+        if (n % c) continue;
+        for (int nb = 1; nb <= g.Ho; ++nb) {
+            const int h = ceil_div(ceil_div(g.Ho, nb), RV) * RV;
+            if (nb > 1 && ceil_div(ceil_div(g.Ho, nb - 1), RV) * RV == h) continue;
+            const int items = c * (h / RV) * g.XS;
+            for (int t = 64; t <= 512; t += 64) {
+                if (items > t) continue;                          // one item per thread
+                const double waste = (double)t / items;
+                const int64_t tiles = (int64_t)N * (n / c) * ceil_div(g.Ho, h);
+                const double waves = (double)tiles * (t / 64);
+                const double starve = waves >= 2048 ? 1.0 : 2048.0 / waves;
+                const double halo = (double)((h - 1) * STRIDE + 1 + 2 * DS::maxd()) / (double)((h - 1) * STRIDE + 1);   // L1 misses at band edges
+                const double score = waste * starve * (0.8 + 0.2 * halo);
+                if (score < best - 1e-9) { best = score; cp = c; th = h; T = t; }
+                break;                                            // smallest t that fits
+            }
+        }
+    }
+    if (T == 0) return 1;
+    if (dbg_cp > 0 && dbg_cp <= 4 && n % dbg_cp == 0) cp = dbg_cp;
+    if (dbg_th > 0) th = ceil_div(std::min(dbg_th, g.Ho), RV) * RV;
+    if (dbg_cp > 0 || dbg_th > 0 || dbg_t > 0) {
+        const int items = cp * (th / RV) * g.XS;
+        T = dbg_t > 0 ? dbg_t : std::min(512, ceil_div(items, 64) * 64);
+        if (T % 64 || T < 64 || T > 512) return 1;
+    }
+    g.CP = cp; g.TH = th;
+    g.bands = ceil_div(g.Ho, th);
+    g.cgroups = n / cp;
+    const int64_t ntiles = (int64_t)N * g.cgroups * g.bands;
+    if (ntiles >= (1ll << 30)) return 1;
+    g.ntiles = (int)ntiles;
+    g.mag_xs = magic20(g.XS);
+    const int max_items = cp * (th / RV) * g.XS;
+    if (max_items >= 4096 || !magic_exact(g.mag_xs, g.XS, max_items + 1024)) return 1;
+    for (int rg = 1; rg <= th / RV; ++rg)
+        if (!magic_exact(magic20(rg), rg, cp * rg + 1024 / g.XS + 2)) return 1;
+    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    g.wt = dbg_wt;
+    const dim3 grid((unsigned)ntiles), blk((unsigned)T);
+#define MSPL_DD(RVV) do { if (partial) hipLaunchKernelGGL((eesp_dw_direct_kernel<STRIDE, DS, RVV, true>), grid, blk, 0, s, x, w, g, e, out); \
+                          else hipLaunchKernelGGL((eesp_dw_direct_kernel<STRIDE, DS, RVV, false>), grid, blk, 0, s, x, w, g, e, out); } while (0)
+    if (RV == 2) MSPL_DD(2); else MSPL_DD(1);
+#undef MSPL_DD
+    MSPL_CHECK_LAUNCH("eesp_dw_hff(direct)");
+    return MSPL_OK;
+}
+
 template <int STRIDE, class DS>
 static int launch(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out,
                   hipStream_t s) {
     constexpr int MAXD = DS::maxd();
+    {
+        const int rc = launch_direct<STRIDE, DS>(x, w, N, n, H, W, e, out, s);
+        if (rc <= 0) return rc;
+    }
     DwGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.n = n; g.H = H; g.W = W;
