@@ -377,6 +377,13 @@ int mspl_nid_hist_bwd(const float* camera, const float* label, int32_t B, int32_
 int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4, const int32_t* dil, int32_t stride, int32_t N,
                      int32_t n, int32_t H, int32_t W, float* gx, float* const* gw, void* stream);
 
+/* Transposed copies of many convolution weights in one launch (the weights of the data-gradient convolutions of a training
+ * step; replaces one ATen permute copy + flip per convolution, autograd.ConvFn.backward).  seg_table: device array of
+ * { const float* src; float* dst; int32 groups, cin_g, cout_g, k, numel, pad } (40 bytes each); src is (G*cout_g, cin_g, k, k),
+ * dst is (G*cin_g, cout_g, k, k) with both spatial axes reversed.  block_table: device array of int32 pairs {segment, first
+ * element} -- one workgroup of 256 destination elements each. */
+int mspl_transpose_weights(const void* seg_table, const void* block_table, int32_t nblocks, void* stream);
+
 /* torch.optim.Adam step on a flat fp32 buffer (L2 weight decay folded into the gradient; bias correction by `step`). */
 int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);

@@ -46,6 +46,93 @@ def _sink(p):
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
 
 
+# ---- transposed weights of the data-gradient convolutions, all in one launch ------------------------------------------------
+# ConvFn.backward runs the data gradient of a stride-1 convolution on the forward kernels with transposed (3x3: also flipped)
+# weights.  Repacking them where they are needed is one ATen permute copy (+ one flip) per convolution on the backward chain.
+# A WeightTransposer knows the convolutions of a model's step (collected during the first, eager step), keeps their transposed
+# copies in one flat buffer and refreshes all of them with ONE kernel at the start of a step; inside `with tr.active():`
+# ConvFn.backward takes its copy from there.  Outside that scope (or for a weight the transposer has not seen) the copy is made
+# on the spot as before, so a stale table can never be read by accident.
+_WT_COLLECT = [None]             # list collecting (weight, groups, k) during the first step, or None
+_WT_ACTIVE = [None]              # {data_ptr: (wt view, groups, k, shape)} while a transposer is active
+
+
+class collect_conv_weights(object):
+    def __enter__(self):
+        self.prev = _WT_COLLECT[0]
+        _WT_COLLECT[0] = []
+        return _WT_COLLECT[0]
+
+    def __exit__(self, *exc):
+        _WT_COLLECT[0] = self.prev
+
+
+class WeightTransposer(object):
+    def __init__(self, collected):
+        import numpy as np
+        seen, items = set(), []
+        for w, groups, k in collected:
+            if w.data_ptr() in seen or not w.is_contiguous() or w.dtype != torch.float32:
+                continue
+            seen.add(w.data_ptr())
+            items.append((w, groups, k))
+        self.items = items
+        dev = items[0][0].device if items else torch.device('cuda')
+        self.flat = torch.empty(max(sum(w.numel() for w, _, _ in items), 1), device=dev, dtype=torch.float32)
+        raw = np.zeros((max(len(items), 1), 10), dtype=np.int32)        # struct WtSeg (train.hip): 2 pointers + 6 int32 = 40 bytes
+        blocks, self.lookup, off = [], {}, 0
+        for i, (w, groups, k) in enumerate(items):
+            cout, cin_g = w.shape[0], w.shape[1]
+            cout_g = cout // groups
+            dst = self.flat[off:off + w.numel()]
+            raw[i, 0:4] = np.array([w.data_ptr(), dst.data_ptr()], dtype=np.int64).view(np.int32)
+            raw[i, 4:10] = (groups, cin_g, cout_g, k, w.numel(), 0)
+            self.lookup[w.data_ptr()] = (dst.view(groups * cin_g, cout_g, k, k), groups, k, tuple(w.shape))
+            blocks.extend((i, b) for b in range(0, w.numel(), 256))
+            off += w.numel()
+        self.seg = torch.from_numpy(raw).to(dev)
+        self.blk = torch.tensor(blocks if blocks else [(0, 0)], dtype=torch.int32).to(dev)
+        self.nblocks = len(blocks)
+
+    def run(self):
+        """Refresh every transposed copy from the current weights (one launch on the current stream)."""
+        check(lib.mspl_transpose_weights(_p(self.seg), _p(self.blk), self.nblocks, _stream()))
+
+    def active(self):
+        return _ActiveTransposer(self)
+
+
+class _ActiveTransposer(object):
+    def __init__(self, tr):
+        self.tr = tr
+
+    def __enter__(self):
+        self.prev = _WT_ACTIVE[0]
+        self.tr.run()
+        _WT_ACTIVE[0] = self.tr.lookup
+        return self.tr
+
+    def __exit__(self, *exc):
+        _WT_ACTIVE[0] = self.prev
+
+
+def _transposed_weights(w, groups, k):
+    """(Cout, Cin/g, k, k) -> (Cin, Cout/g, k, k), spatially flipped for k = 3: the weights of the data-gradient convolution."""
+    if _WT_COLLECT[0] is not None:
+        _WT_COLLECT[0].append((w, groups, k))
+    lk = _WT_ACTIVE[0]
+    if lk is not None:
+        hit = lk.get(w.data_ptr())
+        if hit is not None and hit[1] == groups and hit[2] == k and hit[3] == tuple(w.shape):
+            return hit[0]
+    Cout, cg_in = w.shape[0], w.shape[1]
+    cg_out = Cout // groups
+    wt = w.view(groups, cg_out, cg_in, k, k).transpose(1, 2)
+    if k == 3:
+        wt = wt.flip(3, 4)
+    return wt.reshape(groups * cg_in, cg_out, k, k).contiguous()
+
+
 class ConvFn(torch.autograd.Function):
     """Bias-free grouped conv, K in {1,3} (dilation 1), stride 1|2."""
 
@@ -72,11 +159,7 @@ class ConvFn(torch.autograd.Function):
                 # the data gradient of a stride-1 convolution is a convolution with the transposed (and, for 3x3,
                 # spatially flipped) weights: run it on the forward kernels (MFMA 1x1 / LDS-tiled 3x3).  The weight
                 # repack is a tiny permute copy (data movement).
-                cg_in, cg_out = Cin // groups, Cout // groups
-                wt = w.view(groups, cg_out, cg_in, k, k).transpose(1, 2)
-                if k == 3:
-                    wt = wt.flip(3, 4)
-                wt = wt.reshape(Cin, cg_out, k, k).contiguous()
+                wt = _transposed_weights(w, groups, k)
                 gx = ops.conv1x1(gy, wt, groups) if k == 1 else ops.conv3x3(gy, wt, groups, 1)
             else:
                 gx = torch.empty_like(x)

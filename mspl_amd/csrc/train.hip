@@ -820,6 +820,38 @@ extern "C" int mspl_adam_step(float* p, const float* g, float* m, float* v, int6
     return MSPL_OK;
 }
 
+// Transposed (and, for 3x3, spatially flipped) copies of many convolution weights in ONE launch: the weights of the data-gradient
+// convolutions of a training step (autograd.ConvFn.backward runs the data gradient of a stride-1 convolution on the forward
+// kernels).  Per weight this was a permute copy (+ a flip) of a few KB issued from ATen inside the backward chain: 81 + 33
+// launches of the ~1500 of a step.  seg: per weight {src, dst} pointers and {groups, cin_g, cout_g, k}; blk: per block its
+// segment and the index of its first element inside it.
+namespace mspl {
+struct WtSeg { const float* src; float* dst; int32_t G, cin_g, cout_g, k; int32_t numel, pad; };
+
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const WtSeg* __restrict__ seg, const int2* __restrict__ blk) {
+    const int2 b = blk[blockIdx.x];
+    const WtSeg sg = seg[b.x];
+    const int i = b.y + threadIdx.x;                   // destination index: (((g * cin_g + ci) * cout_g + co) * k + ky) * k + kx
+    if (i >= sg.numel) return;
+    const int kk = sg.k * sg.k;
+    const int t = i / kk, r = i - t * kk;
+    const int co = t % sg.cout_g, t2 = t / sg.cout_g;
+    const int ci = t2 % sg.cin_g, g = t2 / sg.cin_g;
+    const int rs = kk - 1 - r;                          // flip both spatial axes (identity for k = 1)
+    sg.dst[i] = sg.src[(((size_t)g * sg.cout_g + co) * sg.cin_g + ci) * kk + rs];
+}
+}  // namespace mspl
+
+extern "C" int mspl_transpose_weights(const void* seg_table, const void* block_table, int32_t nblocks, void* stream) {
+    MSPL_REQUIRE(seg_table && block_table, MSPL_ERR_NULL_POINTER, "transpose_weights: null pointer");
+    MSPL_REQUIRE(nblocks >= 0, MSPL_ERR_BAD_SHAPE, "transpose_weights: nblocks=%d", nblocks);
+    if (nblocks == 0) return MSPL_OK;
+    hipLaunchKernelGGL(mspl::transpose_weights_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const mspl::WtSeg*)seg_table, (const int2*)block_table);
+    MSPL_CHECK_LAUNCH("transpose_weights");
+    return MSPL_OK;
+}
+
 extern "C" int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream) {
     MSPL_REQUIRE(g && out, MSPL_ERR_NULL_POINTER, "hff_suffix_sum: null pointer");
     MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_suffix_sum: bad shape");

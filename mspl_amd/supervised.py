@@ -105,7 +105,8 @@ def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=No
     optimizer=None on the first call: it is built after the first backward from segmentation_param_groups."""
     if optimizer is not None:
         optimizer.zero_grad()
-    with torch.enable_grad(), ag.grad_sinks():
+    tr = getattr(optimizer, 'transposer', None)
+    with torch.enable_grad(), ag.grad_sinks(), (tr.active() if tr is not None else ag.collect_conv_weights()) as got:
         layers.prefold_frozen_bn(model)
         out = model(inputs, depth) if depth is not None else model(inputs)
         outputs = out[0] + 0.5 * out[1]
@@ -117,6 +118,7 @@ def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=No
     if optimizer is None:
         optimizer = FlatSGD(segmentation_param_groups(model, lr, lr_mult, depth is not None), lr=lr * lr_mult,
                             momentum=momentum, weight_decay=weight_decay)
+        optimizer.transposer = ag.WeightTransposer(got)      # (after FlatSGD: the parameters now live in its flat buffer)
     optimizer.all_reduce_grads()
     optimizer.step()
     return loss.detach(), outputs.detach(), optimizer
@@ -140,7 +142,7 @@ class GraphedSupervisedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.optimizer.zero_grad()
-            with torch.enable_grad(), ag.grad_sinks():
+            with torch.enable_grad(), ag.grad_sinks(), self.optimizer.transposer.active():
                 layers.prefold_frozen_bn(model)
                 out = model(self.inputs, self.depth) if self.depth is not None else model(self.inputs)
                 self.outputs = out[0] + 0.5 * out[1]

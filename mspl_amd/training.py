@@ -96,13 +96,16 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
     after the first backward (which reveals the gradient-bearing parameters)."""
     if optimizer is not None:
         optimizer.zero_grad()
-    with torch.enable_grad(), ag.grad_sinks():
+    tr = getattr(optimizer, 'transposer', None)
+    with torch.enable_grad(), ag.grad_sinks(), (tr.active() if tr is not None else ag.collect_conv_weights()) as got:
         layers.prefold_frozen_bn(model)
         pred, aux = model(images)
         loss = uest_loss(pred, aux, labels, class_weights, ignore_idx, ce_scale)
         loss.backward()
     if optimizer is None:
         optimizer = FlatAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        # (built after FlatAdam: the parameters now live in its flat buffer)
+        optimizer.transposer = ag.WeightTransposer(got)
     optimizer.all_reduce_grads()
     optimizer.step()
     return loss.detach(), optimizer
@@ -128,7 +131,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.optimizer.zero_grad()
-            with torch.enable_grad(), ag.grad_sinks():
+            with torch.enable_grad(), ag.grad_sinks(), self.optimizer.transposer.active():
                 layers.prefold_frozen_bn(model)
                 pred, aux = model(self.images)
                 self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)

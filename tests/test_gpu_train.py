@@ -297,3 +297,28 @@ def test_loss_modules_forward_backward():
         losses.PixelwiseKLD()(pred, aux)
     with pytest.raises(RuntimeError, match="only 'ce'"):
         losses.SegmentationLoss(loss_type='bce')
+
+
+def test_weight_transposer_equals_on_the_spot_copies():
+    """One-launch transposed weights (autograd.WeightTransposer, the data-gradient convolutions of a step) against the
+    permute / flip copies ConvFn.backward makes without it; and the table is only read inside `active()`."""
+    from mspl_amd import autograd as ag
+    torch.manual_seed(3)
+    ws = [(torch.randn(64, 16, 1, 1, device='cuda'), 4, 1), (torch.randn(48, 8, 3, 3, device='cuda'), 16, 3),
+          (torch.randn(16, 1, 3, 3, device='cuda'), 16, 3), (torch.randn(13, 16, 1, 1, device='cuda'), 1, 1),
+          (torch.randn(300, 7, 3, 3, device='cuda'), 2, 3)]
+    want = [ag._transposed_weights(w, g, k).clone() for w, g, k in ws]
+    tr = ag.WeightTransposer(ws + ws[:2])                  # duplicates collapse
+    assert len(tr.items) == len(ws)
+    with tr.active():
+        for (w, g, k), ref in zip(ws, want):
+            got = ag._transposed_weights(w, g, k)
+            assert got.data_ptr() != w.data_ptr() and got.data_ptr() >= tr.flat.data_ptr()
+            assert torch.equal(got, ref)
+        ws[0][0].mul_(2.0)                                  # weights change: the next activation refreshes the copies
+    assert ag._WT_ACTIVE[0] is None
+    with tr.active():
+        assert torch.equal(ag._transposed_weights(ws[0][0], 4, 1), want[0] * 2.0)
+    fresh = ag._transposed_weights(ws[1][0], 16, 3)        # outside the scope: made on the spot
+    assert fresh.data_ptr() < tr.flat.data_ptr() or fresh.data_ptr() >= tr.flat.data_ptr() + tr.flat.numel() * 4
+    assert torch.equal(fresh, want[1])
