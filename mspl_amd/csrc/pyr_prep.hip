@@ -10,6 +10,8 @@
 // by one thread, larger ones by a whole wave (shuffle reduction).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -198,6 +200,188 @@ __global__ __launch_bounds__(256) void pyr_down_prep_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming form (round 2).  The band form above moves the full-resolution map global -> registers -> LDS -> registers and runs
+// load / pool / convolve as phases separated by barriers in workgroups that all start together: 37 us for the 35 MB of the
+// 144x240 stage (floor of moving those bytes: ~8 us).  Here one workgroup owns one (image, channel) plane and the map never
+// goes through LDS: a group of lanes owns a pooled row, reads the input rows of its window straight from global memory (all of
+// them in flight at once, 8- or 16-byte coalesced loads) and reduces them in registers.
+//   * exact 2x2 branches (h = 2 hs, w = 2 ws: the 0.5 scale): a lane's 2 or 4 columns of two rows give 1 or 2 pooled values.
+//   * large windows (the 0.1 scale, ~10 x 10): column sums of the window's rows in registers, written to a row buffer of the
+//     wave in LDS (w floats), then lanes ox < ws add their x window.  Same two-accumulator order as the band form.
+// Only the pooled maps (a quarter of the plane + a few hundred floats) are kept in LDS for the depthwise 3x3 that follows the
+// one barrier.  Rows of the second branch are re-read from L2.
+constexpr int PS_MAXWIN = 12;
+
+struct PsGeom {
+    int N, P, h, w, nb;
+    int hs[PP_MAXB], ws[PP_MAXB], off[PP_MAXB], exact2[PP_MAXB];
+    const float* wts[PP_MAXB];
+    float* out[PP_MAXB];
+    int LPR, lprp_shift;       // lanes per input row (w / VW) and log2 of its power-of-two padding
+    int rboff, RBS;            // row buffers: LDS offset, floats per buffer
+};
+
+template <int VW>
+__global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __restrict__ x, PsGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = blockIdx.x, c = plane % g.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lprp = 1 << g.lprp_shift, rpw = 64 >> g.lprp_shift;        // sub-row groups of a wave
+    const int sr = lane >> g.lprp_shift, cl = lane & (lprp - 1);
+    const bool colok = cl < g.LPR;
+    const int nthr = blockDim.x, nwaves = nthr >> 6;                    // 4 .. 16 waves: enough row loads in flight per CU
+    const int gid = wave * rpw + sr, ngroups = nwaves * rpw;
+    const float* xp = x + (size_t)plane * g.h * g.w;
+    const int w = g.w;
+    typedef float vecw __attribute__((ext_vector_type(VW)));
+    auto load_row = [&](int y) {
+        return *reinterpret_cast<const vecw*>(xp + (size_t)y * w + cl * VW);
+    };
+#pragma unroll
+    for (int i = 0; i < PP_MAXB; ++i) {
+        if (i >= g.nb) break;
+        float* Pm = smem + g.off[i];
+        const int hs = g.hs[i], ws = g.ws[i];
+        if (g.exact2[i]) {
+            constexpr int U = 4;                           // pooled rows per group and trip: 8 row loads in flight per lane
+            for (int o0 = 0; o0 < hs; o0 += ngroups * U) {
+                vecw r0[U], r1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int o = o0 + u * ngroups + gid;
+                    if (o < hs && colok) { r0[u] = load_row(2 * o); r1[u] = load_row(2 * o + 1); }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int o = o0 + u * ngroups + gid;
+                    if (o < hs && colok) {
+#pragma unroll
+                        for (int j = 0; j < VW / 2; ++j) {
+                            float s2 = 0.f;                  // (ATen's order inside the window: row-major)
+                            s2 += r0[u][2 * j]; s2 += r0[u][2 * j + 1]; s2 += r1[u][2 * j]; s2 += r1[u][2 * j + 1];
+                            Pm[o * ws + cl * (VW / 2) + j] = s2 / 4.0f;
+                        }
+                    }
+                }
+            }
+        } else {
+            float* RB = smem + g.rboff + (wave * rpw + sr) * g.RBS;
+            for (int ob = 0; ob < hs; ob += ngroups) {     // uniform trip count
+                const int o = ob + gid;
+                const bool ok = o < hs;
+                const int oc = ok ? o : hs - 1;
+                const int y0 = pp_s(oc, g.h, hs), y1 = pp_e(oc, g.h, hs);
+                vecw r[PS_MAXWIN];
+#pragma unroll
+                for (int t = 0; t < PS_MAXWIN; ++t) {
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) r[t][j] = 0.f;
+                    if (colok && y0 + t < y1) r[t] = load_row(y0 + t);
+                }
+                float a0[VW], a1[VW];
+#pragma unroll
+                for (int j = 0; j < VW; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+#pragma unroll
+                for (int t = 0; t < PS_MAXWIN; t += 2) {
+                    if (y0 + t + 1 < y1) {
+#pragma unroll
+                        for (int j = 0; j < VW; ++j) { a0[j] += r[t][j]; a1[j] += r[t + 1][j]; }
+                    } else if (y0 + t < y1) {
+#pragma unroll
+                        for (int j = 0; j < VW; ++j) a0[j] += r[t][j];
+                    }
+                }
+                if (colok) {
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) RB[cl * VW + j] = a0[j] + a1[j];
+                }
+                // (same wave: its LDS operations execute in order, the reads below see the writes above)
+                for (int ox = cl; ox < ws; ox += lprp) {
+                    const int x0 = pp_s(ox, w, ws), x1 = pp_e(ox, w, ws);
+                    float b0 = 0.f, b1 = 0.f;
+                    int xx = x0;
+                    for (; xx + 1 < x1; xx += 2) { b0 += RB[xx]; b1 += RB[xx + 1]; }
+                    if (xx < x1) b0 += RB[xx];
+                    if (ok) Pm[o * ws + ox] = (b0 + b1) / (float)((y1 - y0) * (x1 - x0));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // depthwise 3x3 (zero padding) on the pooled maps
+#pragma unroll
+    for (int i = 0; i < PP_MAXB; ++i) {
+        if (i >= g.nb) break;
+        const float* Pm = smem + g.off[i];
+        const int hs = g.hs[i], ws = g.ws[i];
+        const float* w9 = g.wts[i] + (size_t)c * 9;
+        const float w00 = w9[0], w01 = w9[1], w02 = w9[2], w10 = w9[3], w11 = w9[4], w12 = w9[5], w20 = w9[6], w21 = w9[7], w22 = w9[8];
+        float* dst = g.out[i] + (size_t)plane * hs * ws;
+        const int total = hs * ws;
+        int oy = tid / ws, ox = tid - oy * ws;             // one division; then the index advances by the block size per trip
+        const int dy256 = nthr / ws, dx256 = nthr - dy256 * ws;
+        for (int idx = tid; idx < total; idx += nthr) {
+            auto at = [&](int yy, int xx) { return (yy >= 0 && yy < hs && xx >= 0 && xx < ws) ? Pm[yy * ws + xx] : 0.f; };
+            float v = w00 * at(oy - 1, ox - 1);
+            v = fmaf(w01, at(oy - 1, ox), v);  v = fmaf(w02, at(oy - 1, ox + 1), v);
+            v = fmaf(w10, at(oy, ox - 1), v);  v = fmaf(w11, at(oy, ox), v);  v = fmaf(w12, at(oy, ox + 1), v);
+            v = fmaf(w20, at(oy + 1, ox - 1), v);  v = fmaf(w21, at(oy + 1, ox), v);  v = fmaf(w22, at(oy + 1, ox + 1), v);
+            dst[idx] = v;
+            oy += dy256;  ox += dx256;
+            if (ox >= ws) { ox -= ws; ++oy; }
+        }
+    }
+}
+
+// Returns MSPL_OK when launched, 1 when the shape is left to the band form.
+static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
+                           const float* const* stage_w, float* const* out, hipStream_t stream) {
+    static const int off = getenv("MSPL_PREP_STREAM") ? atoi(getenv("MSPL_PREP_STREAM")) == 0 : 0;
+    if (off || (w & 1) || (((uintptr_t)x) & 15)) return 1;
+    const int VW = (w & 3) == 0 ? 4 : 2;
+    PsGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.P = P; g.h = h; g.w = w; g.nb = nb;
+    g.LPR = w / VW;
+    if (g.LPR > 64) return 1;
+    g.lprp_shift = 0;
+    while ((1 << g.lprp_shift) < g.LPR) ++g.lprp_shift;
+    int off_f = 0;
+    bool any_large = false;
+    for (int i = 0; i < nb; ++i) {
+        g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i];
+        g.exact2[i] = (h == 2 * hs[i] && w == 2 * ws[i]) ? 1 : 0;
+        if (!g.exact2[i]) {
+            const int wy = ceil_div(h, hs[i]) + 1, wx = ceil_div(w, ws[i]) + 1;
+            if (wy * wx <= 16 || wy > PS_MAXWIN) return 1;         // small ragged windows / very tall windows: band form
+            any_large = true;
+        }
+        g.off[i] = off_f;
+        off_f += (hs[i] * ws[i] + 3) & ~3;
+    }
+    g.rboff = off_f;
+    g.RBS = (w + 3) & ~3;
+    // waves per workgroup: one trip of the 2x2 branch should cover the map's rows (all of a plane's row loads in flight at once:
+    // one workgroup per CU is all a launch of N * P = 256 planes gives, so the loads of a CU come from this workgroup alone)
+    static const int dbg_waves = getenv("MSPL_PREP_WAVES") ? atoi(getenv("MSPL_PREP_WAVES")) : 0;
+    int hmax = 1;
+    for (int i = 0; i < nb; ++i) hmax = std::max(hmax, (int)hs[i]);
+    int waves = 4;
+    while (waves < 16 && waves * (64 >> g.lprp_shift) * 4 < hmax) waves *= 2;
+    if (dbg_waves >= 1 && dbg_waves <= 16) waves = dbg_waves;
+    if (any_large) off_f += waves * (64 >> g.lprp_shift) * g.RBS;
+    const size_t lds = (size_t)off_f * sizeof(float);
+    if (lds > 64 * 1024) return 1;
+    const int64_t planes = (int64_t)N * P;
+    if (planes >= (1ll << 31)) return 1;
+    if (VW == 4) hipLaunchKernelGGL(pyr_prep_stream_kernel<4>, dim3((unsigned)planes), dim3(64 * waves), lds, stream, x, g);
+    else hipLaunchKernelGGL(pyr_prep_stream_kernel<2>, dim3((unsigned)planes), dim3(64 * waves), lds, stream, x, g);
+    MSPL_CHECK_LAUNCH("pyr_down_prep(streaming form)");
+    return MSPL_OK;
+}
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -255,6 +439,15 @@ extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int3
     MSPL_REQUIRE(x && hs && ws && stage_w && out, MSPL_ERR_NULL_POINTER, "pyr_down_prep: null pointer");
     MSPL_REQUIRE(N > 0 && P > 0 && h > 0 && w > 0, MSPL_ERR_BAD_SHAPE, "pyr_down_prep: bad shape N=%d P=%d %dx%d", N, P, h, w);
     MSPL_REQUIRE(nb >= 1 && nb <= PP_MAXB, MSPL_ERR_UNSUPPORTED, "pyr_down_prep: %d branches (1..%d)", nb, PP_MAXB);
+    for (int i = 0; i < nb; ++i) {
+        MSPL_REQUIRE(hs[i] > 0 && ws[i] > 0 && hs[i] <= h && ws[i] <= w, MSPL_ERR_BAD_SHAPE,
+                     "pyr_down_prep: branch %d size %dx%d for a %dx%d map", i, hs[i], ws[i], h, w);
+        MSPL_REQUIRE(stage_w[i] && out[i], MSPL_ERR_NULL_POINTER, "pyr_down_prep: branch %d has a null pointer", i);
+    }
+    {
+        const int rc = mspl::prep_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, out, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     PrepGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.P = P; g.h = h; g.w = w; g.nb = nb;

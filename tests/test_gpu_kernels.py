@@ -260,10 +260,13 @@ def test_pyrpool_fused_equals_unfused_and_oracle(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(2, 16, 144, 240, [(72, 120), (15, 24)]), (1, 8, 18, 30, [(9, 15), (5, 5)]),
-                                 (2, 4, 33, 47, [(17, 24), (5, 5)]), (1, 3, 7, 9, [(5, 5)]), (1, 2, 36, 60, [(18, 30), (5, 6), (36, 60)])])
+                                 (2, 4, 33, 47, [(17, 24), (5, 5)]), (1, 3, 7, 9, [(5, 5)]), (1, 2, 36, 60, [(18, 30), (5, 6), (36, 60)]),
+                                 (2, 16, 72, 120, [(36, 60), (8, 12)]), (1, 4, 36, 60, [(18, 30), (5, 6)]), (1, 3, 40, 64, [(7, 9)]),
+                                 (1, 2, 20, 36, [(10, 18)])])
 def test_pyr_down_prep(cfg):
     """One-launch low-resolution pyramid maps == adaptive_avg_pool2d + depthwise 3x3 (torch CPU), incl. overlapping and
-    ragged pooling windows, a branch as large as the map, and the LDS-size query."""
+    ragged pooling windows, a branch as large as the map, and the LDS-size query.  Even row lengths with exact 2x2 and / or
+    ~10x10 windows take the streaming form (all four decoder stages), everything else the band form."""
     from mspl_amd import ops
     N, P, h, w, sizes = cfg
     x = rnd(N, P, h, w, seed=4)
