@@ -575,7 +575,7 @@ def main():
                                    ', %d independent batches in flight per GPU' % depth,
                        'per_gpu_batch': BATCH, 'batches_in_flight': depth, 'input': [BATCH, 3, H, W], 'classes': CLASSES,
                        'sharding': 'image list sharded by rank, no data-path collective'},
-            'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff_kernel (K2, %d launches/forward)' % k2_launches,
+            'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff (K2: eesp_dw_hff_kernel + eesp_dw_direct_kernel, %d launches/forward)' % k2_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': k2_traffic,
                          'traffic_source': k2_traffic_src,
@@ -584,7 +584,7 @@ def main():
             # the whole hot path against SURVEY section 8(d)'s algorithmic activation traffic (356.9 MB/image at 288x480,
             # convs as in+out, the EESP branches as one shared read, BN/PReLU/add/cat fused = 0)
             'roofline_bs64': None if avg64_s is None else {
-                'kernel': 'eesp_dw_hff_kernel, same 13 shapes at batch 64', 'achieved': round(4 * k2_bytes / k2_launches / avg64_s / 1e9, 1),
+                'kernel': 'eesp_dw_hff (K2), same 13 shapes at batch 64', 'achieved': round(4 * k2_bytes / k2_launches / avg64_s / 1e9, 1),
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(4 * k2_bytes / k2_launches / avg64_s / 1e9 / HBM_PEAK_GBS, 4),
                 'avg_launch_us': round(avg64_s * 1e6, 3)},
             'single_in_flight': single,

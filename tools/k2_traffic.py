@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic of the K2 (eesp_dw_hff) launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
+"""HBM traffic of the K2 (eesp_dw_hff: tiled and direct kernels) launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md, section HBM: both counters are in KiB; on gfx950 FETCH_SIZE tallies
 the 128-B requests of wide coalesced reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
@@ -14,7 +14,7 @@ d, out = sys.argv[1], sys.argv[2]
 
 def k2_values(counter):
     rows = csv.DictReader(open('%s/%s_counter_collection.csv' % (d, counter)))
-    return [float(r['Counter_Value']) for r in rows if 'eesp_dw_hff' in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    return [float(r['Counter_Value']) for r in rows if ('eesp_dw_hff' in r['Kernel_Name'] or 'eesp_dw_direct' in r['Kernel_Name']) and r['Counter_Name'] == counter]
 
 
 f, w = k2_values('FETCH_SIZE'), k2_values('WRITE_SIZE')
