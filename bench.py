@@ -264,7 +264,9 @@ def train_step_rate(dev, iters=10, world=1, rank=0):
     g = torch.Generator().manual_seed(7 + rank)           # every rank trains on its own shard (data parallel)
     x = torch.randn((BATCH, 3, 256, 480), generator=g).to(dev)
     y = torch.randint(0, 5, (BATCH, 256, 480), generator=g).to(dev)
-    step = training.GraphedTrainStep(m, x, y, torch.ones(5), ignore_idx=4)
+    # the batch of 16 runs as 4 concurrent micro-batch graphs (same step: frozen BN, mean loss, atomic gradient sinks)
+    lanes = int(os.environ.get('MSPL_TRAIN_LANES', '4'))
+    step = training.GraphedTrainStep(m, x, y, torch.ones(5), ignore_idx=4, lanes=lanes)
     import torch.distributed as dist
 
     def fence():
@@ -292,7 +294,8 @@ def train_step_rate(dev, iters=10, world=1, rank=0):
         in_sync = bool((hi - lo).abs().item() == 0.0)
     return {'value': round(BATCH * world / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
             'n_gpus': world, 'global_batch': BATCH * world,
-            'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay + ' +
+            'micro_batch_lanes': step.lanes,
+            'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay (%d concurrent micro-batch graphs) + ' % step.lanes +
                         ('one flat-bucket gradient all-reduce (%d floats, RCCL) + ' % step.optimizer.flat_g.numel() if world > 1 else '') +
                         'Adam kernel',
             'weights_identical_across_ranks': in_sync, 'loss_finite': bool(torch.isfinite(loss))}

@@ -259,6 +259,9 @@ int mspl_bn_prelu_bwd(const float* c, const float* pre_add, const float* residua
 /* Backward of mspl_gap_gate_fwd's gate = sigmoid(W . mean): gw (Cout,Cin), gmean (N,Cin). */
 int mspl_gap_gate_bwd(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
                       int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream);
+/* Same, but gw (Cout,Cin) is ACCUMULATED into with atomic adds (the parameter's own gradient buffer, zeroed by the caller). */
+int mspl_gap_gate_bwd_accum(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
+                      int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream);
 /* Backward of the hierarchical feature fusion of K2: out_k = sum_{j>=k} g_j over the 4 branch blocks of g (N,4n,HW);
  * out is branch-major (4,N,n,HW). */
 int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream);

@@ -98,17 +98,20 @@ class WeightTransposer(object):
         """Refresh every transposed copy from the current weights (one launch on the current stream)."""
         check(lib.mspl_transpose_weights(_p(self.seg), _p(self.blk), self.nblocks, _stream()))
 
-    def active(self):
-        return _ActiveTransposer(self)
+    def active(self, refresh=True):
+        """Scope in which ConvFn.backward reads the table.  refresh=False: the caller has already run() this step (micro-batch
+        lanes share one refresh)."""
+        return _ActiveTransposer(self, refresh)
 
 
 class _ActiveTransposer(object):
-    def __init__(self, tr):
-        self.tr = tr
+    def __init__(self, tr, refresh=True):
+        self.tr, self.refresh = tr, refresh
 
     def __enter__(self):
         self.prev = _WT_ACTIVE[0]
-        self.tr.run()
+        if self.refresh:
+            self.tr.run()
         _WT_ACTIVE[0] = self.tr.lookup
         return self.tr
 
@@ -309,6 +312,7 @@ class GapGateFn(torch.autograd.Function):
         check(lib.mspl_gap_gate_fwd(_p(x), _p(w), N, Cin, Cout, H * W, _p(mean), _p(gate), _stream()))
         ctx.save_for_backward(mean, gate, w)
         ctx.shape = x.shape
+        ctx.wsink = _sink(w)
         return gate
 
     @staticmethod
@@ -316,9 +320,13 @@ class GapGateFn(torch.autograd.Function):
         mean, gate, w = ctx.saved_tensors
         N, Cin, H, W = ctx.shape
         Cout = w.shape[0]
-        gw = torch.empty_like(w)
         gmean = torch.empty_like(mean)
-        check(lib.mspl_gap_gate_bwd(_p(_c(ggate)), _p(gate), _p(mean), _p(w), N, Cin, Cout, _p(gw), _p(gmean), _stream()))
+        if ctx.wsink is not None:      # atomically into the parameter's gradient buffer (other micro-batch lanes add to it as well)
+            gw = None
+            check(lib.mspl_gap_gate_bwd_accum(_p(_c(ggate)), _p(gate), _p(mean), _p(w), N, Cin, Cout, _p(ctx.wsink), _p(gmean), _stream()))
+        else:
+            gw = torch.empty_like(w)
+            check(lib.mspl_gap_gate_bwd(_p(_c(ggate)), _p(gate), _p(mean), _p(w), N, Cin, Cout, _p(gw), _p(gmean), _stream()))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(ctx.shape, device=w.device, dtype=torch.float32)

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
 
 // ---- EfficientPWConv gate backward: gate = sigmoid(W . mean); given ggate (N,Cout):
 //      gs = ggate * gate * (1 - gate); gW[co,ci] = sum_n gs[n,co] * mean[n,ci]; gmean[n,ci] = sum_co gs[n,co] * W[co,ci]
+template <bool ACC>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ ggate, const float* __restrict__ gate,
                                                        const float* __restrict__ mean, const float* __restrict__ w, int N,
                                                        int Cin, int Cout, float* __restrict__ gw, float* __restrict__ gmean) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
             const float gt = gate[n * Cout + co];
             s = fmaf(ggate[n * Cout + co] * gt * (1.f - gt), mean[n * Cin + ci], s);
         }
-        gw[idx] = s;
+        if (ACC) atomicAdd(&gw[idx], s); else gw[idx] = s;      // ACC: gw is the parameter's gradient buffer (other launches add to it too)
     }
     if (idx < N * Cin) {
         const int n = idx / Cin, ci = idx - n * Cin;
@@ -787,9 +788,20 @@ extern "C" int mspl_gap_gate_bwd(const float* ggate, const float* gate, const fl
     MSPL_REQUIRE(ggate && gate && mean && w && gw && gmean, MSPL_ERR_NULL_POINTER, "gap_gate_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0, MSPL_ERR_BAD_SHAPE, "gap_gate_bwd: bad shape");
     const int n = max(Cout * Cin, N * Cin);
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ggate, gate, mean, w, N,
+    hipLaunchKernelGGL(gate_bwd_kernel<false>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ggate, gate, mean, w, N,
                        Cin, Cout, gw, gmean);
     MSPL_CHECK_LAUNCH("gap_gate_bwd");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_gap_gate_bwd_accum(const float* ggate, const float* gate, const float* mean, const float* w, int32_t N,
+                                       int32_t Cin, int32_t Cout, float* gw, float* gmean, void* stream) {
+    MSPL_REQUIRE(ggate && gate && mean && w && gw && gmean, MSPL_ERR_NULL_POINTER, "gap_gate_bwd_accum: null pointer");
+    MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0, MSPL_ERR_BAD_SHAPE, "gap_gate_bwd_accum: bad shape");
+    const int n = max(Cout * Cin, N * Cin);
+    hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, ggate, gate, mean, w, N,
+                       Cin, Cout, gw, gmean);
+    MSPL_CHECK_LAUNCH("gap_gate_bwd_accum");
     return MSPL_OK;
 }
 

@@ -112,34 +112,87 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
 
 
 class GraphedTrainStep:
-    """train_step with zero_grad + forward + loss + backward replayed as ONE hipGraph (the step is ~1500 launches of
-    5-100 us; eager issue from Python is slower than the GPU executes them).  The gradient all-reduce and the Adam kernel
-    stay outside the graph, so the same object serves N = 1 and N > 1.
+    """train_step with zero_grad + forward + loss + backward replayed as hipGraphs (the step is ~1400 launches of 5-100 us; eager
+    issue from Python is slower than the GPU executes them).  The gradient all-reduce and the Adam kernel stay outside the graphs,
+    so the same object serves N = 1 and N > 1.
+
+    lanes = 1: ONE graph.  lanes = L > 1: the batch is cut into L micro-batches that run as L graphs on L streams AT THE SAME TIME
+    (the kernels of a batch-16 step are too small to fill the chip; graphs on separate streams overlap, branches inside one
+    graph did not).  Same step: BatchNorm is frozen, the loss is a plain mean over the pixels of the batch (K11: 1 / (N*H*W)), so
+    each lane back-propagates loss_lane / L and every parameter-gradient kernel adds into the shared flat gradient buffer with
+    atomics (autograd.grad_sinks); only the floating-point summation order differs.  A parameter whose gradient would go through
+    autograd's (non-atomic) AccumulateGrad in a lane is refused at construction.
 
     The first call runs one eager step (it reveals the gradient-bearing parameters and builds FlatAdam) and captures;
     later calls copy the batch into static buffers and replay.  Shapes are fixed at construction."""
 
-    def __init__(self, model, images, labels, class_weights, ignore_idx=None, lr=5e-4, weight_decay=5e-4, ce_scale=20.0):
+    def __init__(self, model, images, labels, class_weights, ignore_idx=None, lr=5e-4, weight_decay=5e-4, ce_scale=20.0, lanes=1):
         self.model = model
         self.images = images.detach().clone()
         self.labels = labels.detach().to(torch.int64).clone()
         self.cw = _device_class_weights(class_weights, images.device, ignore_idx)
         self.ce_scale = ce_scale
+        B = self.images.shape[0]
+        self.lanes = lanes if (lanes > 1 and B % lanes == 0) else 1
         _, self.optimizer = train_step(model, self.images, self.labels, class_weights, None, ignore_idx, lr, weight_decay,
                                        ce_scale)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.optimizer.zero_grad()
-            with torch.enable_grad(), ag.grad_sinks(), self.optimizer.transposer.active():
-                layers.prefold_frozen_bn(model)
-                pred, aux = model(self.images)
-                self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)
-                self.loss.backward()
+        tr = self.optimizer.transposer
+        if self.lanes == 1:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.optimizer.zero_grad()
+                with torch.enable_grad(), ag.grad_sinks(), tr.active():
+                    layers.prefold_frozen_bn(model)
+                    pred, aux = model(self.images)
+                    self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)
+                    self.loss.backward()
+        else:
+            # what every lane needs first: zeroed gradients, this step's transposed weights and folded BatchNorms (their tensors live
+            # in this graph's pool, the lanes' graphs read them)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.optimizer.zero_grad()
+                tr.run()
+                with torch.no_grad():
+                    layers.prefold_frozen_bn(model)
+            b = B // self.lanes
+            self.streams = [torch.cuda.Stream(device=self.images.device) for _ in range(self.lanes)]
+            self.lane_graphs, self.lane_losses = [], []
+            stray = []
+            # (a tensor hook sees None when the op accumulated into the sink itself, a tensor when autograd is about to add one)
+            hooks = [p.register_hook(lambda g_: stray.append(1) if g_ is not None else None) for p in self.optimizer.params]
+            try:
+                for i, st in enumerate(self.streams):
+                    st.wait_stream(torch.cuda.current_stream())
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        with torch.enable_grad(), ag.grad_sinks(), tr.active(refresh=False):
+                            pred, aux = model(self.images[i * b:(i + 1) * b])
+                            loss = ag.uw_loss(pred, aux, self.labels[i * b:(i + 1) * b], self.cw, ce_scale) * (1.0 / self.lanes)
+                            loss.backward()
+                    self.lane_graphs.append(g)
+                    self.lane_losses.append(loss)
+            finally:
+                for h in hooks:
+                    h.remove()
+            if stray:
+                raise RuntimeError('GraphedTrainStep(lanes=%d): %d parameter gradients went through AccumulateGrad instead of an '
+                                   'atomic gradient sink; concurrent lanes would race on them' % (self.lanes, len(stray)))
         self._finish()      # the capture did not execute: run the step it recorded
 
     def _finish(self):
         self.graph.replay()
+        if self.lanes > 1:
+            cur = torch.cuda.current_stream()
+            ev = cur.record_event()
+            for st, g in zip(self.streams, self.lane_graphs):
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.streams:
+                cur.wait_stream(st)
+            self.loss = torch.stack([l.detach() for l in self.lane_losses]).sum()
         self.optimizer.all_reduce_grads()
         self.optimizer.step()
         return self.loss.detach()

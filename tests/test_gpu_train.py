@@ -211,6 +211,34 @@ def test_graphed_train_step_equals_eager():
         np.testing.assert_allclose(q.cpu().numpy(), p.cpu().numpy(), rtol=0, atol=5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize('lanes', [2, 4])
+def test_micro_batch_lanes_equal_one_graph(lanes):
+    """The step cut into micro-batches that run as concurrent graphs on separate streams (every lane back-propagates loss / L into
+    the shared gradient buffer with atomic adds) = the one-graph step: same losses, same weights after three steps, and the
+    gradient buffer itself right after a step."""
+    from mspl_amd import models, training
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    x = synth_input((4, 3, 32, 48), 8).to(DEV)
+    y = synth_labels((4, 32, 48), 5, 8).to(DEV)
+    cw = torch.tensor([1.0, 0.5, 2.0, 1.0, 1.0])
+    nets = []
+    for _ in range(2):
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(KEYS['espdnetue_s2.0_c5'], 3))
+        nets.append(m.to(DEV).eval())
+    one = training.GraphedTrainStep(nets[0], x, y, cw, ignore_idx=4)
+    many = training.GraphedTrainStep(nets[1], x, y, cw, ignore_idx=4, lanes=lanes)
+    assert many.lanes == lanes and len(many.lane_graphs) == lanes
+    np.testing.assert_allclose(many.optimizer.flat_g.cpu().numpy(), one.optimizer.flat_g.cpu().numpy(), rtol=0, atol=2e-5)
+    l1 = [float(one(x, y)) for _ in range(2)]
+    l2 = [float(many(x, y)) for _ in range(2)]
+    np.testing.assert_allclose(l2, l1, rtol=2e-4, atol=1e-6)
+    for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+        np.testing.assert_allclose(q.cpu().numpy(), p.cpu().numpy(), rtol=0, atol=5e-5, err_msg=k)
+    # a batch the lanes cannot split evenly falls back to one graph
+    assert training.GraphedTrainStep(nets[1], x[:3], y[:3], cw, ignore_idx=4, lanes=2).lanes == 1
+
+
 def test_direct_gradient_sinks_equal_autograd_accumulation(monkeypatch):
     """Steps 2-3 with the parameter-gradient kernels writing straight into the flat gradient buffer (grad_sinks, the default
     of train_step) against the same steps with autograd's own AccumulateGrad (MSPL_GRAD_SINKS=0)."""
