@@ -46,6 +46,10 @@ typedef enum {
  *      v *= gate[n, c]                                         (EfficientPWConv sigmoid gate)
  * Every pointer may be NULL (step skipped).  scale/shift/alpha/reinf_w/gate are indexed by the
  * ABSOLUTE destination channel; pre_add/residual have the destination tensor's shape.
+ * raw_out (convolutions only: mspl_conv1x1_fwd, mspl_conv3x3_fwd; the output must not be a channel slice): the accumulator value v BEFORE any of the
+ * steps above is also stored there, same shape as the destination -- the training forward keeps it for the backward of the
+ * BatchNorm / PReLU (d gamma and the PReLU sign need the un-transformed convolution result), which saves the separate
+ * BatchNorm + PReLU launch of the unfused form.
  */
 typedef struct {
     const float* scale;
@@ -58,6 +62,7 @@ typedef struct {
     const float* gate;      /* (N, out_ctot) */
     int32_t out_ctot;       /* channels of the destination tensor */
     int32_t out_coff;       /* first destination channel written by this call */
+    float* raw_out;         /* see above; NULL = not wanted */
 } mspl_epilogue_t;
 
 const char* mspl_version(void);

@@ -26,7 +26,7 @@ class Epilogue(ctypes.Structure):
     _fields_ = [('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('alpha', ctypes.c_void_p),
                 ('pre_add', ctypes.c_void_p), ('residual', ctypes.c_void_p), ('reinf_r', ctypes.c_void_p),
                 ('reinf_w', ctypes.c_void_p), ('gate', ctypes.c_void_p),
-                ('out_ctot', c_i32), ('out_coff', c_i32)]
+                ('out_ctot', c_i32), ('out_coff', c_i32), ('raw_out', ctypes.c_void_p)]
 
 
 _EP = ctypes.POINTER(Epilogue)

@@ -152,27 +152,31 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        stride, groups, k = ctx.cfg
-        gy = _c(gy)
-        N, Cin, H, W = x.shape
-        Cout = w.shape[0]
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            if stride == 1:
-                # the data gradient of a stride-1 convolution is a convolution with the transposed (and, for 3x3,
-                # spatially flipped) weights: run it on the forward kernels (MFMA 1x1 / LDS-tiled 3x3).  The weight
-                # repack is a tiny permute copy (data movement).
-                wt = _transposed_weights(w, groups, k)
-                gx = ops.conv1x1(gy, wt, groups) if k == 1 else ops.conv3x3(gy, wt, groups, 1)
-            else:
-                gx = torch.empty_like(x)
-                check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
-        if ctx.needs_input_grad[1]:
-            sink = ctx.wsink
-            gw = torch.empty_like(w) if sink is None else None
-            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0 if sink is None else 1,
-                                           _p(gw if sink is None else sink), _stream()))
+        gx, gw = _conv_backward(x, w, ctx.cfg, ctx.wsink, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, None, None
+
+
+def _conv_backward(x, w, cfg, sink, gy, need_gx, need_gw):
+    """(gx, gw) of a bias-free grouped convolution; gw is None when it was accumulated into `sink`."""
+    stride, groups, k = cfg
+    gy = _c(gy)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    gx = gw = None
+    if need_gx:
+        if stride == 1:
+            # the data gradient of a stride-1 convolution is a convolution with the transposed (and, for 3x3,
+            # spatially flipped) weights: run it on the forward kernels (MFMA 1x1 / LDS-tiled 3x3).
+            wt = _transposed_weights(w, groups, k)
+            gx = ops.conv1x1(gy, wt, groups) if k == 1 else ops.conv3x3(gy, wt, groups, 1)
+        else:
+            gx = torch.empty_like(x)
+            check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
+    if need_gw:
+        gw = torch.empty_like(w) if sink is None else None
+        check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0 if sink is None else 1,
+                                       _p(gw if sink is None else sink), _stream()))
+    return gx, gw
 
 
 class EespDwFn(torch.autograd.Function):
@@ -231,30 +235,70 @@ class AffinePReLUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         c, scale, shift, alpha, pre_add, residual, mean, inv = ctx.saved_tensors
-        gy = _c(gy)
-        N, C = c.shape[:2]
-        hw = c[0, 0].numel()
-        dev = c.device
-        gz = torch.empty_like(c) if residual is not None else None
-        gc = torch.empty_like(c)
-        s_sc, s_sh, s_al = ctx.sinks
-        gacc = torch.zeros(3, C, device=dev) if (s_sc is None or s_sh is None or s_al is None) else None
-        gsc = (s_sc if s_sc is not None else gacc[0]) if scale is not None else None
-        gsh = (s_sh if s_sh is not None else gacc[1]) if shift is not None else None
-        gal = (s_al if s_al is not None else gacc[2]) if alpha is not None else None
-        if ctx.bn:
-            check(lib.mspl_bn_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(mean), _p(inv),
-                                        N, C, hw, _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
-        else:
-            check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
-                                            _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
-        r_sc = gsc if s_sc is None else None
-        r_sh = gsh if s_sh is None else None
-        r_al = gal if s_al is None else None
+        gc, gz, r_sc, r_sh, r_al = _affine_backward(c, scale, shift, alpha, pre_add, residual, mean, inv, ctx.bn, ctx.sinks, gy)
         gpre = gc if pre_add is not None else None
         if ctx.bn:
             return gc, None, None, r_al, gpre, gz, r_sc, r_sh, None, None
         return gc, r_sc, r_sh, r_al, gpre, gz, None, None, None, None
+
+
+def _affine_backward(c, scale, shift, alpha, pre_add, residual, mean, inv, bn, sinks, gy):
+    """Backward of y = PReLU((c + pre_add) * scale + shift + residual): (gc, gz = d residual, and the per-channel gradients that
+    were NOT accumulated into a sink: d scale | d gamma, d shift | d beta, d alpha)."""
+    gy = _c(gy)
+    N, C = c.shape[:2]
+    hw = c[0, 0].numel()
+    dev = c.device
+    gz = torch.empty_like(c) if residual is not None else None
+    gc = torch.empty_like(c)
+    s_sc, s_sh, s_al = sinks
+    gacc = torch.zeros(3, C, device=dev) if (s_sc is None or s_sh is None or s_al is None) else None
+    gsc = (s_sc if s_sc is not None else gacc[0]) if scale is not None else None
+    gsh = (s_sh if s_sh is not None else gacc[1]) if shift is not None else None
+    gal = (s_al if s_al is not None else gacc[2]) if alpha is not None else None
+    if bn:
+        check(lib.mspl_bn_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(mean), _p(inv),
+                                    N, C, hw, _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
+    else:
+        check(lib.mspl_affine_prelu_bwd(_p(c), _p(pre_add), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
+                                        _p(gz), _p(gc), _p(gsc), _p(gsh), _p(gal), _stream()))
+    return gc, gz, (gsc if s_sc is None else None), (gsh if s_sh is None else None), (gal if s_al is None else None)
+
+
+class ConvAffinePReLUFn(torch.autograd.Function):
+    """y = PReLU((conv(x, w) + pre_add) * scale + shift + residual) as ONE forward launch: the convolution kernel applies the
+    epilogue and also stores its bare result (mspl_epilogue_t.raw_out), which the backward of the BatchNorm / PReLU needs (d gamma,
+    the PReLU sign).  Backward = AffinePReLUFn's followed by ConvFn's.  Replaces ConvFn + AffinePReLUFn (two launches, the second one
+    reading the convolution result back) wherever a frozen BatchNorm / bias / PReLU follows a convolution directly."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, groups, scale, shift, alpha, pre_add, residual, gamma, beta, mean, inv):
+        x, w = _c(x), _c(w)
+        pre_add = None if pre_add is None else _c(pre_add)
+        residual = None if residual is None else _c(residual)
+        k = w.shape[-1]
+        N, _, H, W = x.shape
+        s = stride if k == 3 else 1
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        c = torch.empty((N, w.shape[0], Ho, Wo), device=x.device, dtype=torch.float32)
+        ep = Epi(scale, shift, alpha, pre_add=pre_add, residual=residual, raw_out=c)
+        y = ops.conv1x1(x, w, groups, ep) if k == 1 else ops.conv3x3(x, w, groups, stride, 0, ep)
+        ctx.save_for_backward(x, w, c, scale, shift, alpha, pre_add, residual, mean, inv)
+        ctx.cfg = (s, groups, k)
+        ctx.wsink = _sink(w)
+        ctx.bn = gamma is not None
+        ctx.sinks = (_sink(gamma if ctx.bn else scale), _sink(beta if ctx.bn else shift), _sink(alpha))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, c, scale, shift, alpha, pre_add, residual, mean, inv = ctx.saved_tensors
+        gc, gz, r_sc, r_sh, r_al = _affine_backward(c, scale, shift, alpha, pre_add, residual, mean, inv, ctx.bn, ctx.sinks, gy)
+        gx, gw = _conv_backward(x, w, ctx.cfg, ctx.wsink, gc, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gpre = gc if pre_add is not None else None
+        if ctx.bn:
+            return gx, gw, None, None, None, None, r_al, gpre, gz, r_sc, r_sh, None, None
+        return gx, gw, None, None, r_sc, r_sh, r_al, gpre, gz, None, None, None, None
 
 
 class AvgPoolFn(torch.autograd.Function):
@@ -427,6 +471,16 @@ def frozen_bn_inv(bn):
             c = (key, torch.rsqrt(rv + bn.eps))
         bn.__dict__['_mspl_inv'] = c
     return c[1]
+
+
+def conv_bn_prelu(x, w, stride, groups, bn, scale, shift, alpha=None, pre_add=None, residual=None):
+    """PReLU(frozenBN(conv(x, w) + pre_add) + residual), one forward launch; (scale, shift) the current no-grad fold of bn."""
+    return ConvAffinePReLUFn.apply(x, w, stride, groups, scale, shift, alpha, pre_add, residual, bn.weight, bn.bias, bn.running_mean,
+                                   frozen_bn_inv(bn))
+
+
+def conv_affine_prelu(x, w, stride, groups, scale=None, shift=None, alpha=None, pre_add=None, residual=None):
+    return ConvAffinePReLUFn.apply(x, w, stride, groups, scale, shift, alpha, pre_add, residual, None, None, None, None)
 
 
 def bn_prelu(c, bn, scale, shift, alpha=None, pre_add=None, residual=None):

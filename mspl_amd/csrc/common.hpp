@@ -95,6 +95,7 @@ struct Epi {
     int ctot;   // destination tensor channels
     int coff;   // first destination channel of this op
     int hw;     // destination pixels per plane
+    float* raw; // convolutions: also store the bare accumulator here (same shape as the destination, ctot == C), or null
 };
 
 static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
@@ -108,12 +109,15 @@ static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
         e.pre_add = ep->pre_add; e.residual = ep->residual;
         e.reinf_r = ep->reinf_r; e.reinf_w = ep->reinf_w; e.gate = ep->gate;
         if (ep->out_ctot > 0) { e.ctot = ep->out_ctot; e.coff = ep->out_coff; }
+        e.raw = ep->raw_out;
     }
     return e;
 }
 
-static inline int check_epi(const mspl_epilogue_t* ep, int C, const char* who) {
+static inline int check_epi(const mspl_epilogue_t* ep, int C, const char* who, bool raw_ok = false) {
     if (!ep) return MSPL_OK;
+    MSPL_REQUIRE(!ep->raw_out || (raw_ok && (ep->out_ctot == 0 || (ep->out_ctot == C && ep->out_coff == 0))), MSPL_ERR_UNSUPPORTED,
+                 "%s: raw_out is for un-sliced convolution outputs only", who);
     if (ep->out_ctot > 0) {
         MSPL_REQUIRE(ep->out_coff >= 0 && ep->out_coff + C <= ep->out_ctot, MSPL_ERR_BAD_SHAPE,
                      "%s: channel slice [%d,%d) outside destination with %d channels", who,

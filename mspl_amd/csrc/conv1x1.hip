@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, ((NSUB == 4 || RING > 4) ? 2 : 3)) void conv1x
                     float v[NSUB];
 #pragma unroll
                     for (int s = 0; s < NSUB; ++s) v[s] = acc[s][r];
+                    if (e.raw) vec_store<NSUB>(reinterpret_cast<char*>(e.raw) + rowoff + ooff, v);      // (ctot == Cout, coff == 0: same offset)
                     if (pb) {
                         float pa[NSUB];
                         vec_load<NSUB>(pb + rowoff + ooff, pa);
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_areg_kernel(const float* __res
                     float v[NSUB];
 #pragma unroll
                     for (int s2 = 0; s2 < NSUB; ++s2) v[s2] = acc[s2][r];
+                    if (e.raw) vec_store<NSUB>(reinterpret_cast<char*>(e.raw) + rowoff + ooff, v);      // (ctot == Cout, coff == 0: same offset)
                     if (pb) {
                         float pa[NSUB];
                         vec_load<NSUB>(pb + rowoff + ooff, pa);
@@ -661,6 +663,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_pipe_kernel(const float* __res
                     float v[NSUB];
 #pragma unroll
                     for (int s2 = 0; s2 < NSUB; ++s2) v[s2] = acc[s2][r];
+                    if (e.raw) vec_store<NSUB>(reinterpret_cast<char*>(e.raw) + rowoff + ooff, v);      // (ctot == Cout, coff == 0: same offset)
                     if (pb) {
                         float pa[NSUB];
                         vec_load<NSUB>(pb + rowoff + ooff, pa);
@@ -746,6 +749,15 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
         const int cabs = e.coff + grp * g.M + ml;
         const EpiCh ec = epi_channel(e, cabs);
         float* dst = out + epi_offset(e, img, cabs, p0);
+        if (e.raw) {
+            float* rd = e.raw + epi_offset(e, img, cabs, p0);
+            if (v4) store_out4(rd, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (p0 + j < g.HW) rd[j] = acc[m][j];
+            }
+        }
         if (v4) {
             store_out4(dst, epi_apply4(e, ec, acc[m], img, cabs, p0));
         } else {
@@ -918,7 +930,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
                  "conv1x1: bad shape N=%d Cin=%d Cout=%d groups=%d HW=%d", N, Cin, Cout, groups, HW);
     MSPL_REQUIRE(Cin % groups == 0 && Cout % groups == 0, MSPL_ERR_BAD_SHAPE,
                  "conv1x1: channels (%d,%d) not divisible by groups %d", Cin, Cout, groups);
-    if (int rc = check_epi(ep, Cout, "conv1x1")) return rc;
+    if (int rc = check_epi(ep, Cout, "conv1x1", true)) return rc;
     const Epi e = make_epi(ep, Cout, HW);
     hipStream_t s = (hipStream_t)stream;
     PwGeom g;

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const float* __rest
             if (row < g.M && p < g.HW) {
                 const int cabs = e.coff + grp * g.M + row;
                 float t = v;
+                if (e.raw) e.raw[((size_t)n * e.ctot + cabs) * (size_t)g.HW + p] = v;
                 t = fmaf(t, e.scale ? e.scale[cabs] : 1.f, e.shift ? e.shift[cabs] : 0.f);
                 if (e.alpha) t = t > 0.f ? t : e.alpha[cabs] * t;
                 out[((size_t)n * e.ctot + cabs) * (size_t)g.HW + p] = t;

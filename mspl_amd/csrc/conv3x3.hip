@@ -167,6 +167,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             const float* cc = cl + (cb * COB + c) * 6;
             const EpiCh ec = {cc[0], cc[1], cc[2], cc[3], cc[4], cc[5]};
             float* dst = out + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
+            if (e.raw) {                                      // training forward: the bare convolution result as well
+                float* rd = e.raw + ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
+                if (((g.Wo & 3) == 0)) store_out4(rd, make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]));
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (xb + j < g.Wo) rd[j] = acc[c][j];
+                }
+            }
             if (((g.Wo & 3) == 0)) {
                 store_out4(dst, epi_apply4(e, ec, acc[c], img, cabs, pix));
             } else {
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_stream_kernel(const float* __re
         }
         if (writer) {
             const int pix = y * W + c0;
+            if (e.raw) store_out4(e.raw + (op - out) + pix, make_float4(acc[0], acc[1], acc[2], acc[3]));
             store_out4(op + pix, epi_apply4(e, ec, acc, n, cabs, pix));
         }
 #pragma unroll
@@ -354,7 +364,7 @@ extern "C" int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32
     MSPL_REQUIRE(stride == 1 || stride == 2, MSPL_ERR_UNSUPPORTED, "conv3x3: stride %d (1 or 2)", stride);
     MSPL_REQUIRE(shuffle_groups >= 0 && (shuffle_groups == 0 || Cin % shuffle_groups == 0), MSPL_ERR_BAD_SHAPE,
                  "conv3x3: shuffle groups %d do not divide Cin=%d", shuffle_groups, Cin);
-    if (int rc = check_epi(ep, Cout, "conv3x3")) return rc;
+    if (int rc = check_epi(ep, Cout, "conv3x3", true)) return rc;
     C3Geom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.cin_g = Cin / groups; g.cout_g = Cout / groups;

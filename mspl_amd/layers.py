@@ -192,6 +192,21 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
     return ag.affine_prelu(z, scale, shift, alpha, pre_add=pre_add, residual=residual)
 
 
+_FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
+
+
+def _conv_bn_act(x, conv, bn, alpha=None, pre_add=None, residual=None):
+    """PReLU(BN(conv(x) + pre_add) + residual) on the training path.  Frozen BatchNorm: one forward launch (the convolution applies
+    the folded BatchNorm / PReLU and keeps its bare result for the backward, autograd.ConvAffinePReLUFn).  Batch statistics: the
+    convolution result is needed first (two launches, as before)."""
+    if bn.training or not _FUSED_TRAIN_FWD:
+        return _bn_act(_conv_train(x, conv), bn, alpha, pre_add, residual)
+    if conv.kernel_size[0] == 3 and conv.dilation[0] != 1:
+        raise RuntimeError('mspl_amd: dilated 3x3 convolutions only occur inside EESP (fused branch op)')
+    scale, shift = train_fold(bn)
+    return ag.conv_bn_prelu(x, conv.weight, conv.stride[0], conv.groups, bn, scale, shift, alpha, pre_add, residual)
+
+
 def train_fold(bn):
     """No-grad (scale, shift) of a frozen BatchNorm for the training forward, cached until a parameter changes (every
     optimizer step); prefold_frozen_bn() fills the caches of a whole model with two multi-tensor launches."""
@@ -237,7 +252,7 @@ class CBR(nn.Module):
 
     def forward(self, input):
         if _training_path():
-            return _bn_act(_conv_train(input, self.conv), self.bn, self.act.weight)
+            return _conv_bn_act(input, self.conv, self.bn, self.act.weight)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift, self.act.weight))
 
@@ -264,7 +279,7 @@ class CB(nn.Module):
 
     def forward(self, input):
         if _training_path():
-            return _bn_act(_conv_train(input, self.conv), self.bn)
+            return _conv_bn_act(input, self.conv, self.bn)
         scale, shift = bn_fold(self.bn)
         return _conv_fwd(input, self.conv, Epi(scale, shift))
 
@@ -314,7 +329,7 @@ class DecCBR(nn.Module):
 
     def forward(self, x):
         if _training_path():
-            return _bn_act(_conv_train(x, self.cbr[0]), self.cbr[1], self.cbr[2].weight)
+            return _conv_bn_act(x, self.cbr[0], self.cbr[1], self.cbr[2].weight)
         return _conv_fwd(x, self.cbr[0], self.epi())
 
 
@@ -386,11 +401,11 @@ class EESP(nn.Module):
         o1 = self.proj_1x1(input)
         cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
         cat = self.br_after_cat(cat)
-        e = _conv_train(cat, self.conv_1x1_exp.conv)
+        exp = self.conv_1x1_exp
         if self.stride == 2 and self.downAvg:
-            return _bn_act(e, self.conv_1x1_exp.bn)
-        residual = input if (self.stride == 1 and e.shape[1] == input.shape[1]) else None
-        return _bn_act(e, self.conv_1x1_exp.bn, self.module_act.weight, residual=residual)
+            return _conv_bn_act(cat, exp.conv, exp.bn)
+        residual = input if (self.stride == 1 and exp.conv.out_channels == input.shape[1]) else None
+        return _conv_bn_act(cat, exp.conv, exp.bn, self.module_act.weight, residual=residual)
 
     def forward(self, input):
         if _training_path():
@@ -635,10 +650,11 @@ class EfficientPyrPool(nn.Module):
         out = self.merge_layer[1](out)                      # Shuffle: view/transpose copy
         out = self.merge_layer[2](out)
         conv = self.merge_layer[3]
-        c = ag.conv(out, conv.weight, 1, 1)
         if self.last_layer_br:
-            return _bn_act(c, self.br.br[0], self.br.br[1].weight)
-        return ag.affine_prelu(c, None, conv.bias, None)
+            return _conv_bn_act(out, conv, self.br.br[0], self.br.br[1].weight)
+        if _FUSED_TRAIN_FWD:
+            return ag.conv_affine_prelu(out, conv.weight, 1, 1, None, conv.bias, None)
+        return ag.affine_prelu(ag.conv(out, conv.weight, 1, 1), None, conv.bias, None)
 
     def forward(self, x, fused=True):
         if _training_path():

@@ -41,13 +41,14 @@ def _vec(t, n, name):
 
 class Epi:
     """Python mirror of mspl_epilogue_t (see include/mspl_hip.h for the exact order of operations)."""
-    __slots__ = ('scale', 'shift', 'alpha', 'pre_add', 'residual', 'reinf_r', 'reinf_w', 'gate')
+    __slots__ = ('scale', 'shift', 'alpha', 'pre_add', 'residual', 'reinf_r', 'reinf_w', 'gate', 'raw_out')
 
     def __init__(self, scale=None, shift=None, alpha=None, pre_add=None, residual=None, reinf_r=None,
-                 reinf_w=None, gate=None):
+                 reinf_w=None, gate=None, raw_out=None):
         self.scale, self.shift, self.alpha = scale, shift, alpha
         self.pre_add, self.residual = pre_add, residual
         self.reinf_r, self.reinf_w, self.gate = reinf_r, reinf_w, gate
+        self.raw_out = raw_out          # convolutions only: a tensor of the destination's shape that also receives the bare result
 
 
 def _build(ep, out, coff, N, C, hw):
@@ -80,6 +81,12 @@ def _build(ep, out, coff, N, C, hw):
             g = _vec(ep.gate, N * ctot, 'gate')
             keep.append(g)
             s.gate = g.data_ptr()
+        if ep.raw_out is not None:
+            r = ep.raw_out
+            if not r.is_cuda or r.dtype != torch.float32 or not r.is_contiguous() or r.numel() != N * C * hw or coff != 0 or ctot != C:
+                raise RuntimeError('mspl_amd: raw_out must be a contiguous float32 CUDA tensor of the (un-sliced) destination shape')
+            keep.append(r)
+            s.raw_out = r.data_ptr()
     return s, keep
 
 

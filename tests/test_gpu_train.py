@@ -84,6 +84,43 @@ def test_affine_prelu_fn():
     check_op(lambda c_, sh_: ag.affine_prelu(c_, None, sh_, None), lambda c_, sh_: c_ + sh_.view(1, -1, 1, 1), [c, sh])
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 24, 4, 9, 13, 1, 1, True), (1, 64, 64, 4, 6, 10, 1, 1, False), (2, 3, 8, 1, 12, 16, 3, 2, False),
+                                 (1, 16, 16, 16, 11, 9, 3, 1, True), (1, 24, 12, 4, 8, 8, 3, 2, False), (2, 8, 13, 1, 10, 12, 1, 1, False),
+                                 (2, 512, 16, 1, 18, 30, 1, 1, False),     # split-K form of the 1x1
+                                 (1, 16, 16, 16, 12, 64, 3, 1, True),      # streaming depthwise 3x3
+                                 (3, 512, 512, 4, 18, 30, 1, 1, True),
+                                 (2, 40, 24, 1, 9, 11, 1, 1, True), (1, 80, 48, 2, 8, 12, 1, 1, False),   # ring-buffer MFMA form (K % 8 != 0 or unlisted K)
+                                 (2, 36, 20, 1, 7, 9, 1, 1, True)])
+def test_conv_affine_prelu_fn(cfg):
+    """One-launch convolution + affine + PReLU of the training forward (the kernel also stores its bare result for the backward):
+    forward, every gradient, and the stored bare result against torch; and bit-equal to the two-launch form it replaces."""
+    from mspl_amd import autograd as ag
+    N, ci, co, g, h, w, k, s, extras = cfg
+    x, wt = rnd(N, ci, h, w, seed=1), rnd(co, ci // g, k, k, seed=2, scale=0.3)
+    ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+    sc, sh, al = rnd(co, seed=4).abs() + 0.5, rnd(co, seed=5), rnd(co, seed=6).abs() * 0.3
+    conv = lambda a, b: F.conv2d(a, b, None, s, (k - 1) // 2, 1, g)
+    if extras:
+        pre, res = rnd(N, co, ho, wo, seed=7), rnd(N, co, ho, wo, seed=8)
+        cpu = lambda a, b, sc_, sh_, al_, pre_, res_: F.prelu((conv(a, b) + pre_) * sc_.view(1, -1, 1, 1) + sh_.view(1, -1, 1, 1) + res_, al_)
+        gpu = lambda a, b, sc_, sh_, al_, pre_, res_: ag.conv_affine_prelu(a, b, s, g, sc_, sh_, al_, pre_, res_)
+        two = lambda a, b, sc_, sh_, al_, pre_, res_: ag.affine_prelu(ag.conv(a, b, s, g), sc_, sh_, al_, pre_, res_)
+        tensors = [x, wt, sc, sh, al, pre, res]
+    else:
+        cpu = lambda a, b, sh_: conv(a, b) + sh_.view(1, -1, 1, 1)
+        gpu = lambda a, b, sh_: ag.conv_affine_prelu(a, b, s, g, None, sh_, None)
+        two = lambda a, b, sh_: ag.affine_prelu(ag.conv(a, b, s, g), None, sh_, None)
+        tensors = [x, wt, sh]
+    check_op(gpu, cpu, tensors, rtol=2e-3, atol=2e-3 if ci >= 256 else 5e-4)
+    ins1 = [t.clone().to(DEV).requires_grad_(True) for t in tensors]
+    ins2 = [t.clone().to(DEV).requires_grad_(True) for t in tensors]
+    y1, g1 = grads_of(gpu, ins1)
+    y2, g2 = grads_of(two, ins2)
+    assert torch.equal(y1, y2)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)       # (weight gradients combine partials with atomics: order varies)
+
+
 def test_resample_fns():
     from mspl_amd import autograd as ag
     x = rnd(2, 3, 15, 21, seed=1)
