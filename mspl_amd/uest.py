@@ -285,17 +285,28 @@ class PipelinedLabelPass:
         for out in plp.flush(): consume(out)
 
     What `plp(...)` returns is valid on the current stream until the next call (its lane's static buffers are reused depth calls
-    later, and every submit first waits for the work already queued on the current stream).  `hist` sums the lanes' histograms."""
+    later, and every submit first waits for the work already queued on the current stream).  `hist` sums the lanes' histograms.
 
-    def __init__(self, make_pass, depth=3, device='cuda'):
-        if depth < 1:
-            raise ValueError('PipelinedLabelPass: depth must be >= 1')
+    group = g > 1: g consecutive batches are staged in a lane's input buffer and labelled by ONE launch of the lane's pass; outputs
+    still come back batch by batch in submission order, depth * g - 1 calls after their batch went in; a batch of another shape or
+    flush() labels a partly filled lane with a shorter launch."""
+
+    def __init__(self, make_pass, depth=3, device='cuda', group=1):
+        if depth < 1 or group < 1:
+            raise ValueError('PipelinedLabelPass: depth and group must be >= 1')
         self.device = torch.device(device)
-        self.depth = depth
+        self.depth, self.group = depth, group
         self.lanes = [make_pass() for _ in range(depth)]
         self.streams = _concurrent_streams(depth, self.device)
         self._pending = []
         self._n = 0
+        # group > 1: `group` consecutive batches are staged in a lane's input buffer and labelled by ONE launch of the lane's pass
+        # (images are independent, so this changes nothing but the launch shapes: at 16 x 3 x 288 x 480 most kernels of a pass are one
+        # round of workgroups, and 32 images per launch run at 16 100 images/s where 16 run at 15 000 -- tools: bench.py
+        # --profile-batch).  Outputs are handed back per batch, in submission order.
+        self._staged = None              # [lane, count, batch shape, buffer] of the lane being filled
+        self._lane_no = 0
+        self._bufs = {}
 
     @property
     def hist(self):
@@ -313,19 +324,40 @@ class PipelinedLabelPass:
 
     @property
     def next_lane(self):
-        return self._n % self.depth
+        """Index into static_inputs() of the buffer the next submitted batch will use."""
+        return self._n % (self.depth * self.group)
+
+    def _group_buffer(self, i, bshape):
+        """Input buffer of lane i for `group` batches of shape bshape: the captured graph's own buffer once there is one (no copy
+        between staging and launch), a plain tensor before."""
+        full = (self.group * bshape[0],) + tuple(bshape[1:])
+        key = (i, full)
+        buf, owned = self._bufs.get(key, (None, False))
+        if not owned:
+            own = self.lanes[i].static_input(full) if hasattr(self.lanes[i], 'static_input') else None
+            if own is not None:
+                buf, owned = own, True
+            elif buf is None:
+                buf = torch.empty(full, device=self.device, dtype=torch.float32)
+            self._bufs[key] = (buf, owned)
+        return buf
 
     def static_inputs(self, shape):
-        """Per-lane static input buffers of the captured graphs (None for eager lanes): filling lane k's buffer and passing it to
-        the k-th call skips the input copy."""
-        return [lane.static_input(shape) for lane in self.lanes]
+        """Static input buffers of the captured graphs, one per batch slot in submission order (depth * group of them; None for
+        eager lanes or before a lane's first launch): filling slot k and passing it to the k-th call skips the input copy."""
+        if self.group == 1:
+            return [lane.static_input(shape) for lane in self.lanes]
+        B = shape[0]
+        full = (self.group * B,) + tuple(shape[1:])
+        out = []
+        for lane in self.lanes:
+            buf = lane.static_input(full)
+            out += [None if buf is None else buf[j * B:(j + 1) * B] for j in range(self.group)]
+        return out
 
-    def submit(self, images):
-        i = self._n % self.depth
-        self._n += 1
+    def _launch(self, i, images):
+        """One launch of lane i's pass on its stream; returns (outputs, event)."""
         st = self.streams[i]
-        cur = torch.cuda.current_stream(self.device)
-        st.wait_stream(cur)             # the inputs, and whatever still reads this lane's previous outputs, are on `cur`
         prev = lib.mspl_set_throughput_mode(1 if self.depth > 1 else 0)      # launch shapes for a shared chip (read at capture)
         try:
             with torch.cuda.stream(st), layers.side_streams(self.depth == 1):    # lanes are captured as linear graphs
@@ -335,27 +367,74 @@ class PipelinedLabelPass:
         with torch.cuda.stream(st):
             ev = torch.cuda.Event()
             ev.record(st)
-        if torch.is_tensor(images) and images.is_cuda:
-            images.record_stream(st)
-        self._pending.append((out, ev))
+        return out, ev
+
+    def _launch_staged(self):
+        i, count, bshape, buf = self._staged
+        self._staged = None
+        B = bshape[0]
+        out, ev = self._launch(i, buf if count == self.group else buf[:count * B])
+
+        def part(t, j):
+            return t[j * B:(j + 1) * B] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == count * B) else t
+        for j in range(count):
+            self._pending.append((tuple(part(t, j) for t in out) if isinstance(out, (tuple, list)) else part(out, j), ev))
+
+    def submit(self, images):
+        self._n += 1
+        cur = torch.cuda.current_stream(self.device)
+        if self.group == 1:
+            i = self._lane_no % self.depth
+            self._lane_no += 1
+            self.streams[i].wait_stream(cur)    # the inputs, and whatever still reads this lane's previous outputs, are on `cur`
+            out, ev = self._launch(i, images)
+            if torch.is_tensor(images) and images.is_cuda:
+                images.record_stream(self.streams[i])
+            self._pending.append((out, ev))
+            return
+        bshape = tuple(images.shape)
+        if self._staged is not None and self._staged[2] != bshape:
+            self._launch_staged()               # a batch of another shape (the loader's last one): label what is staged first
+        if self._staged is None:
+            i = self._lane_no % self.depth
+            self._lane_no += 1
+            self._staged = [i, 0, bshape, self._group_buffer(i, bshape)]
+        i, count, _, buf = self._staged
+        st = self.streams[i]
+        st.wait_stream(cur)
+        slot = buf[count * bshape[0]:(count + 1) * bshape[0]]
+        if not (images.is_cuda and images.data_ptr() == slot.data_ptr()):
+            with torch.cuda.stream(st):
+                slot.copy_(images, non_blocking=True)
+            if images.is_cuda:
+                images.record_stream(st)
+        self._staged[1] = count + 1
+        if self._staged[1] == self.group:
+            self._launch_staged()
 
     def pop(self):
+        if not self._pending and self._staged is not None:
+            self._launch_staged()
         out, ev = self._pending.pop(0)
         torch.cuda.current_stream(self.device).wait_event(ev)
         return out
 
     def __call__(self, images):
         self.submit(images)
-        return self.pop() if len(self._pending) >= self.depth else None
+        waiting = len(self._pending) + (self._staged[1] if self._staged is not None else 0)
+        return self.pop() if waiting >= self.depth * self.group else None
 
     def flush(self):
+        if self._staged is not None:
+            self._launch_staged()
         while self._pending:
             yield self.pop()
 
 
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
-                                      use_graph=True, writer_workers=4, in_flight=3, pre_sharded=False, _label_pass=None):
+                                      use_graph=True, writer_workers=4, in_flight=3, pre_sharded=False, _label_pass=None,
+                                      batches_per_launch=1):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
 
@@ -370,14 +449,15 @@ def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save
     the path lists (:933-940) gathered in loader order; rank 0 writes the list file, every rank returns the same class
     weights.  pre_sharded=True: the caller's loader already yields this rank's batches only (e.g. a sampler over
     dist.shard_indices) -- use it when skipping a foreign batch is not free (the loader decodes it first).
-    `_label_pass`: an object with PipelinedLabelPass's interface, for host-logic tests."""
+    `_label_pass`: an object with PipelinedLabelPass's interface, for host-logic tests.  batches_per_launch: PipelinedLabelPass's
+    `group` (consecutive loader batches labelled by one launch; worth ~5 % at batch 16)."""
     import os.path as osp
     from . import dist as mdist
     from .io import LabelWriter, update_image_list
     rank, world = mdist.world()
     p = _label_pass if _label_pass is not None else PipelinedLabelPass(
         lambda: PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy,
-                                device=device, use_graph=use_graph), depth=in_flight, device=device)
+                                device=device, use_graph=use_graph), depth=in_flight, device=device, group=batches_per_launch)
     p.reset()
     tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
     writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)

@@ -112,10 +112,11 @@ def test_config3_train_step_bs16_256x480():
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4)
 
 
-@pytest.mark.parametrize('depth', [2, 3])
-def test_pipelined_label_pass_equals_single_lane(depth):
+@pytest.mark.parametrize('depth,group', [(2, 1), (3, 1), (3, 2), (2, 3)])
+def test_pipelined_label_pass_equals_single_lane(depth, group):
     """`depth` label passes in flight (PipelinedLabelPass, hipGraph lanes on their own streams; 3 = bench.py's default): the same
-    label maps, uncertainty maps and class histogram as one pass at a time, batch by batch, at the BASELINE shape."""
+    label maps, uncertainty maps and class histogram as one pass at a time, batch by batch, at the BASELINE shape.  group > 1:
+    that many consecutive batches per launch (bench.py: 2); 7 batches leave a partly filled lane for flush()."""
     import argparse
     from mspl_amd import models, uest
     from tests.synth import synth_state_dict
@@ -130,7 +131,7 @@ def test_pipelined_label_pass_equals_single_lane(depth):
     for b in batches:
         lab, kld = ref(b)
         want.append((lab.clone(), kld.clone()))
-    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=depth)
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=depth, group=group)
     got = []
     for b in batches:
         out = plp(b)
