@@ -42,6 +42,7 @@ if 'bil' in spec:
 if 'label' in spec:
     patch('mspl_label_epilogue_fwd', lambda a: True)
     patch('mspl_label_epilogue_hist_fwd', lambda a: True)
-sys.argv = ['bench.py', '--profile-pass', '--in-flight', sys.argv[2], '--steps', '90', '--warmup', '15']
+grp = sys.argv[3] if len(sys.argv) > 3 else '1'
+sys.argv = ['bench.py', '--profile-pass', '--in-flight', sys.argv[2], '--group', grp, '--steps', '90', '--warmup', '18']
 import bench
 bench.main()
