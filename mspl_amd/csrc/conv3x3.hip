@@ -10,6 +10,8 @@
 // window is reused COB*3 times from registers.  Weight reads are LDS broadcasts.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -289,6 +291,150 @@ static int launch_dws(const float* x, const float* w, const C3Geom& g3, const Ep
     return MSPL_OK;
 }
 
+// ------------------------------------------------------------------ grouped 3x3, stride 1, few channels per group: streaming form
+// The PWConv expansion 256 -> 64 in 64 groups at 36x60 (30 us in the LDS-tiled kernel for 7 us of bytes) and its data gradient.  Same
+// machine mapping as the depthwise kernel above, generalised: a lane owns 4 columns of one row, W / 4 lanes cover a row, and
+// 64 / (W / 4) units (image, group, row segment) share a wave, all of the SAME group, so the group's CG * COB * 9 weights and
+// the epilogue constants are wave-uniform (scalar loads).  An input row is read once (CG 16-byte loads per lane, halo columns from
+// the neighbouring lanes by DPP) and contributes to the three output rows it touches, which are carried in three accumulator
+// sets: no LDS, no barrier, no 3-row window in registers.  Summation order per output: kernel row, input channel, kernel column.
+struct GcsGeom {
+    int N, Cin, Cout, G, H, W, sg;
+    int LPR, SUB;            // lanes per row (W / 4), units per wave (64 / LPR)
+    int SEG, nseg;           // output rows per unit, units per (image, group)
+    int upg, wpg;            // units and waves per group
+    unsigned total;          // waves
+};
+
+template <int CG, int COB>
+__global__ __launch_bounds__(256) void gconv3x3_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              GcsGeom g, Epi e, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wid >= g.total) return;                              // wave-uniform; no barrier in this kernel
+    const int grp = wid / g.wpg, wig = wid - grp * g.wpg;    // uniform
+    const int sub = lane / g.LPR, cl = lane - sub * g.LPR;
+    const int unit = wig * g.SUB + sub;                      // (image, segment) of this lane's unit
+    const bool live = sub < g.SUB && unit < g.upg;
+    const int uc = live ? unit : 0;
+    const int img = uc / g.nseg, sgi = uc - img * g.nseg;
+    const int H = g.H, W = g.W;
+    const int ys = sgi * g.SEG, ye = min(ys + g.SEG, H);
+    const bool lok = cl > 0, rok = cl < g.LPR - 1;           // neighbours inside the same row
+    // input planes of the group (Shuffle-aware channel index, nn_layers/cnn_utils.py:109-125), uniform
+    const float* xch[CG];
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci) {
+        int lc = grp * CG + ci;
+        if (g.sg > 0) lc = (lc % g.sg) * (g.Cin / g.sg) + lc / g.sg;
+        xch[ci] = x + (size_t)lc * H * W;
+    }
+    const size_t img_off = (size_t)img * g.Cin * H * W + (size_t)cl * 4;        // per lane
+    const float* wg = w + (size_t)grp * COB * CG * 9;
+    auto load_row = [&](int r, float4 (&v)[CG]) {
+        const bool in = live && r >= 0 && r < H;
+        const size_t off = img_off + (size_t)min(max(r, 0), H - 1) * W;
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci) {
+            const float4 t = *reinterpret_cast<const float4*>(xch[ci] + off);
+            v[ci] = in ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float acc[3][COB][4];                                    // [0]: output row r-1, [1]: row r, [2]: row r+1 at input row r
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < COB; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][c][j] = 0.f;
+    float4 cur[CG], nxt[CG];
+    load_row(ys - 1, cur);
+    const int hw = H * W;
+#pragma unroll 1
+    for (int t = 0; t < g.SEG + 2; ++t) {                    // uniform trip count; r = ys - 1 + t
+        const int r = ys - 1 + t;
+        load_row(r + 1, nxt);                                 // next row's loads fly during this row's arithmetic
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci) {
+            float win[6];
+            win[1] = cur[ci].x; win[2] = cur[ci].y; win[3] = cur[ci].z; win[4] = cur[ci].w;
+            const float fl = dws_from_left(cur[ci].w), fr = dws_from_right(cur[ci].x);
+            win[0] = lok ? fl : 0.f;
+            win[5] = rok ? fr : 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {                     // accumulator a <-> kernel row 2 - a
+                const int ky = 2 - a;
+#pragma unroll
+                for (int c = 0; c < COB; ++c) {
+                    const float* wk = wg + ((size_t)c * CG + ci) * 9 + ky * 3;
+                    const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[a][c][j] = fmaf(w0, win[j], acc[a][c][j]);
+                        acc[a][c][j] = fmaf(w1, win[j + 1], acc[a][c][j]);
+                        acc[a][c][j] = fmaf(w2, win[j + 2], acc[a][c][j]);
+                    }
+                }
+            }
+        }
+        // output row y = r - 1 is complete
+        const int y = r - 1;
+        if (live && y >= ys && y < ye) {
+            const int pix = y * W + cl * 4;
+#pragma unroll
+            for (int c = 0; c < COB; ++c) {
+                const int cabs = e.coff + grp * COB + c;
+                const EpiCh ec = epi_channel(e, cabs);
+                const size_t o = ((size_t)img * e.ctot + cabs) * (size_t)hw + pix;
+                if (e.raw) store_out4(e.raw + o, make_float4(acc[0][c][0], acc[0][c][1], acc[0][c][2], acc[0][c][3]));
+                store_out4(out + o, epi_apply4(e, ec, acc[0][c], img, cabs, pix));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COB; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0][c][j] = acc[1][c][j]; acc[1][c][j] = acc[2][c][j]; acc[2][c][j] = 0.f; }
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci) cur[ci] = nxt[ci];
+    }
+}
+
+// Returns MSPL_OK when launched, 1 when the shape is left to the LDS-tiled kernel.
+static int gconv3x3_stream_try(const float* x, const float* w, const C3Geom& g3, const Epi& e, float* out, hipStream_t s) {
+    static const int off = getenv("MSPL_GC3S") ? atoi(getenv("MSPL_GC3S")) == 0 : 0;
+    auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+    if (off || (g3.W & 3) != 0 || g3.W < 16 || g3.W > 256 || g3.H < 4) return 1;
+    if (!(al16(x) && al16(out) && al16(e.pre_add) && al16(e.residual) && al16(e.reinf_r) && al16(e.raw))) return 1;
+    if ((int64_t)g3.N * g3.Cin * g3.H * g3.W >= (1ll << 31) || (int64_t)g3.N * e.ctot * g3.H * g3.W >= (1ll << 31)) return 1;
+    GcsGeom g;
+    g.N = g3.N; g.Cin = g3.Cin; g.Cout = g3.Cout; g.G = g3.G; g.H = g3.H; g.W = g3.W; g.sg = g3.sg;
+    g.LPR = g.W / 4;
+    g.SUB = 64 / g.LPR;
+    // rows per unit: enough waves for >= 2 per SIMD when the map allows; each unit reads 2 halo rows
+    int seg = std::min(g.H, 24);
+    while (seg > 6 && (int64_t)g.G * ceil_div64((int64_t)g.N * ceil_div(g.H, seg), g.SUB) < 2048) --seg;
+    seg = ceil_div(g.H, ceil_div(g.H, seg));
+    g.SEG = seg;
+    g.nseg = ceil_div(g.H, seg);
+    g.upg = g.N * g.nseg;
+    g.wpg = ceil_div(g.upg, g.SUB);
+    const int64_t waves = (int64_t)g.G * g.wpg;
+    if (waves >= (1ll << 31)) return 1;
+    g.total = (unsigned)waves;
+    const dim3 grid((unsigned)ceil_div64(waves, 4)), blk(256);
+#define MSPL_GCS(A, B) hipLaunchKernelGGL((gconv3x3_stream_kernel<A, B>), grid, blk, 0, s, x, w, g, e, out)
+    // measured (tools/c3_probe.py, batch 16): 256 -> 64 in 64 groups at 36x60: 24.5 -> 16.0 us.  NOT used for 8 -> 3 per group (128 -> 48
+    // at 72x120: 63 us against 41 us tiled: 237 VGPRs, two waves per SIMD, the 864 FMAs per row and lane are not hidden) nor for
+    // ungrouped 3 -> 3 (one group = too few waves: 18.8 against 6.0 us); those stay with the LDS-tiled kernel.
+    if (g3.G < 16) return 1;
+    if (g3.cin_g == 4 && g3.cout_g == 1) MSPL_GCS(4, 1);
+    else if (g3.cin_g == 1 && g3.cout_g == 4) MSPL_GCS(1, 4);
+    else return 1;
+#undef MSPL_GCS
+    MSPL_CHECK_LAUNCH("conv3x3(grouped, streaming)");
+    return MSPL_OK;
+}
+
 template <int STRIDE>
 static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float* out, hipStream_t s) {
     int cob = 1;
@@ -375,5 +521,9 @@ extern "C" int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32
     hipStream_t s = (hipStream_t)stream;
     static const int no_dws = getenv("MSPL_DWS") ? atoi(getenv("MSPL_DWS")) == 0 : 0;       // tuning aid: 0 = LDS-tiled form only
     if (stride == 1 && !no_dws && dwconv3x3_stream_ok(g, x, out, e)) return launch_dws(x, w, g, e, out, s);
+    if (stride == 1) {
+        const int rc = gconv3x3_stream_try(x, w, g, e, out, s);
+        if (rc <= 0) return rc;
+    }
     return stride == 1 ? launch3<1>(x, w, g, e, out, s) : launch3<2>(x, w, g, e, out, s);
 }

@@ -99,7 +99,12 @@ def test_conv1x1_epilogues(cfg):
     (1, 128, 48, 16, 12, 20, 1, 0), (1, 256, 64, 64, 8, 15, 1, 0), (1, 4, 4, 4, 256, 480, 1, 0), (1, 3, 32, 1, 31, 45, 2, 0),
     (1, 20, 4, 4, 5, 5, 1, 5),
     # depthwise maps wide enough for the register-streaming form: odd height, exactly one column block, a 4-column second block
-    (2, 6, 6, 6, 37, 64, 1, 0), (1, 5, 5, 5, 9, 248, 1, 0), (1, 2, 2, 2, 40, 252, 1, 0)])
+    (2, 6, 6, 6, 37, 64, 1, 0), (1, 5, 5, 5, 9, 248, 1, 0), (1, 2, 2, 2, 40, 252, 1, 0),
+    # grouped shapes around the streaming form (row length % 4 == 0, >= 16 groups, (cin, cout) per group (4,1) or (1,4)): several
+    # units per wave, a partly filled last wave, Shuffle-aware input channels; the other group shapes stay on the LDS-tiled kernel
+    (2, 128, 48, 16, 24, 120, 1, 0), (1, 256, 64, 64, 12, 60, 1, 0), (2, 3, 3, 1, 18, 32, 1, 0), (1, 48, 128, 16, 10, 40, 1, 0),
+    (1, 64, 256, 64, 9, 28, 1, 0), (1, 80, 30, 10, 16, 32, 1, 5), (3, 8, 3, 1, 29, 256, 1, 0), (1, 3, 3, 1, 50, 16, 1, 0),
+    (3, 64, 16, 16, 29, 256, 1, 0), (2, 80, 20, 20, 16, 32, 1, 5), (1, 32, 128, 32, 7, 20, 1, 0)])
 def test_conv3x3(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
