@@ -267,7 +267,7 @@ def test_micro_batch_lanes_equal_one_graph(lanes):
     one = training.GraphedTrainStep(nets[0], x, y, cw, ignore_idx=4)
     many = training.GraphedTrainStep(nets[1], x, y, cw, ignore_idx=4, lanes=lanes)
     assert many.lanes == lanes and len(many.lane_graphs) == lanes
-    np.testing.assert_allclose(many.optimizer.flat_g.cpu().numpy(), one.optimizer.flat_g.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(many.optimizer.flat_g.cpu().numpy(), one.optimizer.flat_g.cpu().numpy(), rtol=1e-4, atol=1e-4)
     l1 = [float(one(x, y)) for _ in range(2)]
     l2 = [float(many(x, y)) for _ in range(2)]
     np.testing.assert_allclose(l2, l1, rtol=2e-4, atol=1e-6)
