@@ -100,6 +100,17 @@ int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int
                      int32_t groups, int32_t H, int32_t W, int32_t stride, int32_t shuffle_groups,
                      const mspl_epilogue_t* ep, float* out, void* stream);
 
+/* K1 + K2 in one launch for stride-1 EESP blocks whose planes fit LDS (nn_layers/eesp.py:60-80: proj_1x1 = grouped 1x1 + BN + PReLU,
+ * then the four dilated depthwise 3x3 + HFF + cat + br_after_cat).  x (N,Cin,H,W); wp (n, Cin/groups): the projection's weights;
+ * pscale/pshift/palpha (n): its folded BatchNorm and PReLU (NULL = identity); w (4,n,3,3), dil, ep, out (N,4n,H,W): as
+ * mspl_eesp_dw_hff_fwd with stride 1.  Covered: Cin/groups in {64,128}, n/groups a multiple of 16, H*W % 4 == 0, W even, W,H <= 64,
+ * dilations {1,1,2,3} or {1,2,3,4}; mspl_eesp_proj_dw_hff_fits() returns 1 for covered shapes (callers run
+ * mspl_conv1x1_fwd + mspl_eesp_dw_hff_fwd otherwise; _fwd returns MSPL_ERR_UNSUPPORTED). */
+int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]);
+int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* pscale, const float* pshift, const float* palpha,
+                              const float* w, const int32_t dil[4], int32_t N, int32_t Cin, int32_t n, int32_t groups,
+                              int32_t H, int32_t W, const mspl_epilogue_t* ep, float* out, void* stream);
+
 /* AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) + epilogue.
  *     Replaces nn_layers/eesp.py:115,128 and the image pyramid of :136-140.
  */

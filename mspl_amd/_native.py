@@ -35,6 +35,8 @@ _EP = ctypes.POINTER(Epilogue)
 SIGNATURES = {
     'mspl_eesp_dw_hff_fwd': [c_f32p, c_f32p, ctypes.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_i32, _EP,
                              c_f32p, ctypes.c_void_p],
+    'mspl_eesp_proj_dw_hff_fits': [c_i32] * 6 + [ctypes.POINTER(c_i32)],
+    'mspl_eesp_proj_dw_hff_fwd': [c_f32p] * 6 + [ctypes.POINTER(c_i32)] + [c_i32] * 6 + [_EP, c_f32p, ctypes.c_void_p],
     'mspl_conv1x1_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_conv3x3_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
                          ctypes.c_void_p],

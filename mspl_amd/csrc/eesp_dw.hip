@@ -31,6 +31,8 @@
 
 #include "common.hpp"
 
+#define COMMA ,
+
 namespace mspl {
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -88,6 +90,145 @@ __device__ __forceinline__ void dw_window(const float* __restrict__ p, float (&v
     }
 }
 
+struct DwItemCtx {
+    int CP, rows_here, XS, PS, RS, Wo, hw, y0, wt;
+    unsigned mag_xs;
+    bool o16, o8, has_act;
+    size_t kstride;
+    char* ob;                       // first output plane of the tile (branch 0)
+    float* out;                     // destination tensor (base of the write-through descriptor)
+    __amdgpu_buffer_rsrc_t orsrc;
+};
+
+// The arithmetic of a tile that sits in LDS (shared by the tiled kernel and the fused projection + K2 kernel, eesp_front.hip).
+template <int STRIDE, class DS>
+__device__ __forceinline__ void dw_compute_items(const float* __restrict__ tile, const float* __restrict__ wl, const float* __restrict__ el,
+                                                 const DwItemCtx& c, int tid, int nthr) {
+    constexpr int MAXD = DS::maxd();
+    constexpr bool ODD = STRIDE == 2 && DS::any_odd();
+        const int rows_here = c.rows_here;
+        const int items = c.CP * rows_here * c.XS;
+        char* ob = c.ob;
+        float* out = c.out;
+        const int hw = c.hw, PS = c.PS, y0 = c.y0;
+        const __amdgpu_buffer_rsrc_t orsrc = c.orsrc;
+        const bool o16 = c.o16, o8 = c.o8, has_act = c.has_act;
+        const size_t kstride = c.kstride;
+        const int OOFF = c.RS >> 1;
+        const unsigned mag_rows = ((1u << 20) + (unsigned)rows_here - 1) / (unsigned)rows_here;   // uniform
+        for (int it = tid; it < items; it += nthr) {
+            const int t2 = (int)(((unsigned)it * c.mag_xs) >> 20);
+            const int xs = it - t2 * c.XS;
+            const int p = (int)(((unsigned)t2 * mag_rows) >> 20);
+            const int ty = t2 - p * rows_here;
+            const float* lp = tile + (size_t)p * PS + (ty * STRIDE + MAXD) * c.RS + 4 * xs;   // centre row window (A / E array)
+            const float4* wp = reinterpret_cast<const float4*>(wl) + p * 12;
+            const float4* ep = reinterpret_cast<const float4*>(el) + p * 4;
+            const int xb = xs * 4;
+            // ONE 32-bit lane offset; the branch part of the address is uniform and goes in the scalar base
+            const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)(y0 + ty) * c.Wo + xb) * sizeof(float));
+            float cA[12], cO[12];
+            dw_window<0, 11>(lp, cA);
+            if (ODD) dw_window<2, 8>(lp + OOFF, cO);      // odd taps use indices 4 + j + {-2, -1, 0, 1}, j = 0..3
+            float prev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = DS::d(k);
+                if (k > 0 && DS::d(k - 1) == d) continue;       // evaluated together with the first branch of its run
+                int R = 1;
+#pragma unroll
+                for (int q = k + 1; q < 4; ++q) if (DS::d(q) == d && q == k + R) ++R;
+                float a[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[r][j] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    float rA[12], rO[12];
+                    if (ky == 1) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) { rA[i] = cA[i]; rO[i] = ODD ? cO[i] : 0.f; }
+                    } else {
+                        const float* row = lp + (ky - 1) * d * c.RS;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) rO[i] = 0.f;
+                        if (STRIDE == 1) {
+                            if (d == 1) dw_window<3, 8>(row, rA); else if (d == 2) dw_window<2, 9>(row, rA);
+                            else if (d == 3) dw_window<1, 10>(row, rA); else dw_window<0, 11>(row, rA);
+                        } else if (d & 1) {
+                            dw_window<4, 7>(row, rA);                                   // centre tap only
+                            if (d == 1) dw_window<3, 7>(row + OOFF, rO); else dw_window<2, 8>(row + OOFF, rO);
+                        } else {
+                            if (d == 2) dw_window<3, 8>(row, rA); else dw_window<2, 9>(row, rA);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r >= R) break;
+                        const float4 w4 = wp[(k + r) * 3 + ky];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float tm, tc, tp;                   // taps at input column offsets -d, 0, +d
+                            if (STRIDE == 1) { tm = rA[4 + j - d]; tc = rA[4 + j]; tp = rA[4 + j + d]; }
+                            else if (d & 1) { tm = rO[4 + j - (d + 1) / 2]; tc = rA[4 + j]; tp = rO[4 + j + (d - 1) / 2]; }
+                            else { tm = rA[4 + j - d / 2]; tc = rA[4 + j]; tp = rA[4 + j + d / 2]; }
+                            a[r][j] = fmaf(w4.x, tm, a[r][j]);
+                            a[r][j] = fmaf(w4.y, tc, a[r][j]);
+                            a[r][j] = fmaf(w4.z, tp, a[r][j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= R) break;
+                    const int kk = k + r;
+                    // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
+                    const float4 ec = ep[kk];
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[r][j] += prev[j];
+                        prev[j] = a[r][j];
+                        float q = fmaf(a[r][j], ec.x, ec.y);
+                        if (has_act) q = q > 0.f ? q : ec.z * q;
+                        v[j] = q;
+                    }
+                    float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
+                    if (o16 && c.wt) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
+                        __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);          // aux 16 = sc1
+                    } else if (o8 && c.wt) {
+                        // rows of an even number of floats: the strip starts 8-byte aligned; a 16-byte buffer store needs dword
+                        // alignment only.  The row's last strip may hold two pixels.
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
+                        if (xb + 2 < c.Wo) {
+                            const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);
+                        } else {
+                            const u32x2 d0 = {__float_as_uint(v[0]), __float_as_uint(v[1])};
+                            __builtin_amdgcn_raw_buffer_store_b64(d0, orsrc, boff, 0, 16);
+                        }
+                    } else if (o16) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (o8) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                        if (xb + 2 < c.Wo) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (xb + j < c.Wo) dst[j] = v[j];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one dilation at a time (keeps the register footprint small)
+            }
+        }
+}
+
 // PERSIST: a workgroup walks tiles b, b + G, ... with the next tile's rows prefetched into registers (many tiles per
 // workgroup, 3 workgroups per CU); otherwise one tile per workgroup (the staging registers die before the arithmetic starts:
 // 4-5 workgroups per CU, which is what hides latency when a launch is a single round of small tiles).
@@ -96,7 +237,6 @@ __global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw
                                                              const float* __restrict__ w,
                                                              DwGeom g, Epi e, float* __restrict__ out) {
     constexpr int MAXD = DS::maxd();
-    constexpr bool ODD = STRIDE == 2 && DS::any_odd();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int PS = g.RIN * g.RS;                          // floats per staged plane
     float* tile = smem;                                   // CP * PS (+16 floats of tail pad)
@@ -213,120 +353,13 @@ __global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw
         if (PERSIST && t + (int)gridDim.x < g.ntiles) issue_loads(t + gridDim.x);     // next tile's rows fly during this tile's arithmetic
 
         // ---- compute: item = (plane p, band row ty, strip xs); xs fastest so that lanes are 16 bytes apart
-        const int rows_here = min(g.TH, g.Ho - y0);
-        const int items = g.CP * rows_here * g.XS;
-        char* ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
-        const unsigned mag_rows = ((1u << 20) + (unsigned)rows_here - 1) / (unsigned)rows_here;   // uniform
-        for (int it = tid; it < items; it += nthr) {
-            const int t2 = (int)(((unsigned)it * g.mag_xs) >> 20);
-            const int xs = it - t2 * g.XS;
-            const int p = (int)(((unsigned)t2 * mag_rows) >> 20);
-            const int ty = t2 - p * rows_here;
-            const float* lp = tile + (size_t)p * PS + (ty * STRIDE + MAXD) * g.RS + 4 * xs;   // centre row window (A / E array)
-            const float4* wp = reinterpret_cast<const float4*>(wl) + p * 12;
-            const float4* ep = reinterpret_cast<const float4*>(el) + p * 4;
-            const int xb = xs * 4;
-            // ONE 32-bit lane offset; the branch part of the address is uniform and goes in the scalar base
-            const unsigned voff = (unsigned)((((size_t)p * hw) + (size_t)(y0 + ty) * g.Wo + xb) * sizeof(float));
-            float cA[12], cO[12];
-            dw_window<0, 11>(lp, cA);
-            if (ODD) dw_window<2, 8>(lp + OOFF, cO);      // odd taps use indices 4 + j + {-2, -1, 0, 1}, j = 0..3
-            float prev[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int d = DS::d(k);
-                if (k > 0 && DS::d(k - 1) == d) continue;       // evaluated together with the first branch of its run
-                int R = 1;
-#pragma unroll
-                for (int q = k + 1; q < 4; ++q) if (DS::d(q) == d && q == k + R) ++R;
-                float a[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[r][j] = 0.f;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    float rA[12], rO[12];
-                    if (ky == 1) {
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) { rA[i] = cA[i]; rO[i] = ODD ? cO[i] : 0.f; }
-                    } else {
-                        const float* row = lp + (ky - 1) * d * g.RS;
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) rO[i] = 0.f;
-                        if (STRIDE == 1) {
-                            if (d == 1) dw_window<3, 8>(row, rA); else if (d == 2) dw_window<2, 9>(row, rA);
-                            else if (d == 3) dw_window<1, 10>(row, rA); else dw_window<0, 11>(row, rA);
-                        } else if (d & 1) {
-                            dw_window<4, 7>(row, rA);                                   // centre tap only
-                            if (d == 1) dw_window<3, 7>(row + OOFF, rO); else dw_window<2, 8>(row + OOFF, rO);
-                        } else {
-                            if (d == 2) dw_window<3, 8>(row, rA); else dw_window<2, 9>(row, rA);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r >= R) break;
-                        const float4 w4 = wp[(k + r) * 3 + ky];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float tm, tc, tp;                   // taps at input column offsets -d, 0, +d
-                            if (STRIDE == 1) { tm = rA[4 + j - d]; tc = rA[4 + j]; tp = rA[4 + j + d]; }
-                            else if (d & 1) { tm = rO[4 + j - (d + 1) / 2]; tc = rA[4 + j]; tp = rO[4 + j + (d - 1) / 2]; }
-                            else { tm = rA[4 + j - d / 2]; tc = rA[4 + j]; tp = rA[4 + j + d / 2]; }
-                            a[r][j] = fmaf(w4.x, tm, a[r][j]);
-                            a[r][j] = fmaf(w4.y, tc, a[r][j]);
-                            a[r][j] = fmaf(w4.z, tp, a[r][j]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (r >= R) break;
-                    const int kk = k + r;
-                    // hierarchical feature fusion: out_k = conv_k + out_{k-1}   (nn_layers/eesp.py:72-76)
-                    const float4 ec = ep[kk];
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[r][j] += prev[j];
-                        prev[j] = a[r][j];
-                        float q = fmaf(a[r][j], ec.x, ec.y);
-                        if (has_act) q = q > 0.f ? q : ec.z * q;
-                        v[j] = q;
-                    }
-                    float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
-                    if (o16 && g.wt) {
-                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
-                        __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);          // aux 16 = sc1
-                    } else if (o8 && g.wt) {
-                        // rows of an even number of floats: the strip starts 8-byte aligned; a 16-byte buffer store needs dword
-                        // alignment only.  The row's last strip may hold two pixels.
-                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                        const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
-                        if (xb + 2 < g.Wo) {
-                            const u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                            __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, boff, 0, 16);
-                        } else {
-                            const u32x2 d0 = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-                            __builtin_amdgcn_raw_buffer_store_b64(d0, orsrc, boff, 0, 16);
-                        }
-                    } else if (o16) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if (o8) {
-                        *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                        if (xb + 2 < g.Wo) *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (xb + j < g.Wo) dst[j] = v[j];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one dilation at a time (keeps the register footprint small)
-            }
+        {
+            DwItemCtx cx;
+            cx.CP = g.CP; cx.rows_here = min(g.TH, g.Ho - y0); cx.XS = g.XS; cx.PS = PS; cx.RS = g.RS; cx.Wo = g.Wo; cx.hw = hw;
+            cx.y0 = y0; cx.mag_xs = g.mag_xs; cx.wt = g.wt; cx.o16 = o16; cx.o8 = o8; cx.has_act = has_act; cx.kstride = kstride;
+            cx.ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
+            cx.out = out; cx.orsrc = orsrc;
+            dw_compute_items<STRIDE, DS>(tile, wl, el, cx, tid, nthr);
         }
         if (PERSIST) __syncthreads();                  // every wave is done reading the tile before the next one is written
     }
@@ -724,9 +757,251 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
     return MSPL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1 + K2 in one launch for the stride-1 EESP blocks whose planes fit LDS (level 4: 16x30 / 18x30).  The reduced tensor never goes
+// to memory: a workgroup owns one image and 16 consecutive projection channels (half a group of the grouped 1x1), computes them
+// for the WHOLE plane on the matrix cores (v_mfma_f32_16x16x4_f32: 16 rows x 16 pixels x 4 k per instruction; a lane's float4 of x
+// feeds four of them, A = the 16 x K weight slab preloaded into K / 4 registers), applies the projection's folded BN + PReLU and
+// writes the values into the same zero-haloed LDS tile the tiled kernel stages from global memory; after one barrier the tile is
+// handed to the tiled kernel's arithmetic (dw_compute_items).  Removes one launch, the reduced tensor's write and read, and the
+// global -> LDS staging phase per block.  nn_layers/eesp.py:60-80.
+typedef float fr_f4 __attribute__((ext_vector_type(4)));
+
+struct FrGeom {
+    int N, Cin, n, G, K, M, H, W, HW;
+    int RS, RIN, PS, XS;
+    unsigned mag_w, mag_xs;
+    int TH, bands;            // output rows per band, bands per plane (a band re-computes MAXD halo rows of the projection on each side)
+    int wt;
+    int stop;                 // tuning aid (MSPL_FRONT_STOP): return after phase k
+};
+
+template <class DS, int KQ>   // KQ = K / 4 MFMA steps
+__global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ pscale, const float* __restrict__ pshift,
+                                                           const float* __restrict__ palpha, const float* __restrict__ w,
+                                                           FrGeom g, Epi e, float* __restrict__ out) {
+    constexpr int MAXD = DS::maxd();
+    constexpr int RING = KQ;                               // ALL k-steps of a tile's B in flight per wave (KQ float4 registers): the loads are the latency to hide
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                   // 16 planes * PS (+16 floats of tail pad)
+    float* wl = smem + 16 * g.PS + 16;                    // [16][branch*3 + ky][4]
+    float* el = wl + 16 * 48;                             // [16][branch][4]
+    if (g.stop == 3) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
+    const int slabs = g.n >> 4;
+    int bid = blockIdx.x;
+    const int band = bid % g.bands;  bid /= g.bands;
+    const int img = bid / slabs, slab = bid - img * slabs;
+    const int c0 = slab * 16;                             // first projection channel of the workgroup
+    const int grp = c0 / g.M;                             // its group of the grouped 1x1
+    const int kq = lane >> 4, nl = lane & 15;
+    // rows of this band: outputs [r0, r1); the projection is needed on [q0, q1) = [r0 - MAXD, r1 + MAXD) inside the image; tile row 0
+    // is image row r0 - MAXD (rows outside the image stay zero)
+    const int r0 = band * g.TH, r1 = min(r0 + g.TH, g.H);
+    const int q0 = max(r0 - MAXD, 0), q1 = min(r1 + MAXD, g.H);
+    const int pbeg = q0 * g.W, pend = q1 * g.W;           // pixel span of the projection (rows are contiguous)
+    const int pb4 = pbeg & ~3;                             // tiles start 16-byte aligned (HW % 4 == 0: a lane's float4 never leaves the plane)
+    const int ntiles = (pend - pb4 + 63) >> 6;
+
+    // ---- every global load of the prologue goes out first, in one batch (they return in order: a wait in between would stack
+    // their latencies): the first tile's B ring, the K2 constants, the A operand, the projection's epilogue constants
+    const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.K + kq) * g.HW;
+    const size_t kstep = (size_t)4 * g.HW;                 // floats between MFMA steps
+    auto tile_base = [&](int t, bool& pok, int& p4) {
+        p4 = pb4 + t * 64 + 4 * nl;
+        pok = t < ntiles && p4 < pend;                     // (a lane's 4 pixels may straddle pbeg / pend: masked below)
+        return xg + (pok ? p4 : pb4);
+    };
+    int t = wave, p4 = 0;
+    bool pok = false;
+    const float* xb = tile_base(t, pok, p4);
+    float4 b[RING];
+#pragma unroll
+    for (int r = 0; r < RING; ++r) b[r] = *reinterpret_cast<const float4*>(xb + r * kstep);
+    float wreg[3], ereg = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = tid + u * nthr;
+        wreg[u] = 0.f;
+        if (i < 16 * 48) {
+            const int p = i / 48, r = i - p * 48, kqq = r >> 2, kx = r & 3, k = kqq / 3, ky = kqq - 3 * k;
+            if (kx < 3) wreg[u] = w[((size_t)k * g.n + (c0 + p)) * 9 + ky * 3 + kx];
+        }
+    }
+    if (tid < 256) {
+        const int p = tid >> 4, r = tid & 15, k = r >> 2, f = r & 3;
+        const int cabs = e.coff + k * g.n + c0 + p;
+        const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
+        ereg = f == 3 ? 0.f : (src ? src[cabs] : (f == 1 ? 0.f : 1.f));
+    }
+    // A: the 16 x K weight slab, loaded coalesced (one float4 per thread) and handed to the lanes through LDS (row stride K + 4:
+    // lane (m = nl, k = 4 st + kq) reads bank 4 nl + kq, conflict-free).  Per-lane strided global loads of it cost 8 us here:
+    // 16 cache lines per load instruction, 32 instructions per wave.
+    float* At = el + 16 * 16;                              // [16][K + 4]
+    const int AS = g.K + 4;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int a_row = tid / (g.K >> 2), a_c4 = tid - a_row * (g.K >> 2);
+    if (a_row < 16) a4 = *reinterpret_cast<const float4*>(wp + ((size_t)(c0 + a_row)) * g.K + 4 * a_c4);
+    float psc[4], psh[4], pal[4];                          // projection epilogue of the lane's rows 4 kq + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = c0 + 4 * kq + i;
+        psc[i] = pscale ? pscale[ch] : 1.f;  psh[i] = pshift ? pshift[ch] : 0.f;  pal[i] = palpha ? palpha[ch] : 1.f;
+    }
+    const bool pact = palpha != nullptr;
+    // ---- zero the tile (halo rows / columns stay zero) while the loads fly, then the K2 constants
+    {
+        const int tot4 = (16 * g.PS + 16) >> 2;
+        for (int i = tid; i < tot4; i += nthr) *reinterpret_cast<float4*>(tile + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (tid + u * nthr < 16 * 48) wl[tid + u * nthr] = wreg[u];
+        if (tid < 256) el[tid] = ereg;
+        if (a_row < 16) *reinterpret_cast<float4*>(At + a_row * AS + 4 * a_c4) = a4;
+    }
+    __syncthreads();                                       // zero fill complete before the projection writes
+    if (g.stop == 1) return;
+    const float* ar = At + nl * AS + kq;
+
+    // ---- projection: wave v handles 64-pixel tiles v, v + nwaves, ... of the span; the ring runs across tiles (the last RING steps
+    // of a tile refill with the first steps of the wave's next tile)
+    for (; t < ntiles; t += nwaves) {
+        bool pokn;  int p4n;
+        const float* xbn = tile_base(t + nwaves, pokn, p4n);
+        fr_f4 acc[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc[s2] = (fr_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < KQ; ++st) {
+            const float4 bv = b[st % RING];
+            const float av = ar[4 * st];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[3], 0, 0, 0);
+            if (st + RING < KQ) b[st % RING] = *reinterpret_cast<const float4*>(xb + (size_t)(st + RING) * kstep);
+            else b[st % RING] = *reinterpret_cast<const float4*>(xbn + (size_t)(st + RING - KQ) * kstep);
+            __builtin_amdgcn_sched_barrier(0);             // keeps the refills where they are (ring really in flight)
+        }
+        if (pok) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int p = p4 + s2;
+                if (p < pbeg || p >= pend) continue;
+                const int y = (int)(((unsigned)p * g.mag_w) >> 20), xx = p - y * g.W;
+                float* d = tile + (size_t)(4 * kq) * g.PS + (y - r0 + MAXD) * g.RS + 4 + xx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = fmaf(acc[s2][i], psc[i], psh[i]);
+                    if (pact) v = v > 0.f ? v : pal[i] * v;
+                    d[(size_t)i * g.PS] = v;
+                }
+            }
+        }
+        xb = xbn;  pok = pokn;  p4 = p4n;
+    }
+    if (g.stop == 2) return;
+    __syncthreads();
+
+    // ---- K2 on the tile
+    const int hw = g.HW;
+    DwItemCtx cx;
+    cx.CP = 16; cx.rows_here = r1 - r0; cx.XS = g.XS; cx.PS = g.PS; cx.RS = g.RS; cx.Wo = g.W; cx.hw = hw; cx.y0 = r0;
+    cx.mag_xs = g.mag_xs; cx.wt = g.wt; cx.o16 = (g.W & 3) == 0; cx.o8 = (g.W & 1) == 0; cx.has_act = e.alpha != nullptr;
+    cx.kstride = (size_t)g.n * hw * sizeof(float);
+    cx.ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
+    cx.out = out;
+    cx.orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)g.N * e.ctot * hw * sizeof(float)), 0x00020000);
+    dw_compute_items<1, DS>(tile, wl, el, cx, tid, nthr);
+}
+
 }  // namespace mspl
 
 using namespace mspl;
+
+// x (N,Cin,H,W); wp: the grouped projection's weights (n, Cin/groups); pscale/pshift/palpha (n): its folded BN + PReLU;
+// w (4,n,3,3) + dil + ep: as mspl_eesp_dw_hff_fwd (stride 1).  Returns MSPL_ERR_UNSUPPORTED for shapes the fused form does not
+// cover (the caller then runs mspl_conv1x1_fwd + mspl_eesp_dw_hff_fwd); mspl_eesp_proj_dw_hff_fits() asks beforehand.
+static int eesp_proj_dw_plan(int N, int Cin, int n, int groups, int H, int W, const int32_t* dil, FrGeom& g, size_t& lds) {
+    if (N < 1 || groups < 1 || Cin % groups || n % groups || (n & 15)) return 0;
+    const int K = Cin / groups, M = n / groups;
+    if (!(K == 64 || K == 128) || (M & 15)) return 0;
+    if ((H * W) & 3 || (W & 1) || W > 64 || H > 64) return 0;
+    const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
+    if (key != 1123 && key != 1234) return 0;
+    const int maxd = key == 1123 ? 3 : 4;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Cin = Cin; g.n = n; g.G = groups; g.K = K; g.M = M; g.H = H; g.W = W; g.HW = H * W;
+    g.XS = ceil_div(W, 4);
+    g.RS = 4 * g.XS + 8;                                   // 4 zero columns + the row + zero fill for the right-hand taps
+    // bands: enough workgroups for every CU (a launch of 16 images x 8 slabs is 128 workgroups); every band re-computes up to
+    // 2 * maxd projection rows
+    static const int dbg_bands = getenv("MSPL_FRONT_BANDS") ? atoi(getenv("MSPL_FRONT_BANDS")) : 0;
+    g.mag_w = magic20(W); g.mag_xs = magic20(g.XS);
+    const int max_bands = 3;                               // (more bands = more of the projection re-computed in the halos than computed once)
+    for (int bands = 1; bands <= max_bands; ++bands) {
+        if (dbg_bands >= 1 && dbg_bands <= max_bands && bands != dbg_bands) continue;
+        g.TH = ceil_div(H, bands);
+        g.bands = ceil_div(H, g.TH);
+        g.RIN = g.TH + 2 * maxd;
+        g.PS = g.RIN * g.RS;
+        lds = ((size_t)16 * g.PS + 16 + 16 * 64 + 16 * (K + 4)) * sizeof(float);
+        const bool enough = (int64_t)N * (n / 16) * g.bands >= 256 || g.TH < 2 * maxd + 2 || bands >= 3;
+        if (lds <= 80 * 1024 && (enough || dbg_bands)) break;
+        if (bands == max_bands) return 0;
+    }
+    if (lds > 80 * 1024) return 0;
+    if (g.HW >= 4096 || 16 * g.TH * g.XS >= 4096 || !magic_exact(g.mag_w, W, g.HW + 64) || !magic_exact(g.mag_xs, g.XS, 16 * g.TH * g.XS)) return 0;
+    for (int rh = 1; rh <= g.TH; ++rh)
+        if (!magic_exact(magic20(rh), rh, 16 * rh)) return 0;
+    return 1;
+}
+
+extern "C" int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]) {
+    static const int off = getenv("MSPL_EESP_FRONT") ? atoi(getenv("MSPL_EESP_FRONT")) == 0 : 0;
+    if (off || !dil) return 0;
+    FrGeom g; size_t lds;
+    return eesp_proj_dw_plan(N, Cin, n, groups, H, W, dil, g, lds);
+}
+
+extern "C" int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* pscale, const float* pshift, const float* palpha,
+                                         const float* w, const int32_t dil[4], int32_t N, int32_t Cin, int32_t n, int32_t groups,
+                                         int32_t H, int32_t W, const mspl_epilogue_t* ep, float* out, void* stream) {
+    MSPL_REQUIRE(x && wp && w && dil && out, MSPL_ERR_NULL_POINTER, "eesp_proj_dw_hff: null pointer");
+    FrGeom g; size_t lds = 0;
+    MSPL_REQUIRE(eesp_proj_dw_plan(N, Cin, n, groups, H, W, dil, g, lds), MSPL_ERR_UNSUPPORTED,
+                 "eesp_proj_dw_hff: shape N=%d Cin=%d n=%d groups=%d %dx%d is not covered by the fused form", N, Cin, n, groups, H, W);
+    if (int rc = check_epi(ep, 4 * n, "eesp_proj_dw_hff")) return rc;
+    MSPL_REQUIRE(!ep || (!ep->pre_add && !ep->residual && !ep->reinf_r && !ep->gate), MSPL_ERR_UNSUPPORTED,
+                 "eesp_proj_dw_hff: only scale/shift/alpha epilogue terms are supported (br_after_cat)");
+    MSPL_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 15) == 0, MSPL_ERR_UNSUPPORTED, "eesp_proj_dw_hff: unaligned tensors");
+    const Epi e = make_epi(ep, 4 * n, H * W);
+    MSPL_REQUIRE((size_t)N * e.ctot * H * W * sizeof(float) < (1ull << 31), MSPL_ERR_UNSUPPORTED, "eesp_proj_dw_hff: output too large");
+    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    g.wt = dbg_wt;
+    static const int dbg_stop = getenv("MSPL_FRONT_STOP") ? atoi(getenv("MSPL_FRONT_STOP")) : 0;
+    g.stop = dbg_stop;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(N * (n / 16) * g.bands)), blk(512);      // (512 threads: one float4 of the 16 x 128 weight slab each)
+    const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
+    static bool attr_done = false;     // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 1, 2, 3>, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 1, 2, 3>, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 2, 3, 4>, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 2, 3, 4>, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+#define MSPL_FR(DSX, KQX) hipLaunchKernelGGL((eesp_proj_dw_kernel<DSX, KQX>), grid, blk, lds, s, x, wp, pscale, pshift, palpha, w, g, e, out)
+    if (key == 1123) { if (g.K == 128) MSPL_FR(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32); else MSPL_FR(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16); }
+    else { if (g.K == 128) MSPL_FR(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32); else MSPL_FR(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16); }
+#undef MSPL_FR
+    MSPL_CHECK_LAUNCH("eesp_proj_dw_hff");
+    return MSPL_OK;
+}
 
 extern "C" int mspl_eesp_dw_hff_fwd(const float* x, const float* w, const int32_t dil[4], int32_t stride,
                                     int32_t N, int32_t n, int32_t H, int32_t W,

@@ -392,8 +392,14 @@ class EESP(nn.Module):
 
     def reduce_transform(self, input):
         """K1 + K2: returns the BN+PReLU'd concatenation that feeds conv_1x1_exp."""
-        o1 = self.proj_1x1(input)
         scale, shift = bn_fold(self.br_after_cat.bn)
+        pj = self.proj_1x1
+        if ops.eesp_proj_dw_hff_fits(input.shape, pj.conv.out_channels, pj.conv.groups, self.dilations, self.stride):
+            # level 4 (planes that fit LDS): projection on the matrix cores straight into K2's LDS tile, one launch
+            ps, pb = bn_fold(pj.bn)
+            return ops.eesp_proj_dw_hff(input, pj.conv.weight, ps, pb, pj.act.weight, self._dw_weights(), self.dilations,
+                                        pj.conv.groups, Epi(scale, shift, self.br_after_cat.act.weight))
+        o1 = pj(input)
         return ops.eesp_dw_hff(o1, self._dw_weights(), self.dilations, self.stride,
                                Epi(scale, shift, self.br_after_cat.act.weight))
 

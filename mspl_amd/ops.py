@@ -114,6 +114,31 @@ def eesp_dw_hff(x, w4, dil, stride, ep=None, out=None):
     return dst
 
 
+def eesp_proj_dw_hff_fits(shape, n, groups, dilations, stride):
+    """True when K1 + K2 of an EESP block run as one launch for an input of `shape` (N,Cin,H,W)."""
+    if stride != 1:
+        return False
+    N, Cin, H, W = [int(v) for v in shape]
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
+    return bool(lib.mspl_eesp_proj_dw_hff_fits(N, Cin, int(n), int(groups), H, W, d))
+
+
+def eesp_proj_dw_hff(x, wproj, pscale, pshift, palpha, w4, dilations, groups, ep=None, out=None):
+    """K1 + K2 (stride 1): PReLU(BN(grouped 1x1(x))) -> four dilated depthwise 3x3 + HFF + cat + epilogue, one launch."""
+    x = _f32(x, 'x')
+    N, Cin, H, W = x.shape
+    wproj = _f32(wproj, 'projection weight')
+    n = wproj.shape[0]
+    w4 = _vec(w4, 4 * n * 9, 'w')
+    ps, pb, pa = _vec(pscale, n, 'pscale'), _vec(pshift, n, 'pshift'), _vec(palpha, n, 'palpha')
+    dst, coff = _dest(out, (N, 4 * n, H, W), x)
+    s, keep = _build(ep, dst, coff, N, 4 * n, H * W)
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
+    check(lib.mspl_eesp_proj_dw_hff_fwd(_p(x), _p(wproj), _p(ps), _p(pb), _p(pa), _p(w4), d, N, Cin, n, int(groups), H, W,
+                                        ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
 def conv1x1(x, w, groups=1, ep=None, out=None):
     """K1/K3.  x (N,Cin,H,W), w (Cout,Cin/groups[,1,1])."""
     x, w = _f32(x, 'x'), _f32(w, 'w')

@@ -40,6 +40,51 @@ def test_eesp_dw_hff(dil, stride, shape):
     close(raw, torch.cat(outs, 1))
 
 
+@pytest.mark.parametrize('cfg', [(2, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 128, 4, 16, 30, [1, 1, 2, 3]), (2, 256, 64, 4, 18, 30, [1, 2, 3, 4]),
+                                 (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4])])
+def test_eesp_proj_dw_hff(cfg):
+    """K1 + K2 in one launch (projection on the matrix cores straight into K2's LDS tile) against torch, and against the two
+    launches it replaces: the projection differs from the 32x32x2 kernel only in the last bits (k order inside an MFMA), K2's
+    arithmetic on it is the same code."""
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, Cin, n, G, H, W, dil = cfg
+    x = rnd(N, Cin, H, W, seed=1)
+    wp = rnd(n, Cin // G, 1, 1, seed=2, scale=0.1)
+    ps, pb, pa = rnd(n, seed=3).abs() + 0.5, rnd(n, seed=4) * 0.1, rnd(n, seed=5).abs() * 0.3
+    w = rnd(4, n, 3, 3, seed=6, scale=0.3)
+    scale, shift, alpha = rnd(4 * n, seed=7).abs() + 0.5, rnd(4 * n, seed=8) * 0.1, rnd(4 * n, seed=9).abs() * 0.3
+    o1 = F.prelu(F.conv2d(x, wp, None, 1, 0, 1, G) * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1), pa)
+    outs = []
+    for k in range(4):
+        o = F.conv2d(o1, w[k].unsqueeze(1), None, 1, dil[k], dil[k], n)
+        outs.append(o if k == 0 else o + outs[-1])
+    ref = F.prelu(torch.cat(outs, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha)
+    assert ops.eesp_proj_dw_hff_fits(x.shape, n, G, dil, 1)
+    d = lambda t: t.to(DEV)
+    ep = Epi(d(scale), d(shift), d(alpha))
+    got = ops.eesp_proj_dw_hff(d(x), d(wp), d(ps), d(pb), d(pa), d(w), dil, G, ep)
+    close(got, ref, atol=2e-4, rtol=2e-4)
+    two = ops.eesp_dw_hff(ops.conv1x1(d(x), d(wp), G, Epi(d(ps), d(pb), d(pa))), d(w), dil, 1, ep)
+    close(got, two.cpu(), atol=2e-5, rtol=1e-5)
+    # into a channel slice of a wider destination
+    wide = torch.zeros(N, 4 * n + 8, H, W, device=DEV)
+    ep2 = Epi(F.pad(d(scale), (8, 0)), F.pad(d(shift), (8, 0)), F.pad(d(alpha), (8, 0)))
+    ops.eesp_proj_dw_hff(d(x), d(wp), d(ps), d(pb), d(pa), d(w), dil, G, ep2, out=(wide, 8))
+    assert torch.equal(wide[:, 8:], got) and float(wide[:, :8].abs().sum()) == 0.0
+
+
+def test_eesp_proj_dw_hff_shapes_left_to_two_launches():
+    from mspl_amd import ops
+    assert not ops.eesp_proj_dw_hff_fits((16, 256, 36, 60), 64, 4, [1, 2, 3, 4], 1)       # 16 planes of 44 x 68 do not fit LDS
+    assert not ops.eesp_proj_dw_hff_fits((16, 512, 18, 30), 128, 4, [1, 1, 2, 3], 2)      # stride 2
+    assert not ops.eesp_proj_dw_hff_fits((16, 96, 18, 30), 24, 4, [1, 1, 2, 3], 1)        # K = 24 per group
+    assert not ops.eesp_proj_dw_hff_fits((1, 512, 18, 31), 128, 4, [1, 1, 2, 3], 1)       # odd row length
+    with pytest.raises(RuntimeError, match='not covered'):
+        ops.eesp_proj_dw_hff(torch.zeros(1, 256, 36, 60, device=DEV), torch.zeros(64, 64, 1, 1, device=DEV), None, None, None,
+                             torch.zeros(4, 64, 3, 3, device=DEV), [1, 2, 3, 4], 4)
+
+
 def test_eesp_dw_unsupported_dilation_raises():
     from mspl_amd import ops
     with pytest.raises(RuntimeError, match='unsupported dilation'):
