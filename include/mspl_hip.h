@@ -104,7 +104,8 @@ int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int
  * then the four dilated depthwise 3x3 + HFF + cat + br_after_cat).  x (N,Cin,H,W); wp (n, Cin/groups): the projection's weights;
  * pscale/pshift/palpha (n): its folded BatchNorm and PReLU (NULL = identity); w (4,n,3,3), dil, ep, out (N,4n,H,W): as
  * mspl_eesp_dw_hff_fwd with stride 1.  Covered: Cin/groups in {64,128}, n/groups a multiple of 16, H*W % 4 == 0, W even, W,H <= 64,
- * dilations {1,1,2,3} or {1,2,3,4}; mspl_eesp_proj_dw_hff_fits() returns 1 for covered shapes (callers run
+ * dilations {1,1,2,3} or {1,2,3,4}, M = n/groups in {16,32}; mspl_eesp_proj_dw_hff_fits() returns 1 for covered shapes outside
+ * throughput mode (mspl_set_throughput_mode: with several launches in flight the two-launch form measured faster) (callers run
  * mspl_conv1x1_fwd + mspl_eesp_dw_hff_fwd otherwise; _fwd returns MSPL_ERR_UNSUPPORTED). */
 int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]);
 int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* pscale, const float* pshift, const float* palpha,

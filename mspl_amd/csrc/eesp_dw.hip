@@ -777,25 +777,25 @@ struct FrGeom {
     int stop;                 // tuning aid (MSPL_FRONT_STOP): return after phase k
 };
 
-template <class DS, int KQ>   // KQ = K / 4 MFMA steps
+template <class DS, int KQ, int SL>   // KQ = K / 4 MFMA steps; SL = 16-row slabs of the group's projection rows (M = 16 SL)
 __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ pscale, const float* __restrict__ pshift,
                                                            const float* __restrict__ palpha, const float* __restrict__ w,
                                                            FrGeom g, Epi e, float* __restrict__ out) {
     constexpr int MAXD = DS::maxd();
     constexpr int RING = KQ;                               // ALL k-steps of a tile's B in flight per wave (KQ float4 registers): the loads are the latency to hide
+    constexpr int CP = 16 * SL;                            // planes of the workgroup = the group's projection channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                   // 16 planes * PS (+16 floats of tail pad)
-    float* wl = smem + 16 * g.PS + 16;                    // [16][branch*3 + ky][4]
-    float* el = wl + 16 * 48;                             // [16][branch][4]
+    float* tile = smem;                                   // CP planes * PS (+16 floats of tail pad)
+    float* wl = smem + CP * g.PS + 16;                    // [CP][branch*3 + ky][4]
+    float* el = wl + CP * 48;                             // [CP][branch][4]
+    float* At = el + CP * 16;                             // [CP][K + 4]
     if (g.stop == 3) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwaves = nthr >> 6;
-    const int slabs = g.n >> 4;
     int bid = blockIdx.x;
     const int band = bid % g.bands;  bid /= g.bands;
-    const int img = bid / slabs, slab = bid - img * slabs;
-    const int c0 = slab * 16;                             // first projection channel of the workgroup
-    const int grp = c0 / g.M;                             // its group of the grouped 1x1
+    const int img = bid / g.G, grp = bid - img * g.G;
+    const int c0 = grp * CP;                              // first projection channel of the workgroup (= of the group)
     const int kq = lane >> 4, nl = lane & 15;
     // rows of this band: outputs [r0, r1); the projection is needed on [q0, q1) = [r0 - MAXD, r1 + MAXD) inside the image; tile row 0
     // is image row r0 - MAXD (rows outside the image stay zero)
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restri
     const int ntiles = (pend - pb4 + 63) >> 6;
 
     // ---- every global load of the prologue goes out first, in one batch (they return in order: a wait in between would stack
-    // their latencies): the first tile's B ring, the K2 constants, the A operand, the projection's epilogue constants
+    // their latencies): the first tile's B (all k-steps), the K2 constants, the weight slab, the projection's epilogue constants
     const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.K + kq) * g.HW;
     const size_t kstep = (size_t)4 * g.HW;                 // floats between MFMA steps
     auto tile_base = [&](int t, bool& pok, int& p4) {
@@ -825,65 +825,78 @@ __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restri
     for (int u = 0; u < 3; ++u) {
         const int i = tid + u * nthr;
         wreg[u] = 0.f;
-        if (i < 16 * 48) {
+        if (i < CP * 48) {
             const int p = i / 48, r = i - p * 48, kqq = r >> 2, kx = r & 3, k = kqq / 3, ky = kqq - 3 * k;
             if (kx < 3) wreg[u] = w[((size_t)k * g.n + (c0 + p)) * 9 + ky * 3 + kx];
         }
     }
-    if (tid < 256) {
+    if (tid < CP * 16) {
         const int p = tid >> 4, r = tid & 15, k = r >> 2, f = r & 3;
         const int cabs = e.coff + k * g.n + c0 + p;
         const float* src = f == 0 ? e.scale : (f == 1 ? e.shift : e.alpha);
         ereg = f == 3 ? 0.f : (src ? src[cabs] : (f == 1 ? 0.f : 1.f));
     }
-    // A: the 16 x K weight slab, loaded coalesced (one float4 per thread) and handed to the lanes through LDS (row stride K + 4:
-    // lane (m = nl, k = 4 st + kq) reads bank 4 nl + kq, conflict-free).  Per-lane strided global loads of it cost 8 us here:
-    // 16 cache lines per load instruction, 32 instructions per wave.
-    float* At = el + 16 * 16;                              // [16][K + 4]
-    const int AS = g.K + 4;
-    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int a_row = tid / (g.K >> 2), a_c4 = tid - a_row * (g.K >> 2);
-    if (a_row < 16) a4 = *reinterpret_cast<const float4*>(wp + ((size_t)(c0 + a_row)) * g.K + 4 * a_c4);
-    float psc[4], psh[4], pal[4];                          // projection epilogue of the lane's rows 4 kq + i
+    // A: the CP x K weight slab, loaded coalesced (float4s) and handed to the lanes through LDS (row stride K + 4: lane (m = nl,
+    // k = 4 st + kq) reads bank 4 nl + kq, conflict-free).  Per-lane strided global loads of it cost 8 us here: 16 cache lines per
+    // load instruction, 32 instructions per wave.
+    const int AS = g.K + 4, kv = g.K >> 2;
+    float4 a4[SL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = c0 + 4 * kq + i;
-        psc[i] = pscale ? pscale[ch] : 1.f;  psh[i] = pshift ? pshift[ch] : 0.f;  pal[i] = palpha ? palpha[ch] : 1.f;
+    for (int u = 0; u < SL; ++u) {
+        const int i = tid + u * nthr, row = i / kv, c4 = i - row * kv;
+        a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < CP) a4[u] = *reinterpret_cast<const float4*>(wp + ((size_t)(c0 + row)) * g.K + 4 * c4);
     }
+    float psc[SL][4], psh[SL][4], pal[SL][4];              // projection epilogue of the lane's rows 16 s + 4 kq + i
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = c0 + 16 * sl + 4 * kq + i;
+            psc[sl][i] = pscale ? pscale[ch] : 1.f;  psh[sl][i] = pshift ? pshift[ch] : 0.f;  pal[sl][i] = palpha ? palpha[ch] : 1.f;
+        }
     const bool pact = palpha != nullptr;
-    // ---- zero the tile (halo rows / columns stay zero) while the loads fly, then the K2 constants
+    // ---- zero the tile (halo rows / columns stay zero) while the loads fly, then the constants
     {
-        const int tot4 = (16 * g.PS + 16) >> 2;
+        const int tot4 = (CP * g.PS + 16) >> 2;
         for (int i = tid; i < tot4; i += nthr) *reinterpret_cast<float4*>(tile + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < 3; ++u)
-            if (tid + u * nthr < 16 * 48) wl[tid + u * nthr] = wreg[u];
-        if (tid < 256) el[tid] = ereg;
-        if (a_row < 16) *reinterpret_cast<float4*>(At + a_row * AS + 4 * a_c4) = a4;
+            if (tid + u * nthr < CP * 48) wl[tid + u * nthr] = wreg[u];
+        if (tid < CP * 16) el[tid] = ereg;
+#pragma unroll
+        for (int u = 0; u < SL; ++u) {
+            const int i = tid + u * nthr, row = i / kv, c4 = i - row * kv;
+            if (row < CP) *reinterpret_cast<float4*>(At + row * AS + 4 * c4) = a4[u];
+        }
     }
     __syncthreads();                                       // zero fill complete before the projection writes
     if (g.stop == 1) return;
     const float* ar = At + nl * AS + kq;
 
-    // ---- projection: wave v handles 64-pixel tiles v, v + nwaves, ... of the span; the ring runs across tiles (the last RING steps
-    // of a tile refill with the first steps of the wave's next tile)
+    // ---- projection: wave v handles 64-pixel tiles v, v + nwaves, ... of the span; a tile's B registers are refilled with the
+    // wave's next tile as they are used
     for (; t < ntiles; t += nwaves) {
         bool pokn;  int p4n;
         const float* xbn = tile_base(t + nwaves, pokn, p4n);
-        fr_f4 acc[4];
+        fr_f4 acc[SL][4];
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc[s2] = (fr_f4){0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc[sl][s2] = (fr_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < KQ; ++st) {
-            const float4 bv = b[st % RING];
-            const float av = ar[4 * st];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[3], 0, 0, 0);
-            if (st + RING < KQ) b[st % RING] = *reinterpret_cast<const float4*>(xb + (size_t)(st + RING) * kstep);
-            else b[st % RING] = *reinterpret_cast<const float4*>(xbn + (size_t)(st + RING - KQ) * kstep);
-            __builtin_amdgcn_sched_barrier(0);             // keeps the refills where they are (ring really in flight)
+            const float4 bv = b[st];
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl) {
+                const float av = ar[sl * 16 * AS + 4 * st];
+                acc[sl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[sl][0], 0, 0, 0);
+                acc[sl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[sl][1], 0, 0, 0);
+                acc[sl][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[sl][2], 0, 0, 0);
+                acc[sl][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[sl][3], 0, 0, 0);
+            }
+            b[st] = *reinterpret_cast<const float4*>(xbn + (size_t)st * kstep);
+            __builtin_amdgcn_sched_barrier(0);             // keeps the refills where they are
         }
         if (pok) {
 #pragma unroll
@@ -891,12 +904,15 @@ __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restri
                 const int p = p4 + s2;
                 if (p < pbeg || p >= pend) continue;
                 const int y = (int)(((unsigned)p * g.mag_w) >> 20), xx = p - y * g.W;
-                float* d = tile + (size_t)(4 * kq) * g.PS + (y - r0 + MAXD) * g.RS + 4 + xx;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = fmaf(acc[s2][i], psc[i], psh[i]);
-                    if (pact) v = v > 0.f ? v : pal[i] * v;
-                    d[(size_t)i * g.PS] = v;
+                for (int sl = 0; sl < SL; ++sl) {
+                    float* d = tile + (size_t)(16 * sl + 4 * kq) * g.PS + (y - r0 + MAXD) * g.RS + 4 + xx;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = fmaf(acc[sl][s2][i], psc[sl][i], psh[sl][i]);
+                        if (pact) v = v > 0.f ? v : pal[sl][i] * v;
+                        d[(size_t)i * g.PS] = v;
+                    }
                 }
             }
         }
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restri
     // ---- K2 on the tile
     const int hw = g.HW;
     DwItemCtx cx;
-    cx.CP = 16; cx.rows_here = r1 - r0; cx.XS = g.XS; cx.PS = g.PS; cx.RS = g.RS; cx.Wo = g.W; cx.hw = hw; cx.y0 = r0;
+    cx.CP = CP; cx.rows_here = r1 - r0; cx.XS = g.XS; cx.PS = g.PS; cx.RS = g.RS; cx.Wo = g.W; cx.hw = hw; cx.y0 = r0;
     cx.mag_xs = g.mag_xs; cx.wt = g.wt; cx.o16 = (g.W & 3) == 0; cx.o8 = (g.W & 1) == 0; cx.has_act = e.alpha != nullptr;
     cx.kstride = (size_t)g.n * hw * sizeof(float);
     cx.ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
@@ -927,7 +943,7 @@ using namespace mspl;
 static int eesp_proj_dw_plan(int N, int Cin, int n, int groups, int H, int W, const int32_t* dil, FrGeom& g, size_t& lds) {
     if (N < 1 || groups < 1 || Cin % groups || n % groups || (n & 15)) return 0;
     const int K = Cin / groups, M = n / groups;
-    if (!(K == 64 || K == 128) || (M & 15)) return 0;
+    if (!(K == 64 || K == 128) || !(M == 16 || M == 32)) return 0;
     if ((H * W) & 3 || (W & 1) || W > 64 || H > 64) return 0;
     const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
     if (key != 1123 && key != 1234) return 0;
@@ -947,21 +963,25 @@ static int eesp_proj_dw_plan(int N, int Cin, int n, int groups, int H, int W, co
         g.bands = ceil_div(H, g.TH);
         g.RIN = g.TH + 2 * maxd;
         g.PS = g.RIN * g.RS;
-        lds = ((size_t)16 * g.PS + 16 + 16 * 64 + 16 * (K + 4)) * sizeof(float);
-        const bool enough = (int64_t)N * (n / 16) * g.bands >= 256 || g.TH < 2 * maxd + 2 || bands >= 3;
-        if (lds <= 80 * 1024 && (enough || dbg_bands)) break;
+        lds = ((size_t)M * g.PS + 16 + (size_t)M * 64 + (size_t)M * (K + 4)) * sizeof(float);
+        const bool enough = (int64_t)N * groups * g.bands >= 256 || g.TH < 2 * maxd + 2 || bands >= 3;
+        if (lds <= 128 * 1024 && (enough || dbg_bands)) break;
         if (bands == max_bands) return 0;
     }
-    if (lds > 80 * 1024) return 0;
-    if (g.HW >= 4096 || 16 * g.TH * g.XS >= 4096 || !magic_exact(g.mag_w, W, g.HW + 64) || !magic_exact(g.mag_xs, g.XS, 16 * g.TH * g.XS)) return 0;
+    if (lds > 128 * 1024) return 0;
+    if (g.HW >= 4096 || M * g.TH * g.XS >= 4096 || !magic_exact(g.mag_w, W, g.HW + 64) || !magic_exact(g.mag_xs, g.XS, M * g.TH * g.XS)) return 0;
     for (int rh = 1; rh <= g.TH; ++rh)
-        if (!magic_exact(magic20(rh), rh, 16 * rh)) return 0;
+        if (!magic_exact(magic20(rh), rh, M * rh)) return 0;
     return 1;
 }
 
 extern "C" int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]) {
-    static const int off = getenv("MSPL_EESP_FRONT") ? atoi(getenv("MSPL_EESP_FRONT")) == 0 : 0;
-    if (off || !dil) return 0;
+    // Measured on the whole label pass: with one batch in flight the fused launch is worth +2 % (it shortens a latency-bound chain);
+    // with three launches of 32 images in flight it costs 1.7 % (its workgroups hold 50-100 KB of LDS and 512 threads, which
+    // crowds out the other lanes' kernels).  So: used unless the library is in throughput mode (mspl_set_throughput_mode, read
+    // when a lane's graph is captured); MSPL_EESP_FRONT=0 / =2 force it off / on.
+    static const int mode = getenv("MSPL_EESP_FRONT") ? atoi(getenv("MSPL_EESP_FRONT")) : 1;
+    if (mode == 0 || !dil || (mode == 1 && g_throughput_mode.load())) return 0;
     FrGeom g; size_t lds;
     return eesp_proj_dw_plan(N, Cin, n, groups, H, W, dil, g, lds);
 }
@@ -984,21 +1004,26 @@ extern "C" int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const 
     static const int dbg_stop = getenv("MSPL_FRONT_STOP") ? atoi(getenv("MSPL_FRONT_STOP")) : 0;
     g.stop = dbg_stop;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)(N * (n / 16) * g.bands)), blk(512);      // (512 threads: one float4 of the 16 x 128 weight slab each)
+    const dim3 grid((unsigned)(N * groups * g.bands)), blk(512);
     const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
     static bool attr_done = false;     // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
+#define MSPL_FR_ALL(OP) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32, 2) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16, 1) \
+                        OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32, 2) OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16, 1) \
+                        OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32, 1) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16, 2) \
+                        OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32, 1) OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16, 2)
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 1, 2, 3>, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 1, 2, 3>, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 2, 3, 4>, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DilSet<1, 2, 3, 4>, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define MSPL_FR_ATTR(DSX, KQX, SLX) (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DSX, KQX, SLX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        MSPL_FR_ALL(MSPL_FR_ATTR)
+#undef MSPL_FR_ATTR
         (void)hipGetLastError();
         attr_done = true;
     }
-#define MSPL_FR(DSX, KQX) hipLaunchKernelGGL((eesp_proj_dw_kernel<DSX, KQX>), grid, blk, lds, s, x, wp, pscale, pshift, palpha, w, g, e, out)
-    if (key == 1123) { if (g.K == 128) MSPL_FR(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32); else MSPL_FR(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16); }
-    else { if (g.K == 128) MSPL_FR(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32); else MSPL_FR(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16); }
-#undef MSPL_FR
+    const int kq = g.K / 4, sl = g.M / 16;
+#define MSPL_FR_GO(DSX, KQX, SLX) if (key == (DSX::d(0) * 1000 + DSX::d(1) * 100 + DSX::d(2) * 10 + DSX::d(3)) && kq == KQX && sl == SLX) \
+        hipLaunchKernelGGL((eesp_proj_dw_kernel<DSX, KQX, SLX>), grid, blk, lds, s, x, wp, pscale, pshift, palpha, w, g, e, out);
+    MSPL_FR_ALL(MSPL_FR_GO)
+#undef MSPL_FR_GO
+#undef MSPL_FR_ALL
     MSPL_CHECK_LAUNCH("eesp_proj_dw_hff");
     return MSPL_OK;
 }

@@ -41,7 +41,8 @@ def test_eesp_dw_hff(dil, stride, shape):
 
 
 @pytest.mark.parametrize('cfg', [(2, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 128, 4, 16, 30, [1, 1, 2, 3]), (2, 256, 64, 4, 18, 30, [1, 2, 3, 4]),
-                                 (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4])])
+                                 (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4]),
+                                 (32, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 64, 4, 20, 36, [1, 1, 2, 3])])
 def test_eesp_proj_dw_hff(cfg):
     """K1 + K2 in one launch (projection on the matrix cores straight into K2's LDS tile) against torch, and against the two
     launches it replaces: the projection differs from the 32x32x2 kernel only in the last bits (k order inside an MFMA), K2's
@@ -76,12 +77,12 @@ def test_eesp_proj_dw_hff(cfg):
 
 def test_eesp_proj_dw_hff_shapes_left_to_two_launches():
     from mspl_amd import ops
-    assert not ops.eesp_proj_dw_hff_fits((16, 256, 36, 60), 64, 4, [1, 2, 3, 4], 1)       # 16 planes of 44 x 68 do not fit LDS
+    assert not ops.eesp_proj_dw_hff_fits((16, 256, 72, 120), 64, 4, [1, 2, 3, 4], 1)      # planes wider than 64 columns
     assert not ops.eesp_proj_dw_hff_fits((16, 512, 18, 30), 128, 4, [1, 1, 2, 3], 2)      # stride 2
     assert not ops.eesp_proj_dw_hff_fits((16, 96, 18, 30), 24, 4, [1, 1, 2, 3], 1)        # K = 24 per group
     assert not ops.eesp_proj_dw_hff_fits((1, 512, 18, 31), 128, 4, [1, 1, 2, 3], 1)       # odd row length
     with pytest.raises(RuntimeError, match='not covered'):
-        ops.eesp_proj_dw_hff(torch.zeros(1, 256, 36, 60, device=DEV), torch.zeros(64, 64, 1, 1, device=DEV), None, None, None,
+        ops.eesp_proj_dw_hff(torch.zeros(1, 256, 72, 120, device=DEV), torch.zeros(64, 64, 1, 1, device=DEV), None, None, None,
                              torch.zeros(4, 64, 3, 3, device=DEV), [1, 2, 3, 4], 4)
 
 
