@@ -496,11 +496,14 @@ def main():
     eager = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=False)
     from mspl_amd import layers as L
     L.ops.eesp_dw_hff = record_k2
+    from mspl_amd._native import lib as _lib
+    prev_mode = _lib.mspl_set_throughput_mode(1)       # the lanes' launch shapes: K1 and K2 as two launches (outside it the stride-1 blocks use the fused K1+K2 launch)
     try:
         eager(x)
         torch.cuda.synchronize()
     finally:
         L.ops.eesp_dw_hff = real
+        _lib.mspl_set_throughput_mode(prev_mode)
     REPS = 20
     k2_ms = []
     for a_, kw in calls:
@@ -520,6 +523,7 @@ def main():
             best = t if best is None or t < best else best
         k2_ms.append(best)
     k2_bytes, k2_launches = k2_algorithmic_bytes(model, BATCH, H, W)
+    assert len(calls) == k2_launches, 'recorded %d K2 launches, the model has %d EESP blocks' % (len(calls), k2_launches)
 
     # The same 13 K2 launches at 4x the batch ("report K2 at bs=16 and bs=64"): at bs=16 seven of the
     # thirteen launches move 22 MB each and are bounded by launch ramp + two memory round trips, not by bandwidth.

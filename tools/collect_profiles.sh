@@ -5,6 +5,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# the kernel set of the headline's lanes (K1 and K2 as two launches: throughput mode); one batch in flight alone would use the fused
+# K1+K2 launch for the stride-1 blocks, and the K2 traffic script expects the 13 K2 launches of a forward
+export MSPL_EESP_FRONT=0
 rocprofv3 --kernel-trace --stats -d $O/if1 -o pp --output-format csv -- python3 $R/bench.py --profile-pass --in-flight 1 --steps 60 --warmup 10 > $O/if1.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/if3 -o pp --output-format csv -- python3 $R/bench.py --profile-pass --in-flight 3 --steps 90 --warmup 15 > $O/if3.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc -o FETCH_SIZE -- python3 $R/bench.py --profile-pass --in-flight 1 --no-graph --steps 3 --warmup 1 > $O/pmc_f.log 2>&1
