@@ -216,3 +216,35 @@ def test_generate_pseudo_label_multi_model_end_to_end(tmp_path, use_graph):
             hist += np.bincount(got.ravel(), minlength=5)[:5]
     ref_w = olab.class_weights_from_histogram(hist)
     assert np.allclose(cw.cpu().numpy(), ref_w.astype(np.float32), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_generate_pseudo_label_batches_per_launch(tmp_path):
+    """Two consecutive loader batches per launch (PipelinedLabelPass group) with a ragged loader -- five batches of two and one
+    of one image -- writes byte-identical label files, the same list and the same class weights as one batch per launch."""
+    import argparse
+    from mspl_amd import models, uest
+    from mspl_amd.io import Preprocessor
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    ms = []
+    for C_, ds, seed in [(13, 'camvid', 61), (5, 'greenhouse', 63)]:
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=C_, dataset=ds, fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+        ms.append(m)
+    pre = Preprocessor(size=(64, 48))
+    sizes = [2, 2, 2, 2, 2, 1]
+    frames = [np.stack([synth_image_u8(72, 96, 90 + 4 * b + i)[0] for i in range(n)]) for b, n in enumerate(sizes)]
+    names = [['/d/color/g_%d_%d.jpg' % (b, i) for i in range(n)] for b, n in enumerate(sizes)]
+    outs = []
+    for grp in (1, 2):
+        d = tmp_path / ('g%d' % grp)
+        d.mkdir()
+        loader = [(pre(torch.from_numpy(f))[0], None, n, 0.0) for f, n in zip(frames, names)]
+        lst, cw = uest.generate_pseudo_label_multi_model(ms, ['camvid', 'forest'], loader, str(d), use_graph=True, in_flight=2,
+                                                         batches_per_launch=grp)
+        files = sorted(os.listdir(str(d / 'pred')))
+        outs.append((open(lst).read().replace(str(d), ''), cw.cpu().numpy(), {f: open(str(d / 'pred' / f), 'rb').read() for f in files}))
+    assert outs[0][0] == outs[1][0] and len(outs[0][2]) == sum(sizes)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
