@@ -373,6 +373,15 @@ int mspl_png_writer_destroy(void* writer);
  * r = (1-momentum)*r + momentum*stat (unbiased variance M/(M-1)).  ws: 2*C doubles of device workspace. */
 int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                             float* running_mean, float* running_var, double* ws, float* mean, float* invstd, void* stream);
+/* Same, and also the fold the affine / PReLU kernel applies: scale = gamma * invstd, shift = beta - mean * scale (C floats each). */
+int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                 float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                 double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Backward of the statistics' dependence on z, per channel: t = gscale - mean * gshift; ggamma = t * invstd;
+ * p = -gamma * t * invstd^3 / M; q = -gshift * scale / M - p * mean  (then gz = p * z + q, one mspl_pointwise_fwd). */
+int mspl_bn_batch_stats_bwd_coeffs(const float* gscale, const float* gshift, const float* gamma, const float* mean,
+                                   const float* invstd, const float* scale, int32_t C, double M, float* ggamma,
+                                   float* p, float* q, void* stream);
 /* torch.optim.SGD (train_segmentation.py:253) on a flat fp32 buffer: g += wd*p; buf = first_step ? g : momentum*buf + g;
  * p -= lr*buf  (dampening 0, no Nesterov; buf may be NULL when momentum == 0).  One call per learning-rate group. */
 int mspl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,

@@ -501,25 +501,25 @@ class BNBatchStatsFn(torch.autograd.Function):
         N, C = z.shape[:2]
         hw = z[0, 0].numel()
         ws = torch.empty(2 * C, dtype=torch.float64, device=z.device)
-        mean = torch.empty(C, dtype=torch.float32, device=z.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=z.device)
-        check(lib.mspl_bn_batch_stats_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(ws), _p(mean),
-                                          _p(invstd), _stream()))
-        scale = gamma * invstd
-        shift = torch.addcmul(beta, mean, scale, value=-1.0)
+        st = torch.empty(4, C, dtype=torch.float32, device=z.device)       # mean, invstd, scale, shift
+        mean, invstd, scale, shift = st[0], st[1], st[2], st[3]
+        gamma, beta = _c(gamma), _c(beta)
+        check(lib.mspl_bn_batch_stats_fold_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma), _p(beta),
+                                               _p(ws), _p(mean), _p(invstd), _p(scale), _p(shift), _stream()))
         ctx.save_for_backward(z, gamma, mean, invstd, scale)
         return scale, shift
 
     @staticmethod
     def backward(ctx, gsc, gsh):
         z, gamma, mean, invstd, scale = ctx.saved_tensors
-        M = z.numel() // z.shape[1]
-        t = torch.addcmul(gsc, mean, gsh, value=-1.0)              # gsc - mean*gsh
-        ggamma = t * invstd
-        p = (gamma * t) * invstd.pow(3) * (-1.0 / M)
-        q = (gsh * scale) * (-1.0 / M) - p * mean
-        gz = ops.pointwise(z, Epi(p.contiguous(), q.contiguous()))
-        return gz, ggamma, gsh, None, None, None, None
+        C = z.shape[1]
+        M = z.numel() // C
+        out = torch.empty(3, C, dtype=torch.float32, device=z.device)       # ggamma, p, q: one launch (was eight ATen launches)
+        gsc, gsh = _c(gsc), _c(gsh)
+        check(lib.mspl_bn_batch_stats_bwd_coeffs(_p(gsc), _p(gsh), _p(gamma), _p(mean), _p(invstd), _p(scale), C, float(M),
+                                                 _p(out[0]), _p(out[1]), _p(out[2]), _stream()))
+        gz = ops.pointwise(z, Epi(out[1], out[2]))
+        return gz, out[0], gsh, None, None, None, None
 
 
 def bn_batch_stats(z, bn):

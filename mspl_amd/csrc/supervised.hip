@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ z, const double* __restrict__ ws, int C, int HW,
                                                           double M, float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ mean,
-                                                          float* __restrict__ invstd) {
+                                                          float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double k = z[(size_t)c * HW];
@@ -58,13 +60,37 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const double mu = k + e1;
     double var = e2 - e1 * e1;
     if (var < 0.0) var = 0.0;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mf;
+    invstd[c] = isf;
+    if (scale) {                                           // the fold the affine/PReLU kernel applies: (gamma * invstd, beta - mean * gamma * invstd)
+        const float sc = gamma[c] * isf;
+        scale[c] = sc;
+        shift[c] = beta[c] + (-mf) * sc;
+    }
     if (running_mean) {
         const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
+}
+
+// Backward of the batch statistics' dependence on z (autograd.BNBatchStatsFn): with t = d scale - mean * d shift per channel,
+//   d gamma = t * invstd,   gz = p * z + q  with  p = -gamma * t * invstd^3 / M,  q = -d shift * scale / M - p * mean.
+// One launch of C threads instead of eight ATen launches on C-element tensors per BatchNorm (~110 BatchNorms per iteration).
+__global__ __launch_bounds__(256) void bn_stats_bwd_coeffs_kernel(const float* __restrict__ gsc, const float* __restrict__ gsh,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                                  int C, float inv_m, float* __restrict__ ggamma,
+                                                                  float* __restrict__ pc, float* __restrict__ qc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float is = invstd[c], mu = mean[c];
+    const float t = gsc[c] + (-mu) * gsh[c];
+    ggamma[c] = t * is;
+    const float p = ((gamma[c] * t) * (is * is * is)) * (-inv_m);
+    pc[c] = p;
+    qc[c] = (gsh[c] * scale[c]) * (-inv_m) - p * mu;
 }
 
 // torch.optim.SGD: g += wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf      (dampening 0, no Nesterov)
@@ -87,9 +113,39 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 
 using namespace mspl;
 
+static int bn_batch_stats_impl(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum, float* running_mean,
+                               float* running_var, const float* gamma, const float* beta, double* ws, float* mean, float* invstd,
+                               float* scale, float* shift, void* stream);
+
 extern "C" int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                        float* running_mean, float* running_var, double* ws, float* mean, float* invstd,
                                        void* stream) {
+    return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, nullptr, nullptr, ws, mean, invstd, nullptr,
+                               nullptr, stream);
+}
+
+extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                            float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                            double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
+    return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int mspl_bn_batch_stats_bwd_coeffs(const float* gscale, const float* gshift, const float* gamma, const float* mean,
+                                              const float* invstd, const float* scale, int32_t C, double M, float* ggamma,
+                                              float* p, float* q, void* stream) {
+    MSPL_REQUIRE(gscale && gshift && gamma && mean && invstd && scale && ggamma && p && q, MSPL_ERR_NULL_POINTER,
+                 "bn_batch_stats_bwd_coeffs: null pointer");
+    MSPL_REQUIRE(C > 0 && M > 0, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_bwd_coeffs: C=%d M=%g", C, M);
+    hipLaunchKernelGGL(bn_stats_bwd_coeffs_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gscale, gshift,
+                       gamma, mean, invstd, scale, C, (float)(1.0 / M), ggamma, p, q);
+    MSPL_CHECK_LAUNCH("bn_batch_stats_bwd_coeffs");
+    return MSPL_OK;
+}
+
+static int bn_batch_stats_impl(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum, float* running_mean,
+                               float* running_var, const float* gamma, const float* beta, double* ws, float* mean, float* invstd,
+                               float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(z && ws && mean && invstd, MSPL_ERR_NULL_POINTER, "bn_batch_stats: null pointer");
     MSPL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MSPL_ERR_NULL_POINTER,
                  "bn_batch_stats: running_mean and running_var go together");
@@ -109,7 +165,7 @@ extern "C" int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(256), 0, s, z, C, HW, per_block, ws);
     MSPL_CHECK_LAUNCH("bn_batch_stats(sum)");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, s, z, ws, C, HW, (double)N * (double)HW, eps,
-                       momentum, running_mean, running_var, mean, invstd);
+                       momentum, running_mean, running_var, mean, invstd, gamma, beta, scale, shift);
     MSPL_CHECK_LAUNCH("bn_batch_stats(finalize)");
     return MSPL_OK;
 }
