@@ -377,11 +377,12 @@ int mspl_bn_batch_stats_fwd(const float* z, int32_t N, int32_t C, int32_t HW, fl
 int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                  float* running_mean, float* running_var, const float* gamma, const float* beta,
                                  double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* Backward of the statistics' dependence on z, per channel: t = gscale - mean * gshift; ggamma = t * invstd;
- * p = -gamma * t * invstd^3 / M; q = -gshift * scale / M - p * mean  (then gz = p * z + q, one mspl_pointwise_fwd). */
+/* Backward of the statistics' dependence on z, per channel: t = gscale - mean * gshift; ggamma = t * invstd; gbeta = gshift (NULL:
+ * not wanted); p = -gamma * t * invstd^3 / M; q = -gshift * scale / M - p * mean  (then gz = p * z + q, one mspl_pointwise_fwd).
+ * accumulate != 0: ggamma / gbeta are added to (the parameters' gradient buffers). */
 int mspl_bn_batch_stats_bwd_coeffs(const float* gscale, const float* gshift, const float* gamma, const float* mean,
-                                   const float* invstd, const float* scale, int32_t C, double M, float* ggamma,
-                                   float* p, float* q, void* stream);
+                                   const float* invstd, const float* scale, int32_t C, double M, int32_t accumulate,
+                                   float* ggamma, float* gbeta, float* p, float* q, void* stream);
 /* torch.optim.SGD (train_segmentation.py:253) on a flat fp32 buffer: g += wd*p; buf = first_step ? g : momentum*buf + g;
  * p -= lr*buf  (dampening 0, no Nesterov; buf may be NULL when momentum == 0).  One call per learning-rate group. */
 int mspl_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,

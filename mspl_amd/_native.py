@@ -93,7 +93,7 @@ SIGNATURES = {
     'mspl_bn_batch_stats_fwd': [c_f32p, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 6,
     'mspl_sgd_step': [c_f32p, c_f32p, c_f32p, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_i32, ctypes.c_void_p],
     'mspl_bn_batch_stats_fold_fwd': [c_f32p, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float] + [c_f32p] * 4 + [ctypes.c_void_p] + [c_f32p] * 4 + [ctypes.c_void_p],
-    'mspl_bn_batch_stats_bwd_coeffs': [c_f32p] * 6 + [c_i32, ctypes.c_double] + [c_f32p] * 3 + [ctypes.c_void_p],
+    'mspl_bn_batch_stats_bwd_coeffs': [c_f32p] * 6 + [c_i32, ctypes.c_double, c_i32] + [c_f32p] * 4 + [ctypes.c_void_p],
     'mspl_nid_workspace_floats': [c_i32, c_i32, c_i32, c_i32],
     'mspl_nid_hist_fwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_nid_hist_bwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],

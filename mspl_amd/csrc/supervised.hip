@@ -81,13 +81,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_stats_bwd_coeffs_kernel(const float* __restrict__ gsc, const float* __restrict__ gsh,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                                  int C, float inv_m, float* __restrict__ ggamma,
-                                                                  float* __restrict__ pc, float* __restrict__ qc) {
+                                                                  int C, float inv_m, int accumulate, float* __restrict__ ggamma,
+                                                                  float* __restrict__ gbeta, float* __restrict__ pc,
+                                                                  float* __restrict__ qc) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const float is = invstd[c], mu = mean[c];
     const float t = gsc[c] + (-mu) * gsh[c];
-    ggamma[c] = t * is;
+    // accumulate: ggamma / gbeta are the parameters' own gradient buffers (one writer per element: plain read-modify-write)
+    ggamma[c] = accumulate ? ggamma[c] + t * is : t * is;
+    if (gbeta) gbeta[c] = accumulate ? gbeta[c] + gsh[c] : gsh[c];
     const float p = ((gamma[c] * t) * (is * is * is)) * (-inv_m);
     pc[c] = p;
     qc[c] = (gsh[c] * scale[c]) * (-inv_m) - p * mu;
@@ -132,13 +135,13 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
 }
 
 extern "C" int mspl_bn_batch_stats_bwd_coeffs(const float* gscale, const float* gshift, const float* gamma, const float* mean,
-                                              const float* invstd, const float* scale, int32_t C, double M, float* ggamma,
-                                              float* p, float* q, void* stream) {
+                                              const float* invstd, const float* scale, int32_t C, double M, int32_t accumulate,
+                                              float* ggamma, float* gbeta, float* p, float* q, void* stream) {
     MSPL_REQUIRE(gscale && gshift && gamma && mean && invstd && scale && ggamma && p && q, MSPL_ERR_NULL_POINTER,
                  "bn_batch_stats_bwd_coeffs: null pointer");
     MSPL_REQUIRE(C > 0 && M > 0, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_bwd_coeffs: C=%d M=%g", C, M);
     hipLaunchKernelGGL(bn_stats_bwd_coeffs_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gscale, gshift,
-                       gamma, mean, invstd, scale, C, (float)(1.0 / M), ggamma, p, q);
+                       gamma, mean, invstd, scale, C, (float)(1.0 / M), accumulate, ggamma, gbeta, p, q);
     MSPL_CHECK_LAUNCH("bn_batch_stats_bwd_coeffs");
     return MSPL_OK;
 }

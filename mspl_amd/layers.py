@@ -185,6 +185,8 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
     if bn.training:
         if pre_add is not None:
             z, pre_add = z + pre_add, None
+        if _FUSED_BN_TRAIN:
+            return ag.bn_train_prelu(z, bn, alpha, residual)
         scale, shift = ag.bn_batch_stats(z, bn)
     else:
         scale, shift = train_fold(bn)
@@ -193,6 +195,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
+_FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
 
 
 def _conv_bn_act(x, conv, bn, alpha=None, pre_add=None, residual=None):
