@@ -407,6 +407,10 @@ int mspl_nid_hist_bwd(const float* camera, const float* label, int32_t B, int32_
 int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4, const int32_t* dil, int32_t stride, int32_t N,
                      int32_t n, int32_t H, int32_t W, float* gx, float* const* gw, void* stream);
 
+/* out = srcs[0] + ... + srcs[n-1] (1 <= n <= 8 equally shaped fp32 tensors of `count` elements, count % 4 == 0, 16-byte aligned; srcs
+ * is a HOST array of device pointers): the gradient of a tensor with several consumers in one launch (autograd.FanOutFn). */
+int mspl_sum_n(const float* const* srcs, int32_t n, int64_t count, float* out, void* stream);
+
 /* Transposed copies of many convolution weights in one launch (the weights of the data-gradient convolutions of a training
  * step; replaces one ATen permute copy + flip per convolution, autograd.ConvFn.backward).  seg_table: device array of
  * { const float* src; float* dst; int32 groups, cin_g, cout_g, k, numel, pad } (40 bytes each); src is (G*cout_g, cin_g, k, k),

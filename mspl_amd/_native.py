@@ -104,6 +104,7 @@ SIGNATURES = {
     'mspl_png_writer_poll': [ctypes.c_void_p, c_i64, c_i32],
     'mspl_png_writer_destroy': [ctypes.c_void_p],
     'mspl_set_throughput_mode': [c_i32],
+    'mspl_sum_n': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_f32p, ctypes.c_void_p],
     'mspl_transpose_weights': [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,

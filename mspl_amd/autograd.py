@@ -301,6 +301,40 @@ class ConvAffinePReLUFn(torch.autograd.Function):
         return gx, gw, None, None, r_sc, r_sh, r_al, gpre, gz, None, None, None, None
 
 
+class FanOutFn(torch.autograd.Function):
+    """n aliases of x for n consumers; backward sums their gradients with ONE launch (mspl_sum_n) instead of autograd's n - 1
+    pairwise ATen adds.  The outputs are views of x: consumers must not write to them (none of this package's ops does)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [_c(g) for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        if live[0].numel() % 4 or any(t.data_ptr() % 16 for t in live):
+            out = live[0]
+            for t in live[1:]:
+                out = out + t
+            return out, None
+        out = torch.empty_like(live[0])
+        ptrs = (ctypes.c_void_p * len(live))(*[t.data_ptr() for t in live])
+        check(lib.mspl_sum_n(ptrs, len(live), live[0].numel(), _p(out), _stream()))
+        return out, None
+
+
+def fan_out(x, n):
+    """n aliases of x whose gradients are summed in one launch (use where one tensor feeds n >= 3 branches)."""
+    if n < 2 or n > 8 or not x.requires_grad:
+        return (x,) * n
+    return FanOutFn.apply(x, n)
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

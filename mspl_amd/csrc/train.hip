@@ -864,6 +864,41 @@ extern "C" int mspl_transpose_weights(const void* seg_table, const void* block_t
     return MSPL_OK;
 }
 
+// out = sum of up to 8 equally shaped tensors in one launch (the gradient of a tensor with several consumers: autograd would add
+// them pairwise, n - 1 launches that read 2 and write 1 tensor each).  Summation order: ((s0 + s1) + s2) + ... like the pairwise adds.
+namespace mspl {
+struct SumSrcs { const float* p[8]; };
+
+__global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs srcs, int n, int64_t count4, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 a = reinterpret_cast<const float4*>(srcs.p[0])[i];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        if (k >= n) break;
+        const float4 b = reinterpret_cast<const float4*>(srcs.p[k])[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+}  // namespace mspl
+
+extern "C" int mspl_sum_n(const float* const* srcs, int32_t n, int64_t count, float* out, void* stream) {
+    MSPL_REQUIRE(srcs && out, MSPL_ERR_NULL_POINTER, "sum_n: null pointer");
+    MSPL_REQUIRE(n >= 1 && n <= 8 && count >= 0 && (count & 3) == 0, MSPL_ERR_BAD_SHAPE, "sum_n: n=%d count=%lld (1..8 tensors, count %% 4 == 0)",
+                 n, (long long)count);
+    mspl::SumSrcs s;
+    for (int k = 0; k < 8; ++k) {
+        s.p[k] = k < n ? srcs[k] : srcs[0];
+        MSPL_REQUIRE(s.p[k] && (((uintptr_t)s.p[k]) & 15) == 0, MSPL_ERR_NULL_POINTER, "sum_n: source %d is NULL or not 16-byte aligned", k);
+    }
+    MSPL_REQUIRE((((uintptr_t)out) & 15) == 0, MSPL_ERR_UNSUPPORTED, "sum_n: unaligned destination");
+    if (count == 0) return MSPL_OK;
+    hipLaunchKernelGGL(mspl::sum_n_kernel, dim3((unsigned)ceil_div64(count / 4, 256)), dim3(256), 0, (hipStream_t)stream, s, n, count / 4, out);
+    MSPL_CHECK_LAUNCH("sum_n");
+    return MSPL_OK;
+}
+
 extern "C" int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream) {
     MSPL_REQUIRE(g && out, MSPL_ERR_NULL_POINTER, "hff_suffix_sum: null pointer");
     MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_suffix_sum: bad shape");

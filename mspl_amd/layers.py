@@ -643,17 +643,18 @@ class EfficientPyrPool(nn.Module):
         height, width = x.shape[2:]
         P = self.proj_planes
         hs = []
-        for stage, sc, (h_s, w_s) in zip(self.stages, self.scales, self.branch_sizes(height, width)):
+        xs = ag.fan_out(x, len(self.stages))               # one alias per branch: their gradients are summed by one launch
+        for xb, stage, sc, (h_s, w_s) in zip(xs, self.stages, self.scales, self.branch_sizes(height, width)):
             if sc < 1.0:
-                h = ag.adaptive_avgpool(x, (h_s, w_s))
+                h = ag.adaptive_avgpool(xb, (h_s, w_s))
                 h = ag.conv(h, stage.weight, 1, P)
                 h = ag.bilinear(h, (height, width))
             elif sc > 1.0:
-                h = ag.bilinear(x, (h_s, w_s))
+                h = ag.bilinear(xb, (h_s, w_s))
                 h = ag.conv(h, stage.weight, 1, P)
                 h = ag.adaptive_avgpool(h, (height, width))
             else:
-                h = ag.conv(x, stage.weight, 1, P)
+                h = ag.conv(xb, stage.weight, 1, P)
             hs.append(h)
         out = self.merge_layer[0](torch.cat(hs, 1))        # BN+PReLU over the concatenation
         out = self.merge_layer[1](out)                      # Shuffle: view/transpose copy

@@ -388,3 +388,23 @@ def test_weight_transposer_equals_on_the_spot_copies():
     fresh = ag._transposed_weights(ws[1][0], 16, 3)        # outside the scope: made on the spot
     assert fresh.data_ptr() < tr.flat.data_ptr() or fresh.data_ptr() >= tr.flat.data_ptr() + tr.flat.numel() * 4
     assert torch.equal(fresh, want[1])
+
+
+def test_fan_out_fn_sums_branch_gradients_in_one_launch():
+    """autograd.fan_out: n aliases of a tensor, their gradients summed by mspl_sum_n; equal to autograd's own pairwise accumulation
+    (same order of additions), incl. an unused alias and the pass-through cases."""
+    from mspl_amd import autograd as ag
+    x = rnd(2, 6, 9, 12, seed=1).to(DEV).requires_grad_(True)
+    ws = [rnd(2, 6, 9, 12, seed=10 + i).to(DEV) for i in range(5)]
+    a = ag.fan_out(x, 5)
+    assert len(a) == 5 and all(t.data_ptr() == x.data_ptr() for t in a)
+    (a[0] * ws[0] + a[1] * ws[1] + a[2] * ws[2] + a[4] * ws[4]).sum().backward()      # a[3] unused
+    got = x.grad.clone()
+    want = ((ws[0] + ws[1]) + ws[2]) + ws[4]
+    assert torch.equal(got, want)
+    y = torch.zeros(3, device=DEV)                                                     # no gradient wanted: plain aliases
+    assert ag.fan_out(y, 3)[1] is y
+    z = rnd(1, 1, 3, 3, seed=2).to(DEV).requires_grad_(True)                           # 9 elements: not a multiple of 4 -> ATen adds
+    b = ag.fan_out(z, 2)
+    (b[0] * 2 + b[1] * 3).sum().backward()
+    assert torch.equal(z.grad, torch.full_like(z, 5.0))
