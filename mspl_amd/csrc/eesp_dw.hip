@@ -31,8 +31,6 @@
 
 #include "common.hpp"
 
-#define COMMA ,
-
 namespace mspl {
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -1007,10 +1005,12 @@ extern "C" int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const 
     const dim3 grid((unsigned)(N * groups * g.bands)), blk(512);
     const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
     static bool attr_done = false;     // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
-#define MSPL_FR_ALL(OP) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32, 2) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16, 1) \
-                        OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32, 2) OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16, 1) \
-                        OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 32, 1) OP(DilSet<1 COMMA 1 COMMA 2 COMMA 3>, 16, 2) \
-                        OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 32, 1) OP(DilSet<1 COMMA 2 COMMA 3 COMMA 4>, 16, 2)
+    typedef DilSet<1, 1, 2, 3> DS1123;
+    typedef DilSet<1, 2, 3, 4> DS1234;
+#define MSPL_FR_ALL(OP) OP(DS1123, 32, 2) OP(DS1123, 16, 1) \
+                        OP(DS1234, 32, 2) OP(DS1234, 16, 1) \
+                        OP(DS1123, 32, 1) OP(DS1123, 16, 2) \
+                        OP(DS1234, 32, 1) OP(DS1234, 16, 2)
     if (!attr_done) {
 #define MSPL_FR_ATTR(DSX, KQX, SLX) (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DSX, KQX, SLX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         MSPL_FR_ALL(MSPL_FR_ATTR)
