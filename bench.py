@@ -626,17 +626,23 @@ def main():
             out['per_kernel'] = json.load(open(pk))
         if train_multi is not None:
             out['train_step'] = train_multi
+        def extra(name, fn, *a_):
+            # an extra field that fails is reported inside the line; it never costs the headline
+            try:
+                out[name] = fn(*a_)
+            except Exception as e_:      # noqa: BLE001
+                out[name] = {'error': repr(e_)[:300]}
         if world == 1 and not args.no_three_source:
-            out['three_source'] = three_source_rate(dev)
+            extra('three_source', three_source_rate, dev)
         if world == 1 and not args.no_train:
-            out['train_step'] = train_step_rate(dev)
-            out['supervised_step'] = supervised_step_rate(dev)
+            extra('train_step', train_step_rate, dev)
+            extra('supervised_step', supervised_step_rate, dev)
         if world == 1 and not args.no_aspp:
-            out['aspp_head'] = aspp_head_rate(dev)
+            extra('aspp_head', aspp_head_rate, dev)
         if world == 1 and not args.no_io:
-            out['loader_io'] = loader_io_rate(dev)
+            extra('loader_io', loader_io_rate, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, shape)
+            extra('cpu_baseline', cpu_baseline, sd, shape)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
