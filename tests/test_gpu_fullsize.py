@@ -110,6 +110,14 @@ def test_config3_train_step_bs16_256x480():
     graphed = [float(gs(x, y)) for _ in range(2)]
     assert np.isfinite(eager).all() and eager[-1] < eager[0]
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4)
+    # bench.py's configuration: the batch as four concurrent micro-batch graphs -- same losses, same weights
+    net4 = _net(5, 'greenhouse', 3)[0].to(DEV).eval()
+    g4 = training.GraphedTrainStep(net4, x, y, cw, ignore_idx=4, lanes=4)
+    assert g4.lanes == 4
+    lanes = [float(g4(x, y)) for _ in range(2)]
+    np.testing.assert_allclose(lanes, eager[2:], rtol=5e-4)
+    worst = max(float((p - q).abs().max()) for p, q in zip(net4.state_dict().values(), nets[1].state_dict().values()))
+    assert worst < 1e-4, worst
 
 
 @pytest.mark.parametrize('depth,group', [(2, 1), (3, 1), (3, 2), (2, 3)])
