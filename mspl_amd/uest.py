@@ -324,8 +324,12 @@ class PipelinedLabelPass:
 
     @property
     def next_lane(self):
-        """Index into static_inputs() of the buffer the next submitted batch will use."""
-        return self._n % (self.depth * self.group)
+        """Index into static_inputs() of the buffer the next submitted batch (of the shape being staged) will use.  Derived from
+        the staging state, not from the number of calls: after a partly filled launch (flush() or a batch of another shape) the
+        next batch starts a fresh lane at slot 0 whatever the call count is."""
+        if self._staged is not None:
+            return self._staged[0] * self.group + self._staged[1]
+        return (self._lane_no % self.depth) * self.group
 
     def _group_buffer(self, i, bshape):
         """Input buffer of lane i for `group` batches of shape bshape: the captured graph's own buffer once there is one (no copy
