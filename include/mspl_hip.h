@@ -191,6 +191,41 @@ int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int32_t h, int3
                            const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
                            float* out, void* stream);
 
+/* ---- fused EfficientPyrPool body on the training path (nn_layers/efficient_pyramid_pool.py:39-58 + its autograd backward) ----
+ * Forward: mspl_pyrpool_fused_fwd that also keeps what the backward needs: zcat (N, nb*P, h, w) = the branch values BEFORE
+ * merge_layer.0's BatchNorm + PReLU, in torch.cat order (channel i*P + c), and -- through ep->raw_out -- the bare result of
+ * merge_layer.2's convolution.  Always the LDS-tiled table form (MSPL_ERR_UNSUPPORTED when a tile does not fit LDS: callers run
+ * the branch-by-branch form then). */
+int mspl_pyrpool_fused_train_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
+                                 const int32_t* hs, const int32_t* ws, const float* const* stage_w,
+                                 const float* const* down_e, const float* br_scale, const float* br_shift,
+                                 const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
+                                 float* out, float* zcat, void* stream);
+/* 1 when mspl_pyrpool_fused_train_fwd covers these shapes (same planning code, nothing is launched). */
+int mspl_pyrpool_fused_train_fits(int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs, const int32_t* ws);
+/* Backward of merge_layer.2 (grouped 3x3 over the shuffled concatenation + BatchNorm + PReLU) and merge_layer.0 (BatchNorm +
+ * PReLU over the concatenation) in one pass: gy (N,P,h,w) = dL/d(body output), mraw = the kept convolution result, zcat as above.
+ * gt (nb, N, P, h, w), BRANCH-major: dL/d(branch value), i.e. through both BatchNorm/PReLU pairs and the transposed convolution.
+ * Parameter gradients are ACCUMULATED (atomics; the caller zeroes them or passes the parameters' own gradient buffers):
+ * g_br_scale/g_br_shift/g_br_alpha (nb*P), g_merge_w (P,nb,3,3), g_m_scale/g_m_shift/g_m_alpha (P).  br_mean/br_inv (nb*P) and
+ * m_mean/m_inv (P): the frozen BatchNorms' running mean and rsqrt(var + eps) -- then (scale, shift) are the folded
+ * (gamma*inv, beta - mean*gamma*inv) and the g_*_scale / g_*_shift outputs receive d gamma / d beta; NULL: plain d scale / d shift. */
+int mspl_pyrpool_merge_bwd(const float* gy, const float* mraw, const float* zcat, int32_t N, int32_t P, int32_t h,
+                           int32_t w, int32_t nb, const float* br_scale, const float* br_shift, const float* br_alpha,
+                           const float* br_mean, const float* br_inv, const float* merge_w, const float* m_scale,
+                           const float* m_shift, const float* m_alpha, const float* m_mean, const float* m_inv,
+                           float* gt, float* g_br_scale, float* g_br_shift, float* g_br_alpha, float* g_merge_w,
+                           float* g_m_scale, float* g_m_shift, float* g_m_alpha, void* stream);
+/* Backward of the branches with hs >= h (adaptive_avg_pool2d(dw3x3(bilinear_up(x))); hs == h: the plain depthwise 3x3), up to
+ * three of them in one launch: gt[i] (N,P,h,w) = dL/d(branch i's value), stage_w[i] (P,1,3,3).  gx (N,P,h,w) is OVERWRITTEN with
+ * the sum of the branches' input gradients + add0 + add1 (optional (N,P,h,w) tensors: the low-resolution branches'
+ * contributions); gw[i] (P,1,3,3) are ACCUMULATED.  Nothing at up-sampled resolution is written to memory.
+ * _fits: 1 when the shapes are covered (branch sizes within [1x, 3x] of the map, tile fits LDS). */
+int mspl_pyrpool_branch_bwd_fits(int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs, const int32_t* ws);
+int mspl_pyrpool_branch_bwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                            const int32_t* ws, const float* const* stage_w, const float* const* gt, float* const* gw,
+                            const float* add0, const float* add1, float* gx, void* stream);
+
 /* K8+K9  label epilogue: bilinear(align_corners) upsample of both heads to (H,W), o = main + 0.5*aux,
  *     class = first-max argmax_c o (== np.argmax of softmax2d(o) up to exp() rounding ties), optional
  *     id LUT, optional softmax probabilities and KL(main||aux) map.

@@ -53,6 +53,14 @@ SIGNATURES = {
     'mspl_pyrpool_fused_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f32p, c_f32p, c_f32p,
                                c_f32p, _EP, c_f32p, ctypes.c_void_p],
+    'mspl_pyrpool_fused_train_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_f32p, c_f32p, c_f32p,
+                                     c_f32p, _EP, c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_pyrpool_fused_train_fits': [c_i32] * 5 + [ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)],
+    'mspl_pyrpool_merge_bwd': [c_f32p] * 3 + [c_i32] * 5 + [c_f32p] * 19 + [ctypes.c_void_p],
+    'mspl_pyrpool_branch_bwd_fits': [c_i32] * 5 + [ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)],
+    'mspl_pyrpool_branch_bwd': [c_f32p] + [c_i32] * 5 + [ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)] +
+                               [ctypes.POINTER(ctypes.c_void_p)] * 3 + [c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_label_epilogue_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                 ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_label_epilogue_hist_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

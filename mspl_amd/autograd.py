@@ -328,6 +328,130 @@ class FanOutFn(torch.autograd.Function):
         return out, None
 
 
+class PyrBodyFn(torch.autograd.Function):
+    """The EfficientPyrPool body between projection_layer and the last 1x1 (nn_layers/efficient_pyramid_pool.py:39-58: the five
+    branches, merge_layer.0 BatchNorm + PReLU over the concatenation, Shuffle, merge_layer.2 grouped 3x3 + BatchNorm + PReLU) as ONE
+    autograd node with frozen BatchNorms.
+
+    forward   one launch of the LDS-tiled fused kernel (+ the low-resolution branches' pooled / convolved maps), which also keeps the
+              branch values before merge_layer.0 (zcat) and the bare merge convolution (mraw).
+    backward  mspl_pyrpool_merge_bwd (everything from the output gradient down to dL/d(branch value), all parameter gradients of the
+              two merge layers), the existing small-map kernels for the scale < 1 branches, and mspl_pyrpool_branch_bwd for the
+              scale >= 1 branches: the concatenation is read once and written once, nothing at up-sampled resolution touches memory.
+    The node-per-op form it replaces moved the 5x-wide concatenation through memory 17 times and the up-sampled intermediates ~44
+    times per pyramid (4.9 of the 11.5 ms of kernel time of a uest step were pyramids: profiles/r03_train_trace_before.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, bn0, bn2, br_gamma, br_beta, br_alpha, merge_w, m_gamma, m_beta, m_alpha, *stage_ws):
+        x = _c(x)
+        N, P, h, w = x.shape
+        nb = len(sizes)
+        br_scale, br_shift = bn0['scale'], bn0['shift']
+        m_scale, m_shift = bn2['scale'], bn2['shift']
+        down = [i for i, (hs_, ws_) in enumerate(sizes) if (hs_ < h or ws_ < w)]
+        pooled, down_es = {}, [None] * nb
+        for i in down:
+            pooled[i] = ops.adaptive_avgpool(x, sizes[i])
+            down_es[i] = ops.conv3x3(pooled[i], stage_ws[i], P)
+        hs = (ctypes.c_int32 * nb)(*[int(s_[0]) for s_ in sizes])
+        ws = (ctypes.c_int32 * nb)(*[int(s_[1]) for s_ in sizes])
+        sw, de = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+        keep = []
+        for i in range(nb):
+            if i in down:
+                de[i] = down_es[i].data_ptr()
+            else:
+                t = _c(stage_ws[i])
+                keep.append(t)
+                sw[i] = t.data_ptr()
+        merge_w = _c(merge_w)
+        y = torch.empty((N, P, h, w), device=x.device, dtype=torch.float32)
+        mraw = torch.empty_like(y)
+        zcat = torch.empty((N, nb * P, h, w), device=x.device, dtype=torch.float32)
+        ep, keep2 = ops._build(Epi(m_scale, m_shift, m_alpha, raw_out=mraw), y, 0, N, P, h * w)
+        check(lib.mspl_pyrpool_fused_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(br_scale), _p(br_shift), _p(_c(br_alpha)),
+                                               _p(merge_w), ctypes.byref(ep), _p(y), _p(zcat), _stream()))
+        ctx.save_for_backward(x, zcat, mraw, br_scale, br_shift, br_alpha, merge_w, m_scale, m_shift, m_alpha,
+                              bn0['mean'], bn0['inv'], bn2['mean'], bn2['inv'], *stage_ws, *[pooled[i] for i in down])
+        ctx.sizes, ctx.down = [tuple(int(v) for v in s_) for s_ in sizes], down
+        ctx.sinks = ([_sink(t) for t in (br_gamma, br_beta, br_alpha, merge_w, m_gamma, m_beta, m_alpha)],
+                     [_sink(t) for t in stage_ws])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sv = ctx.saved_tensors
+        x, zcat, mraw, br_scale, br_shift, br_alpha, merge_w, m_scale, m_shift, m_alpha, mean0, inv0, mean2, inv2 = sv[:14]
+        sizes, down = ctx.sizes, ctx.down
+        nb = len(sizes)
+        stage_ws = sv[14:14 + nb]
+        pooled = dict(zip(down, sv[14 + nb:]))
+        gy = _c(gy)
+        N, P, h, w = x.shape
+        dev = x.device
+        psinks, wsinks = ctx.sinks
+
+        def dst(sink, shape):
+            return sink if sink is not None else torch.zeros(shape, device=dev, dtype=torch.float32)
+        g_br_gamma, g_br_beta, g_br_alpha = dst(psinks[0], (nb * P,)), dst(psinks[1], (nb * P,)), dst(psinks[2], (nb * P,))
+        g_merge_w = dst(psinks[3], tuple(merge_w.shape))
+        g_m_gamma, g_m_beta = dst(psinks[4], (P,)), dst(psinks[5], (P,))
+        g_m_alpha = dst(psinks[6], (P,)) if m_alpha is not None else None
+        gt = torch.empty((nb, N, P, h, w), device=dev, dtype=torch.float32)
+        check(lib.mspl_pyrpool_merge_bwd(_p(gy), _p(mraw), _p(zcat), N, P, h, w, nb, _p(br_scale), _p(br_shift), _p(br_alpha),
+                                         _p(mean0), _p(inv0), _p(merge_w), _p(m_scale), _p(m_shift), _p(m_alpha), _p(mean2),
+                                         _p(inv2), _p(gt), _p(g_br_gamma), _p(g_br_beta), _p(g_br_alpha), _p(g_merge_w),
+                                         _p(g_m_gamma), _p(g_m_beta), _p(g_m_alpha), _stream()))
+        g_stage = [dst(wsinks[i], tuple(stage_ws[i].shape)) for i in range(nb)]
+        # scale < 1 branches (small maps): bilinear^T -> depthwise 3x3 backward -> adaptive pool^T, existing kernels
+        adds = []
+        for i in down:
+            hs_, ws_ = sizes[i]
+            g_e = torch.empty((N, P, hs_, ws_), device=dev, dtype=torch.float32)
+            check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
+            g_pool = ops.conv3x3(g_e, _transposed_weights(stage_ws[i], P, 3), P, 1)
+            check(lib.mspl_conv_bwd_weight(_p(g_e), _p(pooled[i]), N, P, P, P, hs_, ws_, 3, 1, 1, 1, _p(g_stage[i]), _stream()))
+            g_xi = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
+            check(lib.mspl_adaptive_avgpool_bwd(_p(g_pool), N, P, h, w, hs_, ws_, _p(g_xi), _stream()))
+            adds.append(g_xi)
+        # scale >= 1 branches (up to three, pyr_body_fits) in one launch, the low-resolution contributions (up to two) added in.
+        # (always launched: the stage weights' gradients come from it)
+        up = [i for i in range(nb) if i not in down]
+        nbp = len(up)
+        hsa = (ctypes.c_int32 * nbp)(*[sizes[i][0] for i in up])
+        wsa = (ctypes.c_int32 * nbp)(*[sizes[i][1] for i in up])
+        swp = (ctypes.c_void_p * nbp)(*[stage_ws[i].data_ptr() for i in up])
+        gtp = (ctypes.c_void_p * nbp)(*[gt[i].data_ptr() for i in up])
+        gwp = (ctypes.c_void_p * nbp)(*[g_stage[i].data_ptr() for i in up])
+        gx = torch.empty_like(x)
+        check(lib.mspl_pyrpool_branch_bwd(_p(x), N, P, h, w, nbp, hsa, wsa, swp, gtp, gwp, _p(adds[0] if adds else None),
+                                          _p(adds[1] if len(adds) > 1 else None), _p(gx), _stream()))
+        ret = lambda sink, t: None if sink is not None else t          # noqa: E731
+        return (gx, None, None, None, ret(psinks[0], g_br_gamma), ret(psinks[1], g_br_beta), ret(psinks[2], g_br_alpha),
+                ret(psinks[3], g_merge_w), ret(psinks[4], g_m_gamma), ret(psinks[5], g_m_beta),
+                None if m_alpha is None else ret(psinks[6], g_m_alpha),
+                *[ret(wsinks[i], g_stage[i]) for i in range(nb)])
+
+
+def pyr_body_fits(shape, sizes):
+    """True when the fused training body (PyrBodyFn) covers an (N,P,h,w) projection with these branch sizes: every branch purely up
+    (>= the map in both directions) or purely down, one to three of the former, at most two of the latter, tiles fit LDS."""
+    N, P, h, w = [int(v) for v in shape]
+    sizes = [(int(a), int(b)) for a, b in sizes]
+    up = [(a, b) for a, b in sizes if a >= h and b >= w]
+    down = [(a, b) for a, b in sizes if (a, b) not in up]
+    if any(a > h or b > w for a, b in down) or not (1 <= len(up) <= 3) or len(down) > 2 or len(sizes) > 5:
+        return False
+    nb = len(sizes)
+    hs = (ctypes.c_int32 * nb)(*[a for a, _ in sizes])
+    ws = (ctypes.c_int32 * nb)(*[b for _, b in sizes])
+    if not lib.mspl_pyrpool_fused_train_fits(N, P, h, w, nb, hs, ws):
+        return False
+    hsa = (ctypes.c_int32 * len(up))(*[a for a, _ in up])
+    wsa = (ctypes.c_int32 * len(up))(*[b for _, b in up])
+    return bool(lib.mspl_pyrpool_branch_bwd_fits(N, P, h, w, len(up), hsa, wsa))
+
+
 def fan_out(x, n):
     """n aliases of x whose gradients are summed in one launch (use where one tensor feeds n >= 3 branches)."""
     if n < 2 or n > 8 or not x.requires_grad:

@@ -41,6 +41,7 @@ struct PyrGeom {
     unsigned mag_uw[PYR_MAXB], mag_bw;  // exact small-range division by UW[i] / (TW+2): (t * magic) >> 24
     int CPB, cblocks;                   // planes (channels) per workgroup, P / CPB
     int stop_after;                     // tuning aid (MSPL_PYR_STOP): return after phase k; 0 = run everything
+    float* zcat;                        // training forward: (N, nb*P, h, w), the branch values BEFORE merge_layer.0 (torch.cat order), or null
 };
 
 __device__ __forceinline__ int ada_s(int o, int I, int O) { return (int)(((unsigned)o * (unsigned)I) / (unsigned)O); }
@@ -206,6 +207,12 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
     const int npos = BH * BW2;
     const int XWl = g.XW, BWl = g.BW, hl = g.h, wl_ = g.w;
     const unsigned magb = g.mag_bw;
+    // training forward: the branch value before BN+PReLU at the tile's own (non-halo) positions goes to zcat (the backward needs it
+    // for the PReLU sign and d gamma); position (r, q) of the halo tile is pixel (y0 - 1 + r, x0 - 1 + q)
+    auto keep_raw = [&](int i, int r, int q, int py, int px, float b) {
+        if (g.zcat && r >= 1 && r <= g.TH && q >= 1 && q <= g.TW)
+            g.zcat[(((size_t)n * g.nb + i) * g.P + c) * (size_t)hl * wl_ + (size_t)py * wl_ + px] = b;
+    };
 #pragma unroll
     for (int i = 0; i < PYR_MAXB; ++i) {
         if (i >= g.nb) break;
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
                     b = fmaf(w01, p[1], b); b = fmaf(w02, p[2], b);
                     b = fmaf(w10, p[XWl], b); b = fmaf(w11, p[XWl + 1], b); b = fmaf(w12, p[XWl + 2], b);
                     b = fmaf(w20, p[2 * XWl], b); b = fmaf(w21, p[2 * XWl + 1], b); b = fmaf(w22, p[2 * XWl + 2], b);
+                    keep_raw(i, r, q, py, px, b);
                     b = fmaf(b, bsc, bsh);
                     b = b > 0.f ? b : bal * b;
                 }
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
                             }
                         b = s / (float)(rcnt * ccnt);
                     }
+                    keep_raw(i, r, q, py, px, b);
                     b = fmaf(b, bsc, bsh);
                     b = b > 0.f ? b : bal * b;
                 }
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
                     const float top = cc.z * ra[xa] + cc.w * ra[xb];
                     const float bot = cc.z * rb[xa] + cc.w * rb[xb];
                     b = rr.z * top + rr.w * bot;
+                    keep_raw(i, r, q, py, px, b);
                     b = fmaf(b, bsc, bsh);
                     b = b > 0.f ? b : bal * b;
                 }
@@ -339,6 +349,12 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
         }
         const int pix = y * wl_ + xb;
         float* dst = out + epi_offset(e, n, cabs, pix);
+        if (e.raw) {                       // training forward: the bare merge convolution result (un-sliced destination)
+            float* rdst = e.raw + ((size_t)n * g.P + c) * (size_t)hl * wl_ + pix;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (xb + j < wl_) rdst[j] = acc[j];
+        }
         if ((wl_ & 3) == 0) {
             store_out4(dst, epi_apply4(e, ec, acc, n, cabs, pix));
         } else {
@@ -358,38 +374,43 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
 int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                        const float* const* stage_w, const float* const* down_e, const float* br_scale,
                        const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
-                       hipStream_t stream);    // pyrpool_stream.hip
+                       hipStream_t stream, float* zcat = nullptr);    // pyrpool_stream.hip
 
 }  // namespace mspl
 
 using namespace mspl;
 
-extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
-                                      const int32_t* hs, const int32_t* ws, const float* const* stage_w,
-                                      const float* const* down_e, const float* br_scale, const float* br_shift,
-                                      const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
-                                      float* out, void* stream) {
-    MSPL_REQUIRE(x && hs && ws && stage_w && down_e && br_scale && br_shift && br_alpha && merge_w && out,
+static int pyrpool_fused_launch(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
+                               const int32_t* hs, const int32_t* ws, const float* const* stage_w,
+                               const float* const* down_e, const float* br_scale, const float* br_shift,
+                               const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
+                               float* out, float* zcat, void* stream, bool dry = false) {
+    // dry: shape / LDS planning only (mspl_pyrpool_fused_train_fits): no pointer is looked at, nothing is launched
+    MSPL_REQUIRE(dry || (x && hs && ws && stage_w && down_e && br_scale && br_shift && br_alpha && merge_w && out),
                  MSPL_ERR_NULL_POINTER, "pyrpool_fused: null pointer");
+    MSPL_REQUIRE(hs && ws, MSPL_ERR_NULL_POINTER, "pyrpool_fused: null pointer");
     MSPL_REQUIRE(N > 0 && P > 0 && h > 0 && w > 0, MSPL_ERR_BAD_SHAPE, "pyrpool_fused: bad shape N=%d P=%d %dx%d", N, P, h, w);
     MSPL_REQUIRE(nb >= 1 && nb <= PYR_MAXB, MSPL_ERR_UNSUPPORTED, "pyrpool_fused: %d branches (1..%d)", nb, PYR_MAXB);
-    if (int rc = check_epi(ep, P, "pyrpool_fused")) return rc;
-    {   // stencil form first (pyrpool_sep.hip); shapes it does not cover fall through to the table-driven kernel
+    if (int rc = check_epi(ep, P, "pyrpool_fused", zcat != nullptr)) return rc;
+    if (!dry) {   // register-streaming form first, then the LDS-tiled stencil form; shapes they do not cover fall through to the table-driven kernel
         static const int force_tables = getenv("MSPL_PYR_TABLES") ? atoi(getenv("MSPL_PYR_TABLES")) : 0;
         if (!force_tables) {
-            // register-streaming form first (the standard five-branch pyramid), then the LDS-tiled stencil form
+            // (the training forward -- zcat wanted -- exists in the streaming and in the table form)
             const int rc3 = pyrpool_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
-                                               make_epi(ep, P, h * w), out, (hipStream_t)stream);
+                                               make_epi(ep, P, h * w), out, (hipStream_t)stream, zcat);
             if (rc3 <= 0) return rc3;
-            const int rc = pyrpool_sep_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
-                                           make_epi(ep, P, h * w), out, (hipStream_t)stream);
-            if (rc <= 0) return rc;
+            if (!zcat) {
+                const int rc = pyrpool_sep_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
+                                               make_epi(ep, P, h * w), out, (hipStream_t)stream);
+                if (rc <= 0) return rc;
+            }
         }
     }
     PyrGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.P = P; g.h = h; g.w = w; g.nb = nb;
     g.br_scale = br_scale; g.br_shift = br_shift; g.br_alpha = br_alpha; g.merge_w = merge_w;
+    g.zcat = zcat;
     g.TW = w >= 32 ? 32 : ((w + 3) & ~3);
     g.TH = h >= 16 ? 16 : h;
     g.tiles_x = ceil_div(w, g.TW);
@@ -400,13 +421,13 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
     for (int i = 0; i < nb; ++i) {
         MSPL_REQUIRE(hs[i] > 0 && ws[i] > 0, MSPL_ERR_BAD_SHAPE, "pyrpool_fused: branch %d size %dx%d", i, hs[i], ws[i]);
         g.hs[i] = hs[i]; g.ws[i] = ws[i];
-        g.stage_w[i] = stage_w[i]; g.down_e[i] = down_e[i];
+        g.stage_w[i] = dry ? nullptr : stage_w[i]; g.down_e[i] = dry ? nullptr : down_e[i];
         if (hs[i] == h && ws[i] == w) {
             g.kind[i] = 1;
-            MSPL_REQUIRE(stage_w[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs stage weights", i);
+            MSPL_REQUIRE(dry || stage_w[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs stage weights", i);
         } else if (hs[i] >= h && ws[i] >= w) {
             g.kind[i] = 0;
-            MSPL_REQUIRE(stage_w[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs stage weights", i);
+            MSPL_REQUIRE(dry || stage_w[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs stage weights", i);
             // windows of an up-sampled branch must stay small (x-tile halo of 4 covers scales in [1, 4])
             MSPL_REQUIRE(hs[i] <= 4 * h && ws[i] <= 4 * w, MSPL_ERR_UNSUPPORTED, "pyrpool_fused: up-scale beyond 4x");
             g.sh[i] = bilinear_scale(h, hs[i]); g.sw[i] = bilinear_scale(w, ws[i]);
@@ -417,7 +438,7 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
             off = (off + 3) & ~3;
         } else if (hs[i] <= h && ws[i] <= w) {
             g.kind[i] = 2;
-            MSPL_REQUIRE(down_e[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs its low-resolution map", i);
+            MSPL_REQUIRE(dry || down_e[i], MSPL_ERR_NULL_POINTER, "pyrpool_fused: branch %d needs its low-resolution map", i);
             g.sh[i] = bilinear_scale(hs[i], h); g.sw[i] = bilinear_scale(ws[i], w);
         } else {
             set_error("pyrpool_fused: branch %d mixes up- and down-sampling (%dx%d vs %dx%d)", i, hs[i], ws[i], h, w);
@@ -442,6 +463,7 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
     off += nb * 9 * 2 + nb * 3;
     const size_t lds = (size_t)off * sizeof(float);
     MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "pyrpool_fused: tile needs %zu B of LDS", lds);
+    if (dry) return MSPL_OK;
     const Epi e = make_epi(ep, P, h * w);
     int cpb = 1;
     while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= 2048) cpb *= 2;
@@ -453,4 +475,30 @@ extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int3
     hipLaunchKernelGGL(pyrpool_fused_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, g, e, out);
     MSPL_CHECK_LAUNCH("pyrpool_fused");
     return MSPL_OK;
+}
+
+extern "C" int mspl_pyrpool_fused_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
+                                      const int32_t* hs, const int32_t* ws, const float* const* stage_w,
+                                      const float* const* down_e, const float* br_scale, const float* br_shift,
+                                      const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
+                                      float* out, void* stream) {
+    return pyrpool_fused_launch(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w, ep, out, nullptr,
+                                stream);
+}
+
+extern "C" int mspl_pyrpool_fused_train_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb,
+                                            const int32_t* hs, const int32_t* ws, const float* const* stage_w,
+                                            const float* const* down_e, const float* br_scale, const float* br_shift,
+                                            const float* br_alpha, const float* merge_w, const mspl_epilogue_t* ep,
+                                            float* out, float* zcat, void* stream) {
+    MSPL_REQUIRE(zcat, MSPL_ERR_NULL_POINTER, "pyrpool_fused_train: zcat is required");
+    return pyrpool_fused_launch(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w, ep, out, zcat,
+                                stream);
+}
+
+extern "C" int mspl_pyrpool_fused_train_fits(int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                                             const int32_t* ws) {
+    float dummy = 0.f;
+    return pyrpool_fused_launch(nullptr, N, P, h, w, nb, hs, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                &dummy, nullptr, true) == MSPL_OK;
 }

@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "pyr_stencil.hpp"
 
 namespace mspl {
 
@@ -34,40 +35,6 @@ struct Pyr3Geom {
     int SEG, nseg, ncb, CBW;         // output rows per segment, segments per plane, column blocks, output columns per block
     unsigned total;                  // waves
 };
-
-__device__ __forceinline__ int p3_ada_s(int o, int I, int O) { return (int)(((unsigned)o * (unsigned)I) / (unsigned)O); }
-__device__ __forceinline__ int p3_ada_e(int o, int I, int O) { return (int)((((unsigned)(o + 1)) * (unsigned)I + O - 1) / (unsigned)O); }
-
-// Stencil coefficients of one output position p (row or column) and one kernel offset k of an up branch with T taps:
-// acc[q] multiplies x[p - R + q], R = (T - 1) / 2.  Identical to p2_fill_up_tables (pyrpool_sep.hip).
-template <int T>
-__device__ __forceinline__ void p3_coeffs(int p, int k, int I, int S, float sc, float (&acc)[5]) {
-    constexpr int R = (T - 1) / 2;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) acc[q] = 0.f;
-    if (p < 0 || p >= I) return;
-    const int us = p3_ada_s(p, S, I), ue = p3_ada_e(p, S, I);
-    const float inv = 1.0f / (float)(ue - us);
-    for (int uu = us; uu < ue; ++uu) {
-        const int v = uu + k - 1;
-        if (v < 0 || v >= S) continue;          // zero padding of the 3x3 on the up-sampled grid
-        int ia, ib;  float w0, w1;
-        bilinear_src(sc, v, I, ia, ib, w0, w1);
-        const int ta = ia - (p - R), tb = ib - (p - R);
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            if (q == ta) acc[q] += w0 * inv;
-            if (q == tb) acc[q] += w1 * inv;
-        }
-    }
-}
-
-__device__ __forceinline__ float p3_from_left(float v) {    // value of lane - 1 (0 for lane 0)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float p3_from_right(float v) {   // value of lane + 1 (0 for lane 63)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
-}
 
 // One up branch for the lane's PXL columns at one row.  xw[rr][j]: image row br-2+rr, column px0-2+j.
 // Arow: this row's [ky][8] coefficients in LDS (same address for every lane: broadcast read).  Same evaluation order as
@@ -112,7 +79,9 @@ template <> struct P3Vec<2> { typedef float2 T; };
 // Every read-only operand is a `const float* __restrict__` kernel argument of its own: only then does hipcc turn the
 // wave-uniform reads of the plane's weights into scalar loads (pointers inside the geometry struct are not known to be
 // unaliased with `out`, and the per-row constants came back as 13 global_load_dwordx4 per lane and row).
-template <int T0, int T1, int PXL>
+// TRAIN: the training forward also keeps the branch values before merge_layer.0 (zcat, torch.cat order) and the bare merge convolution
+// (mraw): what the backward kernels of pyrpool_train.hip read.
+template <int T0, int T1, int PXL, bool TRAIN>
 __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __restrict__ x, const float* __restrict__ sw0,
                                                                 const float* __restrict__ sw1, const float* __restrict__ sw2,
                                                                 const float* __restrict__ de3, const float* __restrict__ de4,
@@ -121,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                                                                 const float* __restrict__ ep_scale,
                                                                 const float* __restrict__ ep_shift,
                                                                 const float* __restrict__ ep_alpha, int ep_ctot, int ep_coff,
-                                                                Pyr3Geom g, float* __restrict__ out) {
+                                                                Pyr3Geom g, float* __restrict__ out, float* __restrict__ zcat,
+                                                                float* __restrict__ mraw) {
     // The four waves of a workgroup take four consecutive planes of the SAME column block and row segment: the row tables (A) and
     // the channel-independent column tables (G) are identical for them, so they are computed once per workgroup (a quarter of
     // the column tasks per wave) into LDS; after the one barrier every wave folds its own plane's 3x3 weights into its
@@ -302,6 +272,14 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                     const float bot = dw0[i][j] * ecur[i][j][2] + dw1[i][j] * ecur[i][j][3];
                     bv[3 + i][j] = wy0c[i] * top + wy1c[i] * bot;
                 }
+            if (TRAIN && writer && br >= ys && br < ye) {          // rows ys-1 and ye belong to the neighbouring segments
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    float* zp = zcat + (((size_t)n * 5 + i) * g.P + c) * (size_t)h * w + (size_t)br * w + px0;
+                    if (PXL == 2) *reinterpret_cast<float2*>(zp) = make_float2(bv[i][0], bv[i][PXL - 1]);
+                    else zp[0] = bv[i][0];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -357,6 +335,11 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                 float* dst = opl + (size_t)y * w + px0;
                 if (PXL == 2) store_out2(dst, make_float2(v[0], v[PXL - 1]));
                 else dst[0] = v[0];
+                if (TRAIN) {
+                    float* rp = mraw + ((size_t)n * g.P + c) * (size_t)h * w + (size_t)y * w + px0;
+                    if (PXL == 2) *reinterpret_cast<float2*>(rp) = make_float2(acc[0][0], acc[0][PXL - 1]);
+                    else rp[0] = acc[0][0];
+                }
             }
         }
 #pragma unroll
@@ -364,35 +347,11 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
     }
 }
 
-// Host twin of bilinear_src's index part (same fp32 operations; -ffp-contract=off).
-static void p3_host_bilinear_idx(float scale, int dst, int in_size, int& i0, int& i1) {
-    const float real = scale * (float)dst;
-    int idx = (int)floorf(real);
-    if (idx > in_size - 1) idx = in_size - 1;
-    i0 = idx;
-    i1 = idx + ((idx < in_size - 1) ? 1 : 0);
-}
-
-// Smallest R such that every source of output p lies in [p-R, p+R] (one dimension); large when unsupported.
-static int p3_stencil_radius(int I, int S) {
-    const float sc = bilinear_scale(I, S);
-    int R = 0;
-    for (int p = 0; p < I; ++p) {
-        const int us = (int)(((int64_t)p * S) / I), ue = (int)((((int64_t)p + 1) * S + I - 1) / I);
-        for (int v = std::max(us - 1, 0); v <= std::min(ue, S - 1); ++v) {
-            int a, b;
-            p3_host_bilinear_idx(sc, v, I, a, b);
-            R = std::max(R, std::max(p - a, b - p));
-        }
-    }
-    return R;
-}
-
 // Returns MSPL_OK when launched, 1 when the shape is left to the LDS-tiled kernels, < 0 on error.
 int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                        const float* const* stage_w, const float* const* down_e, const float* br_scale,
                        const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
-                       hipStream_t stream) {
+                       hipStream_t stream, float* zcat) {
     static const int off = getenv("MSPL_PYR_STREAM") ? atoi(getenv("MSPL_PYR_STREAM")) == 0 : 0;
     // maps narrower than ~half a wave leave most lanes idle: the LDS-tiled form is faster there (18x30: 12 vs 17 us)
     static const int min_w = getenv("MSPL_PYR_STREAM_MINW") ? atoi(getenv("MSPL_PYR_STREAM_MINW")) : 40;
@@ -412,6 +371,8 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
     }
     const int PXL = w <= 62 ? 1 : 2;
     if (PXL == 2 && ((w & 1) || (((uintptr_t)out) & 7))) return 1;     // 8-byte stores
+    if (zcat && (!e.raw || e.ctot != P || e.coff != 0)) return 1;      // training forward: un-sliced destination + raw output
+    if (zcat && PXL == 2 && ((((uintptr_t)zcat) | ((uintptr_t)e.raw)) & 7)) return 1;
     Pyr3Geom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.P = P; g.h = h; g.w = w;
@@ -435,7 +396,9 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
     if (waves >= (1ll << 31)) return 1;
     g.total = (unsigned)waves;
     const dim3 grid((unsigned)(waves / 4)), blk(256);          // workgroup = 4 consecutive planes of one (column block, segment)
-#define MSPL_P3_LAUNCH(A, B, L) hipLaunchKernelGGL((pyrpool_stream_kernel<A, B, L>), grid, blk, 0, stream, x, stage_w[0], stage_w[1], stage_w[2], down_e[3], down_e[4], br_scale, br_shift, br_alpha, merge_w, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out)
+#define MSPL_P3_LAUNCH(A, B, L) do { \
+        if (zcat) hipLaunchKernelGGL((pyrpool_stream_kernel<A, B, L, true>), grid, blk, 0, stream, x, stage_w[0], stage_w[1], stage_w[2], down_e[3], down_e[4], br_scale, br_shift, br_alpha, merge_w, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out, zcat, e.raw); \
+        else hipLaunchKernelGGL((pyrpool_stream_kernel<A, B, L, false>), grid, blk, 0, stream, x, stage_w[0], stage_w[1], stage_w[2], down_e[3], down_e[4], br_scale, br_shift, br_alpha, merge_w, e.scale, e.shift, e.alpha, e.ctot, e.coff, g, out, (float*)nullptr, (float*)nullptr); } while (0)
     if (PXL == 1) {
         if (taps[0] == 3 && taps[1] == 3) MSPL_P3_LAUNCH(3, 3, 1);
         else if (taps[0] == 3) MSPL_P3_LAUNCH(3, 5, 1);

@@ -196,6 +196,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
+_FUSED_PYR_TRAIN = os.environ.get('MSPL_FUSED_PYR_TRAIN', '1') != '0'    # pyramid body as one autograd node (frozen BatchNorm)
 
 
 def _conv_bn_act(x, conv, bn, alpha=None, pre_add=None, residual=None):
@@ -638,10 +639,30 @@ class EfficientPyrPool(nn.Module):
         return ops.pyrpool_fused(x, sizes, stage_ws, down_es, bscale, bshift, br[1].weight, mcbr.cbr[0].weight,
                                  mcbr.epi())
 
+    def _body_train_fused(self, x, sizes):
+        """Branches + merge_layer.0/1/2 as one autograd node (autograd.PyrBodyFn); frozen BatchNorms only."""
+        bn0, act0 = self.merge_layer[0].br[0], self.merge_layer[0].br[1]
+        mcbr = self.merge_layer[2].cbr
+        conv2, bn2, act2 = mcbr[0], mcbr[1], mcbr[2]
+
+        def fold(bn):
+            scale, shift = train_fold(bn)
+            return {'scale': scale, 'shift': shift, 'mean': bn.running_mean, 'inv': ag.frozen_bn_inv(bn)}
+        return ag.PyrBodyFn.apply(x, sizes, fold(bn0), fold(bn2), bn0.weight, bn0.bias, act0.weight, conv2.weight, bn2.weight,
+                                  bn2.bias, act2.weight, *[st.weight for st in self.stages])
+
     def _forward_train(self, x):
         x = self.projection_layer(x)
         height, width = x.shape[2:]
         P = self.proj_planes
+        sizes = self.branch_sizes(height, width)
+        frozen = not (self.merge_layer[0].br[0].training or self.merge_layer[2].cbr[1].training)
+        if _FUSED_PYR_TRAIN and frozen and ag.pyr_body_fits(x.shape, sizes):
+            out = self._body_train_fused(x, sizes)
+            conv = self.merge_layer[3]
+            if self.last_layer_br:
+                return _conv_bn_act(out, conv, self.br.br[0], self.br.br[1].weight)
+            return ag.conv_affine_prelu(out, conv.weight, 1, 1, None, conv.bias, None)
         hs = []
         xs = ag.fan_out(x, len(self.stages))               # one alias per branch: their gradients are summed by one launch
         for xb, stage, sc, (h_s, w_s) in zip(xs, self.stages, self.scales, self.branch_sizes(height, width)):

@@ -408,3 +408,62 @@ def test_fan_out_fn_sums_branch_gradients_in_one_launch():
     b = ag.fan_out(z, 2)
     (b[0] * 2 + b[1] * 3).sum().backward()
     assert torch.equal(z.grad, torch.full_like(z, 5.0))
+
+
+def _pyr_module(in_planes, out_planes, last_layer_br, seed):
+    from mspl_amd import layers
+    m = layers.EfficientPyrPool(in_planes, 16, out_planes, last_layer_br=last_layer_br)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 24, 16, 30, True), (2, 24, 5, 32, 60, False), (1, 16, 13, 64, 120, False),
+                                 (2, 16, 20, 18, 34, True), (1, 48, 32, 40, 72, True), (3, 16, 5, 17, 33, False),
+                                 (1, 16, 8, 8, 12, True)])
+def test_fused_pyramid_training_equals_node_per_op(cfg):
+    """autograd.PyrBodyFn (one fused forward launch, mspl_pyrpool_merge_bwd + mspl_pyrpool_branch_bwd in the backward) against the
+    node-per-op training path it replaces: output, input gradient and the gradient of every parameter of the module."""
+    from mspl_amd import autograd as ag, layers
+    N, cin, cout, h, w, last_br = cfg
+    m = _pyr_module(cin, cout, last_br, 77)
+    assert ag.pyr_body_fits((N, 16, h, w), m.branch_sizes(h, w))
+    x = rnd(N, cin, h, w, seed=5).to(DEV)
+    go = rnd(N, cout, h, w, seed=6).to(DEV)
+    res = {}
+    for fused in (False, True):
+        prev = layers._FUSED_PYR_TRAIN
+        layers._FUSED_PYR_TRAIN = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            for p in m.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                y = m(xi)
+                y.backward(go)
+            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            layers._FUSED_PYR_TRAIN = prev
+    close(res[True][0], res[False][0], atol=2e-5, rtol=1e-4)
+    close(res[True][1], res[False][1], atol=5e-5, rtol=1e-3)
+    for k in res[False][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
+
+
+def test_fused_pyramid_training_with_gradient_sinks():
+    """Inside grad_sinks() the fused node adds its parameter gradients straight into existing .grad buffers (the flat optimizer
+    buffers of the train step): same values as the returned-gradient form, accumulated on top of what the buffers held."""
+    from mspl_amd import autograd as ag
+    m = _pyr_module(32, 24, True, 78)
+    x = rnd(2, 32, 16, 30, seed=8).to(DEV)
+    go = rnd(2, 24, 16, 30, seed=9).to(DEV)
+    with torch.enable_grad():
+        m(x).backward(go)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 0.5)
+    with torch.enable_grad(), ag.grad_sinks():
+        m(x).backward(go)
+    for k, p in m.named_parameters():
+        close(p.grad - 0.5, ref[k], atol=2e-4, rtol=2e-3)
