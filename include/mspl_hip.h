@@ -318,6 +318,14 @@ int mspl_gap_gate_bwd_accum(const float* ggate, const float* gate, const float* 
  * out is branch-major (4,N,n,HW). */
 int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream);
 
+/* br_after_cat's BatchNorm + PReLU backward fused with mspl_hff_suffix_sum (the EESP block between conv_1x1_exp and the four
+ * depthwise branches, nn_layers/eesp.py:76-80): z (N,4n,HW) = K2's raw concatenation, gy = dL/d(PReLU(BN(z))), scale/shift/alpha
+ * (4n; NULL = identity / no activation); out (4,N,n,HW) branch-major = suffix sums of gy * (u > 0 ? 1 : alpha) * scale;
+ * gscale/gshift/galpha (4n) ACCUMULATED, with bn_mean/bn_inv (4n) they receive d gamma / d beta of the frozen BatchNorm. */
+int mspl_hff_bn_prelu_suffix_bwd(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                 const float* bn_mean, const float* bn_inv, int32_t N, int32_t n, int32_t HW, float* out,
+                                 float* gscale, float* gshift, float* galpha, void* stream);
+
 /* K11  fused PixelwiseKLD + UncertaintyWeightedSegmentationLoss (loss_fns/segmentation_loss.py:146-189) as used at
  *      uest_seg_multi_os.py:1020-1023:  loss = ce_scale * mean_pix(w[t] * -log_softmax(pred+0.5aux)[t] * exp(-kld))
  *      + mean_pix(kld), kld NOT detached.  class_weights: C floats with the ignore class already zeroed; the mean runs

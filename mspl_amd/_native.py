@@ -78,6 +78,7 @@ SIGNATURES = {
     'mspl_plane_broadcast': [c_f32p, c_i32, c_i32, ctypes.c_float, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_gap_gate_bwd': [c_f32p] * 4 + [c_i32] * 3 + [c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_gap_gate_bwd_accum': [c_f32p] * 4 + [c_i32] * 3 + [c_f32p, c_f32p, ctypes.c_void_p],
+    'mspl_hff_bn_prelu_suffix_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 4 + [ctypes.c_void_p],
     'mspl_hff_suffix_sum': [c_f32p, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_uw_loss_fwd_bwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p, c_i32, c_i32, c_i32, ctypes.c_float] + [c_f32p] * 4
                             + [ctypes.c_void_p],

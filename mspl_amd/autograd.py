@@ -328,6 +328,99 @@ class FanOutFn(torch.autograd.Function):
         return out, None
 
 
+def _stack4(ws):
+    """(4, n, 3, 3) tensor of the four depthwise branch weights: a VIEW when they sit back to back in one storage (the flat
+    parameter buffer of FlatAdam / FlatSGD lays consecutive parameters out contiguously), else a torch.stack copy."""
+    w0 = ws[0]
+    n, step = w0.shape[0], w0.numel() * w0.element_size()
+    try:
+        base = w0.untyped_storage().data_ptr()
+        if all(w.is_contiguous() and w.untyped_storage().data_ptr() == base and w.data_ptr() == w0.data_ptr() + k * step
+               for k, w in enumerate(ws)):
+            return torch.as_strided(w0.detach(), (4, n, 3, 3), (n * 9, 9, 3, 1))
+    except RuntimeError:
+        pass
+    return torch.stack([w.reshape(-1, 3, 3) for w in ws]).contiguous()
+
+
+class EESPFn(torch.autograd.Function):
+    """A whole EESP block (nn_layers/eesp.py:60-93) with frozen BatchNorms as ONE autograd node: proj_1x1 (grouped 1x1 + BN + PReLU)
+    -> four dilated depthwise 3x3 + hierarchical add + concat (K2) -> br_after_cat (BN + PReLU) -> conv_1x1_exp (grouped 1x1 + BN)
+    [+ input residual, module_act].  Same forward kernels as the node-per-op form; the backward owns its buffers, so
+      * the residual link's gradient is added by the epilogue of the projection's data-gradient convolution (autograd summed the two
+        gradients of the block input with an ATen kernel per block),
+      * br_after_cat's BatchNorm/PReLU backward and the HFF suffix sum are one pass (mspl_hff_bn_prelu_suffix_bwd),
+      * the four branch weights are passed as one view of the flat parameter buffer (no torch.stack per block and step)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, fp, fb, fe, wp, gp, bp, ap, w0, w1, w2, w3, g2, b2, a2, we, ge, be, am):
+        x, wp, we = _c(x), _c(wp), _c(we)
+        stride, dil, groups, residual = cfg['stride'], cfg['dil'], cfg['groups'], cfg['residual']
+        N, Cin, H, W = x.shape
+        n = wp.shape[0]
+        c1 = torch.empty((N, n, H, W), device=x.device, dtype=torch.float32)
+        o1 = ops.conv1x1(x, wp, groups, Epi(fp['scale'], fp['shift'], ap, raw_out=c1))
+        w4 = _stack4((w0, w1, w2, w3))
+        z2 = ops.eesp_dw_hff(o1, w4, dil, stride)
+        y2 = ops.pointwise(z2, Epi(fb['scale'], fb['shift'], a2))
+        Cout = we.shape[0]
+        c3 = torch.empty((N, Cout) + tuple(z2.shape[2:]), device=x.device, dtype=torch.float32)
+        y = ops.conv1x1(y2, we, groups, Epi(fe['scale'], fe['shift'], am, residual=x if residual else None, raw_out=c3))
+        ctx.save_for_backward(x, c1, o1, z2, y2, c3, w4, wp, we, ap, a2, am, fp['scale'], fp['shift'], fp['mean'], fp['inv'],
+                              fb['scale'], fb['shift'], fb['mean'], fb['inv'], fe['scale'], fe['shift'], fe['mean'], fe['inv'])
+        ctx.cfg = cfg
+        ctx.wshape = tuple(w0.shape)
+        ctx.sinks = {'wp': _sink(wp), 'p': (_sink(gp), _sink(bp), _sink(ap)), 'w4': [_sink(t) for t in (w0, w1, w2, w3)],
+                     'b': (_sink(g2), _sink(b2), _sink(a2)), 'we': _sink(we), 'e': (_sink(ge), _sink(be), _sink(am))}
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x, c1, o1, z2, y2, c3, w4, wp, we, ap, a2, am, sp, hp, mp, ip, sb, hb, mb, ib, se, he, me, ie) = ctx.saved_tensors
+        cfg, sk = ctx.cfg, ctx.sinks
+        stride, dil, groups, residual = cfg['stride'], cfg['dil'], cfg['groups'], cfg['residual']
+        gy = _c(gy)
+        N, Cin, H, W = x.shape
+        n = wp.shape[0]
+        Ho, Wo = z2.shape[2:]
+        dev = x.device
+        # conv_1x1_exp's BatchNorm (+ residual, module_act) and the convolution itself
+        gc3, gres, r_ge, r_be, r_am = _affine_backward(c3, se, he, am, None, x if residual else None, me, ie, True, sk['e'], gy)
+        gy2, gwe = _conv_backward(y2, we, (1, groups, 1), sk['we'], gc3, True, True)
+        # br_after_cat backward + HFF suffix sum
+        C4 = 4 * n
+        s_g2, s_b2, s_a2 = sk['b']
+        acc = torch.zeros(3, C4, device=dev) if (s_g2 is None or s_b2 is None or s_a2 is None) else None
+        d_g2 = s_g2 if s_g2 is not None else acc[0]
+        d_b2 = s_b2 if s_b2 is not None else acc[1]
+        d_a2 = s_a2 if s_a2 is not None else acc[2]
+        gs = torch.empty((4, N, n, Ho, Wo), device=dev, dtype=torch.float32)
+        check(lib.mspl_hff_bn_prelu_suffix_bwd(_p(z2), _p(gy2), _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, Ho * Wo, _p(gs),
+                                               _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
+        # the four depthwise branches
+        go1 = torch.empty_like(o1)
+        wsinks = sk['w4']
+        tmp = torch.zeros((4,) + ctx.wshape, device=dev, dtype=torch.float32) if any(t is None for t in wsinks) else None
+        dst = [wsinks[k] if wsinks[k] is not None else tmp[k] for k in range(4)]
+        ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dst])
+        dil_c = (ctypes.c_int32 * 4)(*dil)
+        check(lib.mspl_eesp_dw_bwd(_p(gs), _p(o1), _p(w4), dil_c, stride, N, n, H, W, _p(go1), ptrs, _stream()))
+        # proj_1x1's BatchNorm + PReLU and the convolution; the residual link's gradient rides on the data gradient's epilogue
+        gc1, _, r_gp, r_bp, r_ap = _affine_backward(c1, sp, hp, ap, None, None, mp, ip, True, sk['p'], go1)
+        gx = gwp = None
+        if ctx.needs_input_grad[0]:
+            wt = _transposed_weights(wp, groups, 1)
+            gx = ops.conv1x1(gc1, wt, groups, Epi(residual=gres) if gres is not None else None)
+        s_wp = sk['wp']
+        gwp = torch.empty_like(wp) if s_wp is None else None
+        check(lib.mspl_conv_bwd_weight(_p(gc1), _p(x), N, Cin, n, groups, H, W, 1, 1, 1, 0 if s_wp is None else 1,
+                                       _p(gwp if s_wp is None else s_wp), _stream()))
+        ret = lambda sink, t: None if sink is not None else t          # noqa: E731
+        gws = [ret(wsinks[k], tmp[k] if tmp is not None else None) for k in range(4)]
+        return (gx, None, None, None, None, gwp, r_gp, r_bp, r_ap, *gws, ret(s_g2, d_g2), ret(s_b2, d_b2), ret(s_a2, d_a2),
+                gwe, r_ge, r_be, r_am if am is not None else None)
+
+
 class PyrBodyFn(torch.autograd.Function):
     """The EfficientPyrPool body between projection_layer and the last 1x1 (nn_layers/efficient_pyramid_pool.py:39-58: the five
     branches, merge_layer.0 BatchNorm + PReLU over the concatenation, Shuffle, merge_layer.2 grouped 3x3 + BatchNorm + PReLU) as ONE

@@ -36,9 +36,15 @@ struct MbGeom {
     float *g_m_scale, *g_m_shift, *g_m_alpha;                            // P
 };
 
+// (the plane's constants come through `const float* __restrict__` kernel arguments of their own: only then does hipcc read the
+// wave-uniform values with scalar loads into SGPRs -- through the geometry struct they cost ~75 VGPRs and a wave per SIMD)
 template <int NB>
 __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mraw,
-                                                            const float* __restrict__ zcat, MbGeom g, float* __restrict__ gt) {
+                                                            const float* __restrict__ zcat, const float* __restrict__ k_merge_w,
+                                                            const float* __restrict__ k_br_scale, const float* __restrict__ k_br_shift,
+                                                            const float* __restrict__ k_br_alpha, const float* __restrict__ k_m_scale,
+                                                            const float* __restrict__ k_m_shift, const float* __restrict__ k_m_alpha,
+                                                            MbGeom g, float* __restrict__ gt) {
     __shared__ __attribute__((aligned(16))) float G[(MB_TH + 2) * MB_GS];
     constexpr int NRED = NB * 12 + 3;
     __shared__ float red[4][NRED];
@@ -52,17 +58,17 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
     const size_t plane = (size_t)h * w;
     const float* gyp = gy + ((size_t)n * g.P + c) * plane;
     const float* mp = mraw + ((size_t)n * g.P + c) * plane;
-    const float msc = g.m_scale[c], msh = g.m_shift[c];
-    const bool mact = g.m_alpha != nullptr;
-    const float mal = mact ? g.m_alpha[c] : 1.f;
+    const float msc = k_m_scale[c], msh = k_m_shift[c];
+    const bool mact = k_m_alpha != nullptr;
+    const float mal = mact ? k_m_alpha[c] : 1.f;
     const bool vec = (w & 3) == 0;
 
     float wm[NB][9], bs[NB], bh[NB], ba[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wm[i][k] = g.merge_w[((size_t)c * NB + i) * 9 + k];
-        bs[i] = g.br_scale[i * g.P + c];  bh[i] = g.br_shift[i * g.P + c];  ba[i] = g.br_alpha[i * g.P + c];
+        for (int k = 0; k < 9; ++k) wm[i][k] = k_merge_w[((size_t)c * NB + i) * 9 + k];
+        bs[i] = k_br_scale[i * g.P + c];  bh[i] = k_br_shift[i * g.P + c];  ba[i] = k_br_alpha[i * g.P + c];
     }
     float dw[NB][9], a_sc[NB], a_sh[NB], a_al[NB];
 #pragma unroll
@@ -76,23 +82,41 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
     for (int tx = 0; tx < g.tiles_x; ++tx) {
         const int x0 = tx * MB_TW;
         // ---- g_m = dL/dm on the tile + a one-pixel halo (zero outside the image): BatchNorm/PReLU backward of merge_layer.2
-        for (int t = tid; t < (MB_TH + 2) * (MB_TW + 2); t += 256) {
-            const int R = t / (MB_TW + 2), Cq = t - R * (MB_TW + 2);
-            const int py = y0 - 1 + R, px = x0 - 1 + Cq;
-            float v = 0.f;
-            if (py >= 0 && py < h && px >= 0 && px < w) {
-                const float gv = gyp[(size_t)py * w + px], mv = mp[(size_t)py * w + px];
-                const float u = mv * msc + msh;
-                const bool pos = !mact || u > 0.f;
-                const float gz = pos ? gv : mal * gv;
-                v = gz * msc;
-                if (R >= 1 && R <= MB_TH && Cq >= 1 && Cq <= MB_TW) {        // the tile's own pixels: every pixel exactly once
-                    q_sc += gz * mv;
-                    q_sh += gz;
-                    if (!pos) q_al += gv * u;
+        {
+            constexpr int NST = ((MB_TH + 2) * (MB_TW + 2) + 255) / 256;       // 5 elements per thread
+            float gvv[NST], mvv[NST];
+            // all loads of the tile first, then the arithmetic (interleaved, hipcc waits for each pair before the next is issued)
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int t = tid + 256 * k;
+                const int R = t / (MB_TW + 2), Cq = t - R * (MB_TW + 2);
+                const int py = y0 - 1 + R, px = x0 - 1 + Cq;
+                const bool in = t < (MB_TH + 2) * (MB_TW + 2) && py >= 0 && py < h && px >= 0 && px < w;
+                const size_t o = (size_t)min(max(py, 0), h - 1) * w + min(max(px, 0), w - 1);
+                const float a = gyp[o], b2 = mp[o];
+                gvv[k] = in ? a : 0.f;
+                mvv[k] = b2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int t = tid + 256 * k;
+                if (t < (MB_TH + 2) * (MB_TW + 2)) {
+                    const int R = t / (MB_TW + 2), Cq = t - R * (MB_TW + 2);
+                    const int py = y0 - 1 + R, px = x0 - 1 + Cq;
+                    const bool in = py >= 0 && py < h && px >= 0 && px < w;
+                    const float gv = gvv[k], mv = mvv[k];
+                    const float u = mv * msc + msh;
+                    const bool pos = !mact || u > 0.f;
+                    const float gz = pos ? gv : mal * gv;                       // gv = 0 outside the image
+                    if (in && R >= 1 && R <= MB_TH && Cq >= 1 && Cq <= MB_TW) {  // the tile's own pixels: every pixel exactly once
+                        q_sc += gz * mv;
+                        q_sh += gz;
+                        if (!pos) q_al += gv * u;
+                    }
+                    G[R * MB_GS + Cq] = gz * msc;
                 }
             }
-            G[R * MB_GS + Cq] = v;
         }
         __syncthreads();
         const int y = y0 + r, xb = x0 + s4;
@@ -567,7 +591,7 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream_kernel(const float*
         for (int ky = 0; ky < 3; ++ky) {
             const float4 t4 = *reinterpret_cast<const float4*>(Ap + ky * 8);
             A[ky][0] = t4.x; A[ky][1] = t4.y; A[ky][2] = t4.z;
-            if (T > 3) { A[ky][3] = t4.w; A[ky][T - 1] = Ap[ky * 8 + 4]; }
+            if constexpr (T > 3) { A[ky][3] = t4.w; A[ky][T - 1] = Ap[ky * 8 + 4]; }
         }
         // ---- gx: row p of gt through the transposed column stencils, then scattered over the T rows it touches
 #pragma unroll
@@ -750,23 +774,28 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
     const size_t pbase = ((size_t)n * g.P + c) * pl;
     const bool cin = px0 >= 0 && px0 < w;                // both of the lane's columns are inside or outside together (w, px0 even)
     const unsigned coff = (unsigned)min(max(px0, 0), w - 2) * 4u;
-    auto load2 = [&](const float* base, int r, float (&v)[2]) {
-        const bool rin = r >= 0 && r < h;                                                   // uniform
+    // Rows / columns outside the image: the address is clamped and the value multiplied by 0 WHEN IT IS CONSUMED.  (With a select
+    // hipcc puts the load behind a branch and waits for it on the spot; with the multiply next to the load it waits there too: either
+    // way one exposed memory round trip per row and operand.  Raw values requested at the top of an iteration, masked at its end.)
+    const float cmask = cin ? 1.f : 0.f;
+    auto rmask = [&](int r) { return (r >= 0 && r < h) ? cmask : 0.f; };
+    auto load_raw = [&](const float* base, int r) {
         const char* row = reinterpret_cast<const char*>(base + pbase + (size_t)min(max(r, 0), h - 1) * w);
-        const float2 t = *reinterpret_cast<const float2*>(row + coff);
-        v[0] = (rin && cin) ? t.x : 0.f;
-        v[1] = (rin && cin) ? t.y : 0.f;
+        return *reinterpret_cast<const float2*>(row + coff);
+    };
+    auto load2 = [&](const float* base, int r, float (&v)[2]) {      // prologue only
+        const float2 t = load_raw(base, r);
+        const float m = rmask(r);
+        v[0] = t.x * m;  v[1] = t.y * m;
     };
 
     float xw[TW][2];                        // x rows p-RM .. p+RM, own columns
 #pragma unroll
     for (int q = 0; q < TW; ++q) load2(x, ys - 2 * RM + q, xw[q]);
-    float xn[2];
-    load2(x, ys + 1, xn);
-    float ga[2], gb[2], gc[2], gan[2], gbn[2], gcn[2];
-    load2(gt0, ys - RM, ga);  load2(gt0, ys - RM + 1, gan);
-    if (NUP > 1) { load2(gt1, ys - RM, gb);  load2(gt1, ys - RM + 1, gbn); }
-    if (SAME) { load2(gt2, ys - RM, gc);  load2(gt2, ys - RM + 1, gcn); }
+    float ga[2], gb[2], gc[2];
+    load2(gt0, ys - RM, ga);
+    if (NUP > 1) load2(gt1, ys - RM, gb);
+    if (SAME) load2(gt2, ys - RM, gc);
     float gacc[TW][2];
 #pragma unroll
     for (int q = 0; q < TW; ++q) { gacc[q][0] = 0.f; gacc[q][1] = 0.f; }
@@ -777,6 +806,10 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
 #pragma unroll 1
     for (int p = ys - RM; p < ye + RM; ++p) {
         const bool own_row = p >= ys && p < ye;                  // uniform
+        // next row's operands: requested now, consumed (masked) at the end of this iteration
+        const float2 xr = load_raw(x, p + 1 + RM), gar = load_raw(gt0, p + 1);
+        const float2 gbr = NUP > 1 ? load_raw(gt1, p + 1) : make_float2(0.f, 0.f);
+        const float2 gcr = SAME ? load_raw(gt2, p + 1) : make_float2(0.f, 0.f);
         // ---- one up-sampled branch: K_kx, then gx rows and (owned rows) the weight gradient
         auto up_branch = [&](auto tt, const float (&G)[3][2][decltype(tt)::value], const float* Ab, const float* wp, const float (&gv)[2],
                              float (&dw)[9]) {
@@ -786,7 +819,7 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
             for (int ky = 0; ky < 3; ++ky) {
                 const float4 t4 = *reinterpret_cast<const float4*>(Ab + ky * 8);
                 A[ky][0] = t4.x; A[ky][1] = t4.y; A[ky][2] = t4.z;
-                if (T > 3) { A[ky][3] = t4.w; A[ky][T - 1] = Ab[ky * 8 + 4]; }
+                if constexpr (T > 3) { A[ky][3] = t4.w; A[ky][T - 1] = Ab[ky * 8 + 4]; }
             }
             float hk[3][2];
 #pragma unroll
@@ -857,22 +890,24 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
         if (r >= ys && writer) {
             const size_t o = pbase + (size_t)r * w + px0;
             float v0 = gacc[0][0], v1 = gacc[0][1];
-            if (add0) { const float2 t = *reinterpret_cast<const float2*>(add0 + o); v0 += t.x; v1 += t.y; }
-            if (add1) { const float2 t = *reinterpret_cast<const float2*>(add1 + o); v0 += t.x; v1 += t.y; }
+            if (add0 && add1) {
+                const float2 t = *reinterpret_cast<const float2*>(add0 + o), t2 = *reinterpret_cast<const float2*>(add1 + o);
+                v0 += t.x + t2.x;  v1 += t.y + t2.y;
+            } else if (add0) {
+                const float2 t = *reinterpret_cast<const float2*>(add0 + o);
+                v0 += t.x;  v1 += t.y;
+            }
             *reinterpret_cast<float2*>(gx + o) = make_float2(v0, v1);
         }
 #pragma unroll
         for (int q = 0; q < TW - 1; ++q) { gacc[q][0] = gacc[q + 1][0]; gacc[q][1] = gacc[q + 1][1]; xw[q][0] = xw[q + 1][0]; xw[q][1] = xw[q + 1][1]; }
         gacc[TW - 1][0] = 0.f;  gacc[TW - 1][1] = 0.f;
-        xw[TW - 1][0] = xn[0];  xw[TW - 1][1] = xn[1];
-        ga[0] = gan[0];  ga[1] = gan[1];
-        if (NUP > 1) { gb[0] = gbn[0];  gb[1] = gbn[1]; }
-        if (SAME) { gc[0] = gcn[0];  gc[1] = gcn[1]; }
-        if (p + 1 < ye + RM) {
-            load2(x, p + 2 + RM, xn);
-            load2(gt0, p + 2, gan);
-            if (NUP > 1) load2(gt1, p + 2, gbn);
-            if (SAME) load2(gt2, p + 2, gcn);
+        {
+            const float mx = rmask(p + 1 + RM), mg = rmask(p + 1);
+            xw[TW - 1][0] = xr.x * mx;  xw[TW - 1][1] = xr.y * mx;
+            ga[0] = gar.x * mg;  ga[1] = gar.y * mg;
+            if (NUP > 1) { gb[0] = gbr.x * mg;  gb[1] = gbr.y * mg; }
+            if (SAME) { gc[0] = gcr.x * mg;  gc[1] = gcr.y * mg; }
         }
     }
     auto flush = [&](float (&dw)[9], float* gw) {
@@ -984,11 +1019,11 @@ extern "C" int mspl_pyrpool_merge_bwd(const float* gy, const float* mraw, const 
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t s = (hipStream_t)stream;
     switch (nb) {
-        case 1: hipLaunchKernelGGL(pyr_merge_bwd_kernel<1>, grid, blk, 0, s, gy, mraw, zcat, g, gt); break;
-        case 2: hipLaunchKernelGGL(pyr_merge_bwd_kernel<2>, grid, blk, 0, s, gy, mraw, zcat, g, gt); break;
-        case 3: hipLaunchKernelGGL(pyr_merge_bwd_kernel<3>, grid, blk, 0, s, gy, mraw, zcat, g, gt); break;
-        case 4: hipLaunchKernelGGL(pyr_merge_bwd_kernel<4>, grid, blk, 0, s, gy, mraw, zcat, g, gt); break;
-        default: hipLaunchKernelGGL(pyr_merge_bwd_kernel<5>, grid, blk, 0, s, gy, mraw, zcat, g, gt); break;
+        case 1: hipLaunchKernelGGL(pyr_merge_bwd_kernel<1>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 2: hipLaunchKernelGGL(pyr_merge_bwd_kernel<2>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 3: hipLaunchKernelGGL(pyr_merge_bwd_kernel<3>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 4: hipLaunchKernelGGL(pyr_merge_bwd_kernel<4>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        default: hipLaunchKernelGGL(pyr_merge_bwd_kernel<5>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
     }
     MSPL_CHECK_LAUNCH("pyrpool_merge_bwd");
     return MSPL_OK;

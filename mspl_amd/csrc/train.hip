@@ -584,6 +584,92 @@ __global__ __launch_bounds__(256) void hff_suffix_kernel(const float* __restrict
     out[idx] = g0; out[total + idx] = g1; out[2 * total + idx] = g2; out[3 * total + idx] = g3;
 }
 
+// ---- br_after_cat's BatchNorm + PReLU backward and the suffix sum in one pass (the EESP block's backward between conv_1x1_exp and
+//      the four depthwise branches, nn_layers/eesp.py:76-80): z (N,4n,HW) = the raw concatenation K2 produced, gy = dL/d(PReLU(BN(z))).
+//      gc = gy * (u > 0 ? 1 : alpha) * scale; out_k = sum_{m >= k} gc_m, branch-major (4,N,n,HW); per-channel sums -> d gamma / d beta /
+//      d alpha (frozen BatchNorm transform as in affine_prelu_bwd_kernel).  One workgroup per (image, j, chunk): the four channels
+//      k*n + j of a pixel are needed together.
+__global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ alpha, const float* __restrict__ bn_mean,
+                                                                  const float* __restrict__ bn_inv, int n, int HW, int chunks,
+                                                                  int64_t total, float* __restrict__ out, float* __restrict__ gscale,
+                                                                  float* __restrict__ gshift, float* __restrict__ galpha) {
+    int b = blockIdx.x;
+    const int chunk = b % chunks;  b /= chunks;
+    const int j = b % n;
+    const int img = b / n;
+    float sc[4], sh[4], al[4], s_sc[4], s_sh[4], s_al[4];
+    const bool act = alpha != nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ch = k * n + j;
+        sc[k] = scale ? scale[ch] : 1.f;  sh[k] = shift ? shift[ch] : 0.f;  al[k] = act ? alpha[ch] : 1.f;
+        s_sc[k] = s_sh[k] = s_al[k] = 0.f;
+    }
+    const size_t in0 = ((size_t)img * 4 * n + j) * (size_t)HW, kin = (size_t)n * HW;
+    const size_t out0 = ((size_t)img * n + j) * (size_t)HW;
+    auto one = [&](int k, float zv, float g) {
+        const float u = zv * sc[k] + sh[k];
+        const bool pos = !act || u > 0.f;
+        const float gz = pos ? g : al[k] * g;
+        if (!pos) s_al[k] += g * u;
+        s_sc[k] += gz * zv;
+        s_sh[k] += gz;
+        return gz * sc[k];
+    };
+    if ((HW & 3) == 0) {
+        const int q4 = HW >> 2, per = (q4 + chunks - 1) / chunks;
+        const int q0 = chunk * per, q1 = min(q4, q0 + per);
+        for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+            float4 zv[4], gv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                zv[k] = reinterpret_cast<const float4*>(z + in0 + k * kin)[q];
+                gv[k] = reinterpret_cast<const float4*>(gy + in0 + k * kin)[q];
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                acc.x += one(k, zv[k].x, gv[k].x);  acc.y += one(k, zv[k].y, gv[k].y);
+                acc.z += one(k, zv[k].z, gv[k].z);  acc.w += one(k, zv[k].w, gv[k].w);
+                reinterpret_cast<float4*>(out + (size_t)k * total + out0)[q] = acc;
+            }
+        }
+    } else {
+        const int per = (HW + chunks - 1) / chunks;
+        const int p0 = chunk * per, p1 = min(HW, p0 + per);
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                acc += one(k, z[in0 + k * kin + p], gy[in0 + k * kin + p]);
+                out[(size_t)k * total + out0 + p] = acc;
+            }
+        }
+    }
+    __shared__ float part[12][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v[3] = {s_sc[k], s_sh[k], s_al[k]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[t] += __shfl_down(v[t], o, 64);
+            if ((threadIdx.x & 63) == 0) part[k * 3 + t][threadIdx.x >> 6] = v[t];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x, ch = k * n + j;
+        auto tot = [&](int i) { return (part[i][0] + part[i][1]) + (part[i][2] + part[i][3]); };
+        const float t_sc = tot(k * 3), t_sh = tot(k * 3 + 1);
+        if (gscale) atomicAdd(&gscale[ch], bn_inv ? (t_sc - bn_mean[ch] * t_sh) * bn_inv[ch] : t_sc);
+        if (gshift) atomicAdd(&gshift[ch], t_sh);
+        if (galpha && act) atomicAdd(&galpha[ch], tot(k * 3 + 2));
+    }
+}
+
 static int conv_geom(const char* who, int N, int Cin, int Cout, int groups, int H, int W, int K, int stride, int dil, ConvGeom& g) {
     MSPL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && groups > 0 && H > 0 && W > 0, MSPL_ERR_BAD_SHAPE, "%s: bad shape", who);
     MSPL_REQUIRE(Cin % groups == 0 && Cout % groups == 0, MSPL_ERR_BAD_SHAPE, "%s: channels not divisible by groups", who);
@@ -905,5 +991,22 @@ extern "C" int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t
     const int64_t total = (int64_t)N * n * HW;
     hipLaunchKernelGGL(hff_suffix_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, g, n, HW, out, total);
     MSPL_CHECK_LAUNCH("hff_suffix_sum");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_hff_bn_prelu_suffix_bwd(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                            const float* bn_mean, const float* bn_inv, int32_t N, int32_t n, int32_t HW, float* out,
+                                            float* gscale, float* gshift, float* galpha, void* stream) {
+    MSPL_REQUIRE(z && gy && out, MSPL_ERR_NULL_POINTER, "hff_bn_prelu_suffix_bwd: null pointer");
+    MSPL_REQUIRE((bn_mean == nullptr) == (bn_inv == nullptr), MSPL_ERR_NULL_POINTER, "hff_bn_prelu_suffix_bwd: mean / inv must come together");
+    MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_bn_prelu_suffix_bwd: bad shape");
+    const int64_t total = (int64_t)N * n * HW;
+    int chunks = 1;
+    while ((int64_t)N * n * chunks < 2048 && HW / (chunks * 2) >= 1024) chunks *= 2;
+    const int64_t blocks = (int64_t)N * n * chunks;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "hff_bn_prelu_suffix_bwd: grid too large");
+    hipLaunchKernelGGL(hff_bn_prelu_suffix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, scale, shift, alpha,
+                       bn_mean, bn_inv, n, HW, chunks, total, out, gscale, gshift, galpha);
+    MSPL_CHECK_LAUNCH("hff_bn_prelu_suffix_bwd");
     return MSPL_OK;
 }

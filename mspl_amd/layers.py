@@ -196,6 +196,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
+_FUSED_EESP_TRAIN = os.environ.get('MSPL_FUSED_EESP_TRAIN', '1') != '0'  # EESP block as one autograd node (frozen BatchNorm)
 _FUSED_PYR_TRAIN = os.environ.get('MSPL_FUSED_PYR_TRAIN', '1') != '0'    # pyramid body as one autograd node (frozen BatchNorm)
 
 
@@ -408,6 +409,19 @@ class EESP(nn.Module):
                                Epi(scale, shift, self.br_after_cat.act.weight))
 
     def _forward_train(self, input):
+        pj, br, exp = self.proj_1x1, self.br_after_cat, self.conv_1x1_exp
+        if _FUSED_EESP_TRAIN and not (pj.bn.training or br.bn.training or exp.bn.training):
+            # the whole block as one autograd node (frozen BatchNorms): autograd.EESPFn
+            def fold(bn):
+                scale, shift = train_fold(bn)
+                return {'scale': scale, 'shift': shift, 'mean': bn.running_mean, 'inv': ag.frozen_bn_inv(bn)}
+            strided_avg = self.stride == 2 and self.downAvg
+            residual = (not strided_avg) and self.stride == 1 and exp.conv.out_channels == input.shape[1]
+            cfg = {'stride': self.stride, 'dil': tuple(self.dilations), 'groups': pj.conv.groups, 'residual': residual}
+            ws = [m.conv.weight for m in self.spp_dw]
+            return ag.EESPFn.apply(input, cfg, fold(pj.bn), fold(br.bn), fold(exp.bn), pj.conv.weight, pj.bn.weight, pj.bn.bias,
+                                   pj.act.weight, ws[0], ws[1], ws[2], ws[3], br.bn.weight, br.bn.bias, br.act.weight,
+                                   exp.conv.weight, exp.bn.weight, exp.bn.bias, None if strided_avg else self.module_act.weight)
         o1 = self.proj_1x1(input)
         cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
         cat = self.br_after_cat(cat)

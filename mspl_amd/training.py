@@ -157,7 +157,11 @@ class GraphedTrainStep:
                 with torch.no_grad():
                     layers.prefold_frozen_bn(model)
             b = B // self.lanes
-            self.streams = [torch.cuda.Stream(device=self.images.device) for _ in range(self.lanes)]
+            # streams that really run side by side (HIP multiplexes streams onto a few hardware queues; two lanes on one queue run one
+            # after the other, and four serialised micro-batches are SLOWER than the one-graph step: 12.2 vs 9.0 ms, both seen in one
+            # process with plain new streams, depending on how many streams existed before)
+            from .uest import _concurrent_streams
+            self.streams = _concurrent_streams(self.lanes, self.images.device)
             self.lane_graphs, self.lane_losses = [], []
             stray = []
             # (a tensor hook sees None when the op accumulated into the sink itself, a tensor when autograd is about to add one)

@@ -467,3 +467,40 @@ def test_fused_pyramid_training_with_gradient_sinks():
         m(x).backward(go)
     for k, p in m.named_parameters():
         close(p.grad - 0.5, ref[k], atol=2e-4, rtol=2e-3)
+
+
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 1, 7, 12, 20), (1, 128, 128, 1, 9, 9, 15), (2, 32, 96, 2, 13, 16, 24), (1, 64, 64, 2, 9, 15, 21),
+                                 (3, 256, 256, 1, 9, 18, 30)])
+def test_fused_eesp_block_training_equals_node_per_op(cfg):
+    """autograd.EESPFn (whole block as one node: residual gradient in the projection's data-gradient epilogue, BatchNorm/PReLU backward
+    fused with the HFF suffix sum, branch weights as one view) against the node-per-op path: output, input gradient, every parameter
+    gradient.  Stride 2 is the DownSampler's EESP (down_method='avg': no residual, no module_act)."""
+    from mspl_amd import layers
+    N, cin, cout, stride, r_lim, h, w = cfg
+    m = layers.EESP(cin, cout, stride=stride, r_lim=r_lim, down_method='avg' if stride == 2 else 'esp')
+    m.load_state_dict(synth_state_dict(m.state_dict(), 41))
+    m = m.to(DEV).eval()
+    x = rnd(N, cin, h, w, seed=3).to(DEV)
+    res = {}
+    for fused in (False, True):
+        prev = layers._FUSED_EESP_TRAIN
+        layers._FUSED_EESP_TRAIN = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            for p in m.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                y = m(xi)
+                go = rnd(*y.shape, seed=4).to(DEV)
+                y.backward(go)
+            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()})
+        finally:
+            layers._FUSED_EESP_TRAIN = prev
+    assert torch.equal(res[True][0], res[False][0])
+    close(res[True][1], res[False][1], atol=5e-5, rtol=1e-3)
+    for k, b in res[False][2].items():
+        a = res[True][2][k]
+        assert (a is None) == (b is None), k
+        if b is not None:
+            scale = float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
