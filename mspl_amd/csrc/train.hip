@@ -416,6 +416,43 @@ __global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const float* __r
     if (lane == 0) gx[w] = acc;
 }
 
+// Large ratios, second form: a workgroup per (plane, INPUT row).  The candidate output rows of that input row are reduced
+// vertically with coalesced reads (thread = output column), the row of column sums goes through LDS, then thread b < Wi finishes
+// input pixel (row, b) over its candidate columns.  Every output row is read about twice (once per input row it feeds) instead of
+// once per input PIXEL and candidate column block: 96 -> ~15 us for the 13x24 -> 128x240 map of the pyramid's 0.1 branch.
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx) {
+    extern __shared__ float colsum[];                       // Wo floats
+    const int iy = blockIdx.x % g.Hi;
+    const int t = blockIdx.x / g.Hi;                        // plane
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    int ylo = 0, yhi = g.Ho - 1;
+    if (g.sh > 0.f) { ylo = max(0, (int)floorf((float)(iy - 1) / g.sh) - 1); yhi = min(g.Ho - 1, (int)ceilf((float)(iy + 1) / g.sh) + 1); }
+    for (int ox = threadIdx.x; ox < g.Wo; ox += 256) {
+        float col = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1;  float wy0, wy1;
+            bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+            const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            if (wy == 0.f) continue;                            // uniform
+            col = fmaf(wy, gp[(size_t)oy * g.Wo + ox], col);
+        }
+        colsum[ox] = col;
+    }
+    __syncthreads();
+    for (int ix = threadIdx.x; ix < g.Wi; ix += 256) {
+        int xlo = 0, xhi = g.Wo - 1;
+        if (g.sw > 0.f) { xlo = max(0, (int)floorf((float)(ix - 1) / g.sw) - 1); xhi = min(g.Wo - 1, (int)ceilf((float)(ix + 1) / g.sw) + 1); }
+        float acc = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            int x0, x1;  float wx0, wx1;
+            bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
+            const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+            acc = fmaf(wx, colsum[ox], acc);
+        }
+        gx[((size_t)t * g.Hi + iy) * g.Wi + ix] = acc;
+    }
+}
+
 // Gather form (deterministic, no atomics, no zero fill): one thread per INPUT pixel; the outputs whose window
 // [floor(o*I/O), ceil((o+1)*I/O)) contains it are o in [floor(i*O/I), ceil((i+1)*O/I) - 1] (1-2 per axis when pooling down,
 // 2-3 when the "pool" enlarges the map, the 2.0 / 1.5 pyramid scales).
@@ -595,7 +632,8 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
                                                                   const float* __restrict__ bn_inv, int n, int HW, int chunks,
                                                                   int64_t total, float* __restrict__ out, float* __restrict__ gscale,
                                                                   float* __restrict__ gshift, float* __restrict__ galpha) {
-    int b = blockIdx.x;
+    const int tix = (int)threadIdx.x, tstep = 256;
+    int b = (int)blockIdx.x;
     const int chunk = b % chunks;  b /= chunks;
     const int j = b % n;
     const int img = b / n;
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
     if ((HW & 3) == 0) {
         const int q4 = HW >> 2, per = (q4 + chunks - 1) / chunks;
         const int q0 = chunk * per, q1 = min(q4, q0 + per);
-        for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+        for (int q = q0 + tix; q < q1; q += tstep) {
             float4 zv[4], gv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
     } else {
         const int per = (HW + chunks - 1) / chunks;
         const int p0 = chunk * per, p1 = min(HW, p0 + per);
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        for (int p = p0 + tix; p < p1; p += tstep) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 3; k >= 0; --k) {
@@ -817,6 +855,13 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
     const int64_t total = (int64_t)N * C * Hi * Wi;
     // candidate window per input pixel is 2/scale + 3 wide: beyond 12 columns a wave per input pixel is the better shape
     const bool wide = g.sw <= 0.f || 2.0f / g.sw + 3.0f > 12.0f;
+    static const int rows_form = getenv("MSPL_BILINEAR_BWD_ROWS") ? atoi(getenv("MSPL_BILINEAR_BWD_ROWS")) : 1;
+    if (wide && rows_form && Wo <= 8192 && (int64_t)N * C * Hi < (1ll << 31)) {
+        hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3((unsigned)((int64_t)N * C * Hi)), dim3(256), (size_t)Wo * sizeof(float),
+                           (hipStream_t)stream, gy, g, gx);
+        MSPL_CHECK_LAUNCH("bilinear_bwd(rows)");
+        return MSPL_OK;
+    }
     if (wide && total * 64 < (1ll << 31) * 256ll) {
         hipLaunchKernelGGL(bilinear_bwd_wave_kernel, dim3((unsigned)ceil_div64(total * 64, 256)), dim3(256), 0, (hipStream_t)stream, gy, g,
                            gx, total);

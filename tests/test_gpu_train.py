@@ -138,6 +138,9 @@ def test_resample_fns():
     y = rnd(1, 2, 5, 6, seed=2)
     check_op(lambda a: ag.bilinear(a, (64, 120)), lambda a: F.interpolate(a, (64, 120), mode='bilinear', align_corners=True), [y])
     check_op(lambda a: ag.bilinear(a, (5, 6)), lambda a: F.interpolate(a, (5, 6), mode='bilinear', align_corners=True), [y])
+    # rows form of the wide backward: more output columns than threads, more input columns than one candidate window
+    z = rnd(2, 3, 13, 24, seed=3)
+    check_op(lambda a: ag.bilinear(a, (128, 300)), lambda a: F.interpolate(a, (128, 300), mode='bilinear', align_corners=True), [z])
 
 
 def test_gate_fns():
