@@ -503,14 +503,12 @@ def main():
     eager = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=False)
     from mspl_amd import layers as L
     L.ops.eesp_dw_hff = record_k2
-    from mspl_amd._native import lib as _lib
-    prev_mode = _lib.mspl_set_throughput_mode(1)       # the lanes' launch shapes: K1 and K2 as two launches (outside it the stride-1 blocks use the fused K1+K2 launch)
     try:
-        eager(x)
+        with ops.launch_flags(throughput=True):        # the lanes' launch shapes: K1 and K2 as two launches (without it the stride-1 blocks use the fused K1+K2 launch)
+            eager(x)
         torch.cuda.synchronize()
     finally:
         L.ops.eesp_dw_hff = real
-        _lib.mspl_set_throughput_mode(prev_mode)
     REPS = 20
     k2_ms = []
     for a_, kw in calls:
@@ -565,10 +563,9 @@ def main():
             e1.record()
             rec.append((e0, e1))
             return r
-        prev = _lib.mspl_set_throughput_mode(1)
         L.ops.eesp_dw_hff = timed_k2
         try:
-            with L.side_streams(False):
+            with L.side_streams(False), ops.launch_flags(throughput=True):
                 eager(xin)                                  # allocator / caches warm for this batch size
                 torch.cuda.synchronize()
                 for _ in range(passes):
@@ -583,7 +580,6 @@ def main():
                     per_pass.append([e0.elapsed_time(e1) for e0, e1 in rec])
         finally:
             L.ops.eesp_dw_hff = real
-            _lib.mspl_set_throughput_mode(prev)
         ovh = sorted(calib)[len(calib) // 2]
         n = len(per_pass[0])
         med = [sorted(pp[i] for pp in per_pass)[len(per_pass) // 2] - ovh for i in range(n)]

@@ -63,9 +63,19 @@ typedef struct {
     int32_t out_ctot;       /* channels of the destination tensor */
     int32_t out_coff;       /* first destination channel written by this call */
     float* raw_out;         /* see above; NULL = not wanted */
+    uint32_t struct_size;   /* sizeof(mspl_epilogue_t) of the CALLER's header: a library built against another layout rejects the
+                               call (MSPL_ERR_BAD_SHAPE, "epilogue struct size") instead of reading fields that are not there */
+    uint32_t flags;         /* MSPL_LAUNCH_* launch-shape preferences of THIS call (never change results) */
 } mspl_epilogue_t;
 
+/* Launch-shape preference of a call: the caller keeps several independent passes in flight (mspl_amd.uest.PipelinedLabelPass), so
+ * fewer, longer workgroups are preferred (another pass fills the ramp and tail) and the big-LDS fused K1+K2 launch is not used.
+ * Per call, not per process: the library holds no mutable global state and is re-entrant (rounds 1-2 had a process-wide switch). */
+#define MSPL_LAUNCH_THROUGHPUT 1u
+
 const char* mspl_version(void);
+/* ABI revision of this library; it changes whenever a struct layout or a signature in this header does.  3 = this header. */
+int mspl_abi_version(void);
 /* Copies the calling thread's last error text (NUL-terminated) into buf; returns its length. */
 size_t mspl_last_error(char* buf, size_t cap);
 
@@ -104,10 +114,11 @@ int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32_t Cin, int
  * then the four dilated depthwise 3x3 + HFF + cat + br_after_cat).  x (N,Cin,H,W); wp (n, Cin/groups): the projection's weights;
  * pscale/pshift/palpha (n): its folded BatchNorm and PReLU (NULL = identity); w (4,n,3,3), dil, ep, out (N,4n,H,W): as
  * mspl_eesp_dw_hff_fwd with stride 1.  Covered: Cin/groups in {64,128}, n/groups a multiple of 16, H*W % 4 == 0, W even, W,H <= 64,
- * dilations {1,1,2,3} or {1,2,3,4}, M = n/groups in {16,32}; mspl_eesp_proj_dw_hff_fits() returns 1 for covered shapes outside
- * throughput mode (mspl_set_throughput_mode: with several launches in flight the two-launch form measured faster) (callers run
+ * dilations {1,1,2,3} or {1,2,3,4}, M = n/groups in {16,32}; mspl_eesp_proj_dw_hff_fits() returns 1 for covered shapes unless
+ * launch_flags has MSPL_LAUNCH_THROUGHPUT (with several launches in flight the two-launch form measured faster) (callers run
  * mspl_conv1x1_fwd + mspl_eesp_dw_hff_fwd otherwise; _fwd returns MSPL_ERR_UNSUPPORTED). */
-int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]);
+int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4],
+                               uint32_t launch_flags);
 int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* pscale, const float* pshift, const float* palpha,
                               const float* w, const int32_t dil[4], int32_t N, int32_t Cin, int32_t n, int32_t groups,
                               int32_t H, int32_t W, const mspl_epilogue_t* ep, float* out, void* stream);
@@ -249,6 +260,9 @@ int mspl_label_epilogue_fwd(const float* main, const float* aux, int32_t N, int3
  *     same-address device atomics from ~10^4 workgroups serialise).
  */
 int64_t mspl_label_epilogue_hist_workspace_bytes(int32_t N, int32_t H, int32_t W);
+/* 1 when mspl_label_epilogue_hist_fwd covers the shape (the LDS-staged tile of both heads fits; Ha = Wa = 0: no second head);
+ * callers run mspl_label_epilogue_fwd + mspl_merge_labels_fwd(S = 1, thresh = 1) otherwise. */
+int mspl_label_epilogue_hist_fits(int32_t N, int32_t C, int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W);
 int mspl_label_epilogue_hist_fwd(const float* main, const float* aux, int32_t N, int32_t C,
                                  int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
                                  const uint8_t* lut, uint8_t* labels, float* kld, unsigned long long* hist,
@@ -366,11 +380,6 @@ int mspl_weighted_ce_fwd(const float* pred, const int64_t* target, const float* 
 int mspl_weighted_ce_bwd(const float* pred, const int64_t* target, const float* u_weight, const float* class_weights,
                          int32_t ignore_index, int32_t N, int32_t C, int32_t HW, const float* g, const float* den,
                          float* gpred, float* gu, void* stream);
-
-/* Launch-shape preference for callers that keep several independent passes in flight (mspl_amd.uest.PipelinedLabelPass): non-zero
- * = prefer fewer, longer workgroups.  Returns the previous setting.  Results never change; it is read when a kernel is launched
- * (under hipGraph capture: once, at capture). */
-int mspl_set_throughput_mode(int32_t on);
 
 /* ---- loader-side transforms: the step in front of the hot path -------------------------------------
  * Replace, for a whole batch of decoded uint8 images, data_loader/segmentation/greenhouse.py:216-222 (val_transforms =

@@ -26,7 +26,12 @@ class Epilogue(ctypes.Structure):
     _fields_ = [('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('alpha', ctypes.c_void_p),
                 ('pre_add', ctypes.c_void_p), ('residual', ctypes.c_void_p), ('reinf_r', ctypes.c_void_p),
                 ('reinf_w', ctypes.c_void_p), ('gate', ctypes.c_void_p),
-                ('out_ctot', c_i32), ('out_coff', c_i32), ('raw_out', ctypes.c_void_p)]
+                ('out_ctot', c_i32), ('out_coff', c_i32), ('raw_out', ctypes.c_void_p),
+                ('struct_size', ctypes.c_uint32), ('flags', ctypes.c_uint32)]
+
+
+ABI_VERSION = 3                 # include/mspl_hip.h: mspl_abi_version()
+LAUNCH_THROUGHPUT = 1           # MSPL_LAUNCH_THROUGHPUT
 
 
 _EP = ctypes.POINTER(Epilogue)
@@ -35,7 +40,7 @@ _EP = ctypes.POINTER(Epilogue)
 SIGNATURES = {
     'mspl_eesp_dw_hff_fwd': [c_f32p, c_f32p, ctypes.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_i32, _EP,
                              c_f32p, ctypes.c_void_p],
-    'mspl_eesp_proj_dw_hff_fits': [c_i32] * 6 + [ctypes.POINTER(c_i32)],
+    'mspl_eesp_proj_dw_hff_fits': [c_i32] * 6 + [ctypes.POINTER(c_i32), ctypes.c_uint32],
     'mspl_eesp_proj_dw_hff_fwd': [c_f32p] * 6 + [ctypes.POINTER(c_i32)] + [c_i32] * 6 + [_EP, c_f32p, ctypes.c_void_p],
     'mspl_conv1x1_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_conv3x3_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
@@ -67,6 +72,7 @@ SIGNATURES = {
                                      ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_i32, ctypes.c_void_p, c_i64,
                                      ctypes.c_void_p],
     'mspl_label_epilogue_hist_workspace_bytes': [c_i32, c_i32, c_i32],
+    'mspl_label_epilogue_hist_fits': [c_i32] * 8,
     'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
@@ -112,7 +118,7 @@ SIGNATURES = {
     'mspl_png_writer_submit': [ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p],
     'mspl_png_writer_poll': [ctypes.c_void_p, c_i64, c_i32],
     'mspl_png_writer_destroy': [ctypes.c_void_p],
-    'mspl_set_throughput_mode': [c_i32],
+    'mspl_abi_version': [],
     'mspl_sum_n': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_f32p, ctypes.c_void_p],
     'mspl_transpose_weights': [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
@@ -137,6 +143,9 @@ def _load():
     lib.mspl_png_writer_create.restype = ctypes.c_void_p          # a handle
     lib.mspl_png_writer_submit.restype = ctypes.c_int64           # a ticket (or a negative status)
     lib.mspl_version.restype = ctypes.c_char_p
+    if lib.mspl_abi_version() != ABI_VERSION:
+        raise ImportError('mspl_amd: %s has ABI revision %d, this package binds revision %d: rebuild the library (make -C mspl_amd/csrc)'
+                          % (LIB_PATH, lib.mspl_abi_version(), ABI_VERSION))
     lib.mspl_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.mspl_last_error.restype = ctypes.c_size_t
     return lib

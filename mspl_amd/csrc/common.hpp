@@ -69,7 +69,6 @@ __device__ __forceinline__ void store_out2(float* p, const float2& v) {
 #endif
 }
 
-extern std::atomic<int> g_throughput_mode;     // api.hip: mspl_set_throughput_mode
 
 // XCD-contiguous workgroup order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, and each XCD has its own
 // L2: tiles that share halo rows / low-resolution source maps should sit on ONE XCD.  With the grid padded to 8 * per workgroups,
@@ -114,8 +113,13 @@ static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
     return e;
 }
 
+static inline unsigned epi_flags(const mspl_epilogue_t* ep) { return ep ? ep->flags : 0u; }
+
 static inline int check_epi(const mspl_epilogue_t* ep, int C, const char* who, bool raw_ok = false) {
     if (!ep) return MSPL_OK;
+    MSPL_REQUIRE(ep->struct_size == sizeof(mspl_epilogue_t), MSPL_ERR_BAD_SHAPE,
+                 "%s: epilogue struct size %u, this library expects %zu (caller built against another mspl_hip.h: ABI %d)", who,
+                 ep->struct_size, sizeof(mspl_epilogue_t), 3);
     MSPL_REQUIRE(!ep->raw_out || (raw_ok && (ep->out_ctot == 0 || (ep->out_ctot == C && ep->out_coff == 0))), MSPL_ERR_UNSUPPORTED,
                  "%s: raw_out is for un-sliced convolution outputs only", who);
     if (ep->out_ctot > 0) {

@@ -18,6 +18,8 @@
 // K < 16: the matrix tile would be mostly padding; a VALU kernel streams 4 pixels per lane.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -813,8 +815,8 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     if (lds > 64 * 1024) {
 #define MSPL_PIPE_ATTR(NG) do { (void)hipFuncSetAttribute((const void*)conv1x1_pipe_kernel<2, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
                                 (void)hipFuncSetAttribute((const void*)conv1x1_pipe_kernel<1, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); } while (0)
-        static bool attr_done = false;
-        if (!attr_done) { MSPL_PIPE_ATTR(8); MSPL_PIPE_ATTR(12); MSPL_PIPE_ATTR(16); (void)hipGetLastError(); attr_done = true; }
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] { MSPL_PIPE_ATTR(8); MSPL_PIPE_ATTR(12); MSPL_PIPE_ATTR(16); (void)hipGetLastError(); });
 #undef MSPL_PIPE_ATTR
     }
 #define MSPL_PIPE(NG) do { if (nsub == 2) hipLaunchKernelGGL((conv1x1_pipe_kernel<2, NG>), grid, blk, lds, s, x, w, g, e, out); \
@@ -979,18 +981,19 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     g.WM = g.mc_total >= 3 ? 4 : g.mc_total;     // one 32-row chunk per wave; chunks share B loads through L1
     const int wp = 4 / g.WM;
     const size_t lds = (size_t)g.MB * (g.KS + rowf) * sizeof(float);
-    static bool attr_done = false;   // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
-    if (!attr_done) {
-        const int cap = (int)lds_cap;
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipGetLastError();
-        attr_done = true;
+    static std::once_flag attr_once;   // dynamic LDS above 64 KiB needs the opt-in (once per process, thread-safe)
+    {
+        constexpr int cap = 96 * 1024;            // = lds_cap
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv1x1_mfma_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipGetLastError();
+        });
     }
     // pixels per lane: the widest vector the shape/alignment allows that still yields enough waves to fill
     // 256 CUs x 4 SIMDs (small feature maps prefer narrower tiles over idle CUs)

@@ -29,6 +29,8 @@
 
 #include <algorithm>
 
+#include <mutex>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -973,13 +975,14 @@ static int eesp_proj_dw_plan(int N, int Cin, int n, int groups, int H, int W, co
     return 1;
 }
 
-extern "C" int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4]) {
+extern "C" int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int32_t groups, int32_t H, int32_t W, const int32_t dil[4],
+                                          uint32_t launch_flags) {
     // Measured on the whole label pass: with one batch in flight the fused launch is worth +2 % (it shortens a latency-bound chain);
     // with three launches of 32 images in flight it costs 1.7 % (its workgroups hold 50-100 KB of LDS and 512 threads, which
-    // crowds out the other lanes' kernels).  So: used unless the library is in throughput mode (mspl_set_throughput_mode, read
-    // when a lane's graph is captured); MSPL_EESP_FRONT=0 / =2 force it off / on.
+    // crowds out the other lanes' kernels).  So: used unless the caller asks for throughput launch shapes (MSPL_LAUNCH_THROUGHPUT,
+    // per call); MSPL_EESP_FRONT=0 / =2 force it off / on.
     static const int mode = getenv("MSPL_EESP_FRONT") ? atoi(getenv("MSPL_EESP_FRONT")) : 1;
-    if (mode == 0 || !dil || (mode == 1 && g_throughput_mode.load())) return 0;
+    if (mode == 0 || !dil || (mode == 1 && (launch_flags & MSPL_LAUNCH_THROUGHPUT))) return 0;
     FrGeom g; size_t lds;
     return eesp_proj_dw_plan(N, Cin, n, groups, H, W, dil, g, lds);
 }
@@ -1004,20 +1007,19 @@ extern "C" int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * groups * g.bands)), blk(512);
     const int key = dil[0] * 1000 + dil[1] * 100 + dil[2] * 10 + dil[3];
-    static bool attr_done = false;     // dynamic LDS above 64 KiB needs the opt-in (idempotent, no sync)
+    static std::once_flag attr_once;   // dynamic LDS above 64 KiB needs the opt-in (once per process, thread-safe)
     typedef DilSet<1, 1, 2, 3> DS1123;
     typedef DilSet<1, 2, 3, 4> DS1234;
 #define MSPL_FR_ALL(OP) OP(DS1123, 32, 2) OP(DS1123, 16, 1) \
                         OP(DS1234, 32, 2) OP(DS1234, 16, 1) \
                         OP(DS1123, 32, 1) OP(DS1123, 16, 2) \
                         OP(DS1234, 32, 1) OP(DS1234, 16, 2)
-    if (!attr_done) {
+    std::call_once(attr_once, [] {
 #define MSPL_FR_ATTR(DSX, KQX, SLX) (void)hipFuncSetAttribute((const void*)eesp_proj_dw_kernel<DSX, KQX, SLX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         MSPL_FR_ALL(MSPL_FR_ATTR)
 #undef MSPL_FR_ATTR
         (void)hipGetLastError();
-        attr_done = true;
-    }
+    });
     const int kq = g.K / 4, sl = g.M / 16;
 #define MSPL_FR_GO(DSX, KQX, SLX) if (key == (DSX::d(0) * 1000 + DSX::d(1) * 100 + DSX::d(2) * 10 + DSX::d(3)) && kq == KQX && sl == SLX) \
         hipLaunchKernelGGL((eesp_proj_dw_kernel<DSX, KQX, SLX>), grid, blk, lds, s, x, wp, pscale, pshift, palpha, w, g, e, out);

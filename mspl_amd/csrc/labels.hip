@@ -676,10 +676,15 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
                              (long long)workspace_bytes, (long long)need);
                 ws = (unsigned int*)workspace;
             }
-            static const bool big_lds = [] {          // C = 24 at 256 columns needs 72 KB (the default cap is 64 KB)
-                bool ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<24, false, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
-                ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<20, true, 132, 68>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok;
+            static const bool big_lds = [] {          // up to 128 KB of staged rows (the default cap is 64 KB): every instantiation launched below
+                bool ok = true;
+#define MSPL_LE_ATTR(CM, EX, A, B) ok = hipFuncSetAttribute((const void*)label_epilogue_lds_kernel<CM, EX, A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess && ok
+                MSPL_LE_ATTR(5, true, 0, 0);  MSPL_LE_ATTR(5, true, 132, 68);
+                MSPL_LE_ATTR(13, true, 0, 0); MSPL_LE_ATTR(13, true, 132, 68);
+                MSPL_LE_ATTR(20, true, 0, 0); MSPL_LE_ATTR(20, true, 132, 68);
+                MSPL_LE_ATTR(8, false, 0, 0); MSPL_LE_ATTR(16, false, 0, 0); MSPL_LE_ATTR(24, false, 0, 0);
+#undef MSPL_LE_ATTR
+                (void)hipGetLastError();
                 return ok;
             }();
             MSPL_REQUIRE(big_lds || lds <= 64 * 1024, MSPL_ERR_HIP, "label_epilogue: could not raise the dynamic LDS limit");
@@ -728,6 +733,22 @@ extern "C" int mspl_label_epilogue_fwd(const float* mainp, const float* aux, int
 extern "C" int64_t mspl_label_epilogue_hist_workspace_bytes(int32_t N, int32_t H, int32_t W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     return le_blocks(N, H, W) * 32 * (int64_t)sizeof(unsigned int);
+}
+
+extern "C" int mspl_label_epilogue_hist_fits(int32_t N, int32_t C, int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W) {
+    // the conditions of the LDS-staged label form in label_epilogue_impl (the only form that accumulates the histogram)
+    if (N <= 0 || C <= 0 || C > 24 || Hm <= 0 || Wm <= 0 || H <= 0 || W <= 0 || Ha < 0 || Wa < 0) return 0;
+    const bool aux = Ha > 0 && Wa > 0;
+    if (!(H <= 65535 * LE_RB / 4 && N <= 65535 && (int64_t)N * C * Hm * Wm < (1ll << 31) && (int64_t)N * C * (int64_t)Ha * Wa < (1ll << 31))) return 0;
+    const bool vec = (Wm % 4 == 0) && (!aux || Wa % 4 == 0);      // (pointer alignment can only shrink the tile: unaligned = 4-byte staging)
+    const int nrm = le_span(Hm, H, LE_RB, false), nra = aux ? le_span(Ha, H, LE_RB, false) : 0;
+    int wms = le_span(Wm, W, 256, vec), was = aux ? le_span(Wa, W, 256, vec) : 4;
+    if (!vec) { wms = (wms + 3) & ~3; was = (was + 3) & ~3; }
+    const int wms4 = (le_span(Wm, W, 256, true) + 3) & ~3, was4 = aux ? (le_span(Wa, W, 256, true) + 3) & ~3 : 4;   // worst case of either staging
+    wms = std::max(wms, wms4); was = std::max(was, was4);
+    const size_t lds = ((size_t)nrm * C * wms + (size_t)nra * C * was + 32) * sizeof(float);
+    if ((C == 5 || C == 13 || C == 20) == false && C <= 8 && wms == 132 && (!aux || was == 68)) return 0;   // (no <8, false, 132, 68> instantiation)
+    return lds <= 128 * 1024 && (nrm + nra) * C < 4096 && wms <= 256 && was <= 256;
 }
 
 extern "C" int mspl_label_epilogue_hist_fwd(const float* mainp, const float* aux, int32_t N, int32_t C,

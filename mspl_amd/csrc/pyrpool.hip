@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void pyrpool_fused_kernel(const float* __restr
 int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                     const float* const* stage_w, const float* const* down_e, const float* br_scale,
                     const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
-                    hipStream_t stream);       // pyrpool_sep.hip
+                    hipStream_t stream, unsigned launch_flags);       // pyrpool_sep.hip
 int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                        const float* const* stage_w, const float* const* down_e, const float* br_scale,
                        const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
@@ -401,7 +401,7 @@ static int pyrpool_fused_launch(const float* x, int32_t N, int32_t P, int32_t h,
             if (rc3 <= 0) return rc3;
             if (!zcat) {
                 const int rc = pyrpool_sep_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
-                                               make_epi(ep, P, h * w), out, (hipStream_t)stream);
+                                               make_epi(ep, P, h * w), out, (hipStream_t)stream, epi_flags(ep));
                 if (rc <= 0) return rc;
             }
         }

@@ -479,7 +479,7 @@ static int stencil_radius(int I, int S) {
 int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                     const float* const* stage_w, const float* const* down_e, const float* br_scale,
                     const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
-                    hipStream_t stream) {
+                    hipStream_t stream, unsigned launch_flags) {
     if (e.pre_add || e.residual || e.reinf_r || e.gate) return 1;    // only the scale/shift/PReLU epilogue
     Pyr2Geom g;
     memset(&g, 0, sizeof(g));
@@ -541,8 +541,8 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
     const size_t lds = (size_t)off * sizeof(float);
     if (lds > 64 * 1024) return 1;
     // planes per workgroup (each workgroup walks them with the next plane's loads in flight): as many as keep >= 2048 workgroups
-    // for a lone pass; in throughput mode 512 are enough -- fewer, longer workgroups (+2.5 % images/s with three passes in flight)
-    const int64_t min_blocks = g_throughput_mode.load() ? 512 : 2048;
+    // for a lone pass; with MSPL_LAUNCH_THROUGHPUT 512 are enough -- fewer, longer workgroups (+2.5 % images/s with three passes in flight)
+    const int64_t min_blocks = (launch_flags & MSPL_LAUNCH_THROUGHPUT) ? 512 : 2048;
     int cpb = 1;
     while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= min_blocks) cpb *= 2;
     static const int dbg_cpb = getenv("MSPL_PYR_CPB") ? atoi(getenv("MSPL_PYR_CPB")) : 0;

@@ -51,12 +51,40 @@ class Epi:
         self.raw_out = raw_out          # convolutions only: a tensor of the destination's shape that also receives the bare result
 
 
+# Launch-shape preference of the calls issued by this THREAD (mspl_epilogue_t.flags / MSPL_LAUNCH_*): per call, carried in every
+# epilogue struct -- the library itself holds no mutable state (rounds 1-2 flipped a process-wide switch around every lane launch).
+import threading
+_LAUNCH = threading.local()
+
+
+class launch_flags(object):
+    """with launch_flags(throughput=True): every op issued by this thread asks for launch shapes that favour steady-state
+    efficiency over the latency of a lone launch (PipelinedLabelPass captures its lanes like this).  Results never change."""
+
+    def __init__(self, throughput=False):
+        self.value = nat.LAUNCH_THROUGHPUT if throughput else 0
+
+    def __enter__(self):
+        self.prev = getattr(_LAUNCH, 'flags', 0)
+        _LAUNCH.flags = self.value
+        return self
+
+    def __exit__(self, *exc):
+        _LAUNCH.flags = self.prev
+
+
+def current_launch_flags():
+    return getattr(_LAUNCH, 'flags', 0)
+
+
 def _build(ep, out, coff, N, C, hw):
     """Validate an Epi against the destination tensor `out` (N, ctot, ...) and build the C struct."""
     ctot = out.shape[1]
     if coff < 0 or coff + C > ctot:
         raise RuntimeError('mspl_amd: channel slice [%d,%d) outside destination with %d channels' % (coff, coff + C, ctot))
     s = Epilogue()
+    s.struct_size = ctypes.sizeof(Epilogue)
+    s.flags = current_launch_flags()
     s.out_ctot, s.out_coff = ctot, coff
     keep = []
     if ep is not None:
@@ -120,7 +148,7 @@ def eesp_proj_dw_hff_fits(shape, n, groups, dilations, stride):
         return False
     N, Cin, H, W = [int(v) for v in shape]
     d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
-    return bool(lib.mspl_eesp_proj_dw_hff_fits(N, Cin, int(n), int(groups), H, W, d))
+    return bool(lib.mspl_eesp_proj_dw_hff_fits(N, Cin, int(n), int(groups), H, W, d, current_launch_flags()))
 
 
 def eesp_proj_dw_hff(x, wproj, pscale, pshift, palpha, w4, dilations, groups, ep=None, out=None):
@@ -376,6 +404,13 @@ def label_epilogue(main, aux, size, lut=None, want_labels=True, want_prob=False,
                                       _p(res.get('prob')), _p(res.get('kld')), _p(res.get('main_up')),
                                       _p(res.get('aux_up')), _stream()))
     return res
+
+
+def label_epilogue_hist_fits(main, aux, size):
+    """True when label_epilogue_hist covers these head shapes (else: label_epilogue + merge_labels(S=1))."""
+    N, C, Hm, Wm = [int(v) for v in main.shape]
+    Ha, Wa = ([int(v) for v in aux.shape[2:]] if aux is not None else (0, 0))
+    return bool(lib.mspl_label_epilogue_hist_fits(N, C, Hm, Wm, Ha, Wa, int(size[0]), int(size[1])))
 
 
 def label_epilogue_hist(main, aux, size, hist, num_classes, lut=None, want_kld=False):

@@ -15,7 +15,6 @@ import numpy as np
 import torch
 
 from . import layers, ops
-from ._native import lib
 
 # data_loader/segmentation/greenhouse.py:15-58 (literal tables: source class id -> greenhouse class id)
 id_camvid_to_greenhouse = np.array([4, 2, 2, 3, 3, 1, 2, 2, 2, 4, 4, 2, 4])
@@ -101,15 +100,30 @@ class _GraphedPassMixin:
         optimizer step rebuilds the folded caches elsewhere)."""
 
     def _signature(self):
+        """(epoch, (id, data_ptr, _version) of every floating-point parameter / buffer SLOT of the models).  The slots (module, dict,
+        name) are cached, the tensors are looked up on every call: a replaced nn.Parameter / buffer object (model surgery,
+        `module.weight = nn.Parameter(...)`) changes the id and the pointer.  An in-place edit through `.data` bumps neither: callers
+        that do that must call layers.bump_param_epoch() or invalidate_graphs()."""
         if _NO_SIGNATURE:
             return (layers._PARAM_EPOCH[0],)
-        ts = self.__dict__.get('_sig_tensors')
-        if ts is None:
-            ts = []
+        slots = self.__dict__.get('_sig_slots')
+        if slots is None:
+            slots = []
             for m in self._graph_models():
-                ts += [t for t in list(m.parameters()) + list(m.buffers()) if t.is_floating_point()]
-            self._sig_tensors = ts
-        return (layers._PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in ts)
+                for mod in m.modules():
+                    slots += [(mod._parameters, k) for k, t in mod._parameters.items() if t is not None and t.is_floating_point()]
+                    slots += [(mod._buffers, k) for k, t in mod._buffers.items() if t is not None and t.is_floating_point()]
+            self._sig_slots = slots
+        sig = [layers._PARAM_EPOCH[0]]
+        for d, k in slots:
+            t = d.get(k)
+            sig.append(None if t is None else (id(t), t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def invalidate_graphs(self):
+        """Drop every captured graph (after editing parameters in a way the signature cannot see, e.g. through `.data`)."""
+        self._graphs.clear()
+        self.__dict__.pop('_sig_slots', None)
 
     def _cache_tensors(self):
         keep = []
@@ -362,12 +376,9 @@ class PipelinedLabelPass:
     def _launch(self, i, images):
         """One launch of lane i's pass on its stream; returns (outputs, event)."""
         st = self.streams[i]
-        prev = lib.mspl_set_throughput_mode(1 if self.depth > 1 else 0)      # launch shapes for a shared chip (read at capture)
-        try:
-            with torch.cuda.stream(st), layers.side_streams(self.depth == 1):    # lanes are captured as linear graphs
-                out = self.lanes[i](images)
-        finally:
-            lib.mspl_set_throughput_mode(prev)
+        # launch shapes for a shared chip (per call, read at capture); lanes are captured as linear graphs
+        with torch.cuda.stream(st), layers.side_streams(self.depth == 1), ops.launch_flags(throughput=self.depth > 1):
+            out = self.lanes[i](images)
         with torch.cuda.stream(st):
             ev = torch.cuda.Event()
             ev.record(st)
@@ -515,7 +526,7 @@ class SelfLabelPass(_GraphedPassMixin):
 
     def _run(self, images):
         main, aux = _lowres(self.model, images)
-        if main.shape[1] <= min(24, self.classes, 32):
+        if main.shape[1] <= min(24, self.classes, 32) and ops.label_epilogue_hist_fits(main, aux, images.shape[2:]):
             # every argmax is a counted class: the epilogue kernel accumulates the histogram itself (one launch; the S = 1 merge
             # would be the identity on these labels)
             r = ops.label_epilogue_hist(main, aux, images.shape[2:], self.hist, self.classes, want_kld=self.with_kld)

@@ -376,3 +376,26 @@ def test_avgpool_plane_sums_and_gate_from_sums(shape):
     torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-6)
     y2, sums2 = ops.avgpool3x3s2(xd, plane_sums=True)                      # deterministic: same bits every time
     assert torch.equal(sums2, sums) and torch.equal(ops.gate_from_sums(sums2, w.to(DEV), shape[2] * shape[3]), g1)
+
+
+def test_label_epilogue_hist_fits_and_fallback():
+    """Shapes outside the LDS-staged form (heads at or near the output resolution: staged rows wider than 256 columns) are reported
+    by label_epilogue_hist_fits; SelfLabelPass then takes label_epilogue + merge_labels(S=1), the two-launch form, instead of
+    raising.  Covered shapes of every class-count instantiation launch (the dynamic-LDS opt-in is set for all of them)."""
+    from mspl_amd import ops
+    main = rnd(2, 5, 64, 300, seed=21, scale=2.0).to(DEV)
+    aux = rnd(2, 5, 32, 150, seed=22, scale=2.0).to(DEV)
+    assert not ops.label_epilogue_hist_fits(main, aux, (64, 300))            # main head at the output resolution: 300 > 256 staged columns
+    h = torch.zeros(5, dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.label_epilogue_hist(main, aux, (64, 300), h, 5)
+    two = ops.label_epilogue(main, aux, (64, 300))
+    ops.merge_labels([two['labels']], 5, 1, 4, h)
+    assert int(h.sum()) == 2 * 64 * 300
+    for C in (3, 8, 11, 16, 19, 24):          # the <8>, <16>, <24> instantiations, with tiles above and below 64 KB
+        m2 = rnd(1, C, 96, 240, seed=23 + C, scale=2.0).to(DEV)
+        a2 = rnd(1, C, 48, 120, seed=24 + C, scale=2.0).to(DEV)
+        assert ops.label_epilogue_hist_fits(m2, a2, (192, 480))
+        hh = torch.zeros(C, dtype=torch.int64, device=DEV)
+        one = ops.label_epilogue_hist(m2, a2, (192, 480), hh, C)
+        assert torch.equal(one['labels'], ops.label_epilogue(m2, a2, (192, 480))['labels']) and int(hh.sum()) == 192 * 480
