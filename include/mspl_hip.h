@@ -363,6 +363,22 @@ int mspl_dense_conv_fwd(const float* x, const float* w_packed, int32_t N, int32_
 int mspl_miou_areas_fwd(const float* logits, const uint8_t* labels, const int64_t* target, int32_t N, int32_t C, int32_t HW,
                         int32_t num_classes, unsigned long long* hist, void* stream);
 
+/* Evaluation step epilogue: val_seg_ue (utilities/train_eval_seg.py:279-302) / the body of test() (uest_seg_multi_os.py:1196-1198)
+ * after the network, in one pass over the low-resolution heads -- full-resolution logits are never written:
+ *     o = upsample(main) + aux_weight * upsample(aux)   (bilinear, align_corners; aux NULL or aux_weight 0: main alone)
+ *     loss_sums[0] += sum_valid w[t] * (lse(o) - o[t]),  loss_sums[1] += sum_valid w[t]     (nn.CrossEntropyLoss(weight, ignore_index)
+ *         = loss_sums[0] / loss_sums[1]; valid: t != ignore_index and 0 <= t < C; class_weights NULL = 1; doubles, ACCUMULATED)
+ *     areas[0..3K) += [area_inter | area_pred | area_mask] of MIOU(K).get_iou(o, target) in the reference's uint8 arithmetic
+ *         (as mspl_miou_areas_fwd; K = miou_classes, normally C - 1)
+ *     labels (N,H,W) uint8: optional argmax map (first maximum).
+ * mspl_eval_batch_finalize: AverageMeter.update(loss.item(), n) on the device -- acc[0] += (loss_sums[0]/loss_sums[1]) * n,
+ * acc[1] += n, acc[2] = this batch's loss; loss_sums is cleared for the next batch. */
+int mspl_eval_epilogue_fwd(const float* main, const float* aux, const int64_t* target, const float* class_weights,
+                           int32_t N, int32_t C, int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                           float aux_weight, int32_t ignore_index, int32_t miou_classes, double* loss_sums,
+                           unsigned long long* areas, uint8_t* labels, void* stream);
+int mspl_eval_batch_finalize(double* loss_sums, double* acc, int32_t batch_images, void* stream);
+
 /* Stand-alone loss modules (callers that compose them themselves instead of the fused K11 form):
  *  PixelwiseKLD.forward (loss_fns/segmentation_loss.py:181-189): kld (N,HW) = sum_c softmax(d1)*(log_softmax(d1)-log_softmax(d2));
  *  its backward: gd1/gd2 (N,C,HW) from gkld (N,HW); either output may be NULL. */

@@ -98,6 +98,9 @@ SIGNATURES = {
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
     'mspl_dense_conv_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
                             ctypes.c_void_p],
+    'mspl_eval_epilogue_fwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p] + [c_i32] * 8 + [ctypes.c_float, c_i32, c_i32, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    'mspl_eval_batch_finalize': [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p],
     'mspl_miou_areas_fwd': [c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_i32, c_i32, c_i32, c_i32, ctypes.c_void_p, ctypes.c_void_p],
     'mspl_resample_ksize': [c_i32, c_i32],
     'mspl_resample_coeffs': [c_i32, c_i32, ctypes.c_void_p, ctypes.c_void_p],

@@ -747,7 +747,6 @@ extern "C" int mspl_label_epilogue_hist_fits(int32_t N, int32_t C, int32_t Hm, i
     const int wms4 = (le_span(Wm, W, 256, true) + 3) & ~3, was4 = aux ? (le_span(Wa, W, 256, true) + 3) & ~3 : 4;   // worst case of either staging
     wms = std::max(wms, wms4); was = std::max(was, was4);
     const size_t lds = ((size_t)nrm * C * wms + (size_t)nra * C * was + 32) * sizeof(float);
-    if ((C == 5 || C == 13 || C == 20) == false && C <= 8 && wms == 132 && (!aux || was == 68)) return 0;   // (no <8, false, 132, 68> instantiation)
     return lds <= 128 * 1024 && (nrm + nra) * C < 4096 && wms <= 256 && was <= 256;
 }
 

@@ -126,6 +126,8 @@ def install_dropin(force=False):
            LinearLR=R.LinearLR, HybirdLR=R.HybirdLR, CosineLR=R.CosineLR)
     from . import metrics as Q
     _alias('utilities.metrics.segmentation_miou', MIOU=Q.MIOU)
+    from . import evaluation as E
+    _alias('utilities.train_eval_seg', val_seg_ue=E.val_seg_ue)
     _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,
            UncertaintyWeightedSegmentationLoss=S.UncertaintyWeightedSegmentationLoss,
            SegmentationLoss=S.SegmentationLoss, NIDLoss=S.NIDLoss)

@@ -134,31 +134,50 @@ class _GraphedPassMixin:
         return keep
 
     def _replay(self, images, copy_always=False):
-        key = tuple(images.shape)
+        key = self._shape_key(images)
         sig = self._signature()
         g = self._graphs.get(key)
         if g is not None and g.signature != sig:
             del self._graphs[key]                     # parameters changed since the capture: this graph holds stale values
             g = None
         if g is None:
-            static_in = images.clone()
-            hist_before = self.hist.clone()
+            static_in = self._clone_input(images)
+            state = self._graph_state()               # accumulators the pass adds to (histogram, ...): the warm-up must not count
+            before = [t.clone() for t in state]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):             # warm-up: fills the folded-BN caches outside the capture
                 self._run(static_in)
             torch.cuda.current_stream().wait_stream(side)
-            self.hist.copy_(hist_before)
+            for t, b in zip(state, before):
+                t.copy_(b)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode='thread_local'):      # other threads (the PNG writer) keep using HIP
                 static_out = self._graph_outputs(self._run(static_in))
-            self.hist.copy_(hist_before)              # capture does not execute, but keep the invariant explicit
-            graph._mspl_keep = (static_in, self.hist, self._cache_tensors(), list(getattr(self, 'luts', ())))
+            for t, b in zip(state, before):           # capture does not execute, but keep the invariant explicit
+                t.copy_(b)
+            graph._mspl_keep = (static_in, state, self._cache_tensors(), list(getattr(self, 'luts', ())))
             g = self._graphs[key] = _Captured(graph, static_in, static_out, sig)
-        if copy_always or g.static_in.data_ptr() != images.data_ptr():
-            g.static_in.copy_(images)
+        self._copy_input(g.static_in, images, copy_always)
         g.graph.replay()
         return g.static_out
+
+    # hooks (single-tensor input, one histogram by default)
+    @staticmethod
+    def _shape_key(images):
+        return tuple(images.shape)
+
+    def _graph_state(self):
+        return [self.hist]
+
+    @staticmethod
+    def _clone_input(images):
+        return images.clone()
+
+    @staticmethod
+    def _copy_input(static_in, images, copy_always):
+        if copy_always or static_in.data_ptr() != images.data_ptr():
+            static_in.copy_(images)
 
     def static_input(self, shape):
         """The graph's own input buffer for `shape` (write batches straight into it to skip the copy); None before the first

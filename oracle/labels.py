@@ -149,3 +149,24 @@ def nid_loss(camera, label, image_bin=16, label_bin=4, bw_camera=0.005, bw_label
     I = torch.sum(p_cl * (torch.log(p_cl + eps) - torch.log(torch.mm(p_c, p_l.t()) + eps)))
     H = -torch.sum(p_cl * torch.log(p_cl + eps))
     return ((1 - I / H) - 0.95) * 20
+
+
+def val_seg_ue(forward, loader, class_weights, ignore_idx, num_classes, aux_weight=0.5):
+    """val_seg_ue, utilities/train_eval_seg.py:249-324 (aux_weight 0.5), and the body of test(), uest_seg_multi_os.py:1150-1200
+    (aux_weight 0: criterion and MIOU on the main head alone).  forward(x) -> (main, aux) full-resolution logits.
+    Returns (iou float64[K], average loss) exactly as the reference's meters accumulate them."""
+    K = num_classes - 1
+    inter_sum, union_sum = np.zeros(K, np.float64), np.zeros(K, np.float64)
+    loss_sum, count = 0.0, 0
+    crit = torch.nn.CrossEntropyLoss(ignore_index=ignore_idx, weight=class_weights)
+    with torch.no_grad():
+        for x, y in loader:
+            main, aux = forward(x)
+            out = main + aux_weight * aux if aux_weight != 0.0 else main
+            loss = crit(out, y).mean()
+            inter, union = miou_areas(out, y, K)
+            inter_sum += inter
+            union_sum += union
+            loss_sum += float(loss.item()) * x.size(0)
+            count += x.size(0)
+    return inter_sum / (union_sum + 1e-10), loss_sum / count

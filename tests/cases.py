@@ -90,3 +90,10 @@ ASPP_CASES = {
     'aspp_bottleneck_c20': ('ASPP_Bottleneck', 20, (2, 2048, 10, 14), 400, 401),
     'aspp_c13': ('ASPP', 13, (1, 512, 20, 33), 402, 403),
 }
+
+# evaluation step (utilities/train_eval_seg.py:249-324 val_seg_ue; uest_seg_multi_os.py:1150-1200 test()): name ->
+# (classes, dataset, batch shape, batches, sd seed, first input seed, ignore_idx, class-weight seed, labels may hold 255)
+EVAL_CASES = {
+    'eval_c5_ign4': (5, 'greenhouse', (2, 3, 64, 96), 3, 61, 600, 4, 62, False),      # the uest target model: class 4 = "other" ignored
+    'eval_c13_ign255': (13, 'camvid', (3, 3, 48, 80), 2, 63, 610, 255, 64, True),     # CamVid-style: 255 = void
+}

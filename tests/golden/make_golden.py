@@ -24,8 +24,8 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, ESPDNET_CASES, IMAGEIO_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
-from tests.synth import synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
+from tests.synth import synth_eval_batches, synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
@@ -370,7 +370,50 @@ def gen_imageio():
     save('imageio', **out)
 
 
+def gen_eval():
+    """val_seg_ue (utilities/train_eval_seg.py:249-324), AST-extracted and run with the reference's own model, loss and MIOU classes on
+    a seeded loader; and the body of test() (uest_seg_multi_os.py:1150-1200): the main head alone through the same criterion / MIOU."""
+    from utilities.metrics.segmentation_miou import MIOU
+    from utilities import print_utils
+    from collections import OrderedDict
+    import time
+    ns = {'torch': torch, 'np': np, 'time': time, 'MIOU': MIOU, 'OrderedDict': OrderedDict, 'gather': None}
+    ns.update({k: getattr(print_utils, k) for k in dir(print_utils) if k.startswith('print_')})
+    tree = ast.parse(open(os.path.join(REF, 'utilities/utils.py')).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == 'AverageMeter':
+            exec(compile(ast.Module([node], []), 'utils', 'exec'), ns)
+    extract_functions(os.path.join(REF, 'utilities/train_eval_seg.py'), {'val_seg_ue'}, ns)
+    out = {}
+    for name, case in sorted(EVAL_CASES.items()):
+        C, ds, shape, nb, sd_seed, in_seed, ign, cw_seed, with_void = case
+        m = build_model('espdnetue', 2.0, C, ds).eval()
+        m.load_state_dict(synth_state_dict(m.state_dict(), sd_seed))
+        cw = torch.rand(C, generator=torch.Generator().manual_seed(cw_seed)) + 0.5
+        crit = SegmentationLoss(n_classes=C, device='cpu', ignore_idx=ign, class_weights=cw)
+        loader = synth_eval_batches(case)
+        iou, loss = ns['val_seg_ue'](m, loader, criterion=crit, num_classes=C, device='cpu')
+        out[name + '.iou'] = np.asarray(iou, dtype=np.float64)
+        out[name + '.loss'] = np.float64(loss)
+        out[name + '.cw'] = cw
+        # test() of the uest script: pred alone (":1196-1198": criterion(pred, labels); get_iou(pred, labels))
+        AverageMeter = ns['AverageMeter']
+        inter_m, union_m, losses = AverageMeter(), AverageMeter(), AverageMeter()
+        miou_class = MIOU(num_classes=C - 1)
+        with torch.no_grad():
+            for x, y in loader:
+                pred, _ = m(x)
+                l = crit(pred, y)
+                inter, union = miou_class.get_iou(pred, y)
+                inter_m.update(inter); union_m.update(union); losses.update(l.item(), x.size(0))
+        out[name + '.test_iou'] = np.asarray(inter_m.sum / (union_m.sum + 1e-10), dtype=np.float64)
+        out[name + '.test_loss'] = np.float64(losses.avg)
+        out[name + '.inter'] = np.asarray(inter_m.sum, dtype=np.float64)
+        out[name + '.union'] = np.asarray(union_m.sum, dtype=np.float64)
+    save('eval', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio', 'supervised', 'nid']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio', 'supervised', 'nid', 'eval']
     for w in which:
         globals()['gen_' + w]()

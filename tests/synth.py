@@ -94,3 +94,18 @@ def synth_nid_inputs(shape, classes, seed):
         lab[:, c][m] = top[m]
         lab[:, c + 1][m] = (top + delta)[m]
     return cam, lab
+
+
+def synth_eval_batches(case):
+    """The seeded loader of a tests.cases.EVAL_CASES entry: [(images, labels)] -- shared by the golden generator (which feeds it to
+    the reference's val_seg_ue) and the tests."""
+    C, ds, shape, nb, sd_seed, in_seed, ign, cw_seed, with_void = case
+    out = []
+    for b in range(nb):
+        x = synth_input(shape, in_seed + b)
+        y = synth_labels((shape[0],) + shape[2:], C, in_seed + b)
+        if with_void:
+            void = synth_labels((shape[0],) + shape[2:], 10, in_seed + 50 + b) == 0      # ~10 % void pixels
+            y = torch.where(void, torch.full_like(y, 255), y)
+        out.append((x, y))
+    return out

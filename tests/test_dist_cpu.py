@@ -118,6 +118,63 @@ def _check_sharded_label_function(rank, world, tmp):
             assert np.array_equal(arr, all_labels[bi][j].numpy())
 
 
+def _check_sharded_eval(rank, world):
+    """evaluation.val_seg_ue under world 2 with a CPU stand-in for the device pass: rank r evaluates batches b == r (mod world), ONE
+    all-reduce of the sums, every rank returns what the reference loop gives on the whole loader (oracle.labels.val_seg_ue)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from mspl_amd import evaluation as ev
+    from oracle import labels as olab
+    C, K = 6, 5
+    g = torch.Generator().manual_seed(23)
+    sizes = [2, 3, 1, 2, 2]                               # ragged batches, odd count
+    batches = []
+    for n in sizes:
+        y = torch.randint(0, C, (n, 10, 14), generator=g)
+        y[torch.rand(n, 10, 14, generator=g) < 0.1] = 255
+        batches.append((torch.randn(n, 3, 10, 14, generator=g), y))
+    proj = torch.randn(C, 3, generator=g)
+    cw = torch.rand(C, generator=g) + 0.5
+
+    def fwd(x):
+        main = torch.einsum('cj,njhw->nchw', proj, x)
+        return main, main.flip(1) * 0.3
+
+    class Stub(ev.EvalSums):
+        def __init__(self):
+            self.K = K
+            self.areas = torch.zeros(3, K, dtype=torch.float64)
+            self.acc = torch.zeros(2, dtype=torch.float64)
+            self.batches = 0
+
+        def __call__(self, images, labels, depth=None):
+            main, aux = fwd(images)
+            out = main + 0.5 * aux
+            pred = (out.argmax(1).to(torch.uint8) + 1) * ((labels.to(torch.uint8) + 1) > 0)
+            tgt = labels.to(torch.uint8) + 1
+            inter = pred * (pred == tgt)
+            for i, t in enumerate((inter, pred, tgt)):
+                self.areas[i] += torch.histc(t.float(), bins=K, min=1, max=K).double()
+            loss = F.cross_entropy(out, labels, weight=cw, ignore_index=255)
+            self.acc[0] += float(loss) * images.shape[0]
+            self.acc[1] += images.shape[0]
+            self.batches += 1
+
+        def sums(self):
+            return torch.cat([self.areas.reshape(-1), self.acc, torch.tensor([float(self.batches)], dtype=torch.float64)])
+
+    class Crit:
+        loss_type, class_wts, ignore_idx = 'ce', cw, 255
+    stub = Stub()
+    iou, loss = ev.val_seg_ue(None, batches, criterion=Crit(), num_classes=C, device='cpu', _eval_pass=stub)
+    assert stub.batches == len([b for b in range(len(batches)) if b % world == rank])      # this rank saw only its own batches
+    ref_iou, ref_loss = olab.val_seg_ue(fwd, batches, cw, 255, C, aux_weight=0.5)
+    assert np.allclose(iou, ref_iou, rtol=0, atol=1e-6), (iou, ref_iou)      # (the reference adds its 1e-6 in float32)
+    assert abs(loss - ref_loss) < 1e-6, (loss, ref_loss)
+    iou2, zero = ev.val_seg_ue(None, batches, criterion=None, num_classes=C, device='cpu', _eval_pass=Stub())
+    assert zero == 0 and np.allclose(iou2, ref_iou, atol=1e-6)
+
+
 def _worker(rank, world, port, q, tmp):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -154,6 +211,7 @@ def _worker(rank, world, port, q, tmp):
         assert w1.grad.data_ptr() == b.flat.data_ptr()      # grads are views of the flat bucket
         _check_flat_optimizers(rank, world)
         _check_sharded_label_function(rank, world, tmp)
+        _check_sharded_eval(rank, world)
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))

@@ -12,9 +12,9 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import ASPP_CASES, ESPDNET_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
 from tests.conftest import GOLDEN
-from tests.synth import synth_input, synth_labels, synth_state_dict
+from tests.synth import synth_eval_batches, synth_input, synth_labels, synth_state_dict
 
 KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
 
@@ -198,3 +198,21 @@ def test_espdnet_forward(name, golden):
     with torch.no_grad():
         y = onet.espdnet_forward(sd, x, x_d, dense_fuse=dense, trainable_fusion=trainable)
     torch.testing.assert_close(y, torch.from_numpy(golden('rgbd')[name]), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', sorted(EVAL_CASES))
+def test_eval_step(name, golden):
+    """oracle.labels.val_seg_ue against the reference's own val_seg_ue (AST-extracted, tests/golden/make_golden.py gen_eval) and
+    against the body of the uest script's test() (main head alone)."""
+    g = golden('eval')
+    C, ds, shape, nb, sd_seed, in_seed, ign, cw_seed, with_void = EVAL_CASES[name]
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % C], sd_seed)
+    cw = torch.from_numpy(g[name + '.cw'])
+    loader = synth_eval_batches(EVAL_CASES[name])
+    fwd = lambda x: onet.espdnet_ue_forward(sd, x)
+    iou, loss = olab.val_seg_ue(fwd, loader, cw, ign, C, aux_weight=0.5)
+    np.testing.assert_allclose(iou, g[name + '.iou'], rtol=0, atol=1e-6)
+    assert abs(loss - float(g[name + '.loss'])) < 2e-5
+    iou0, loss0 = olab.val_seg_ue(fwd, loader, cw, ign, C, aux_weight=0.0)
+    np.testing.assert_allclose(iou0, g[name + '.test_iou'], rtol=0, atol=1e-6)
+    assert abs(loss0 - float(g[name + '.test_loss'])) < 2e-5
