@@ -251,10 +251,12 @@ def three_source_rate(dev, iters=20):
     return out
 
 
-def train_step_rate(dev, iters=10, world=1, rank=0):
-    """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
-    KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as one hipGraph replay
-    (+ the Adam kernel) per step.  Extra field; `value` stays the label-pass metric."""
+TRAIN_BYTES_PER_IMAGE = 3 * 306.9e6      # forward + data-gradient + weight-gradient passes over SURVEY 8(d)'s 306.9 MB/image (C=5, 256x480)
+
+
+def train_step_build(dev, rank=0):
+    """Everything of the uest train step that can fail on one rank alone (model, first eager step, graph capture), WITHOUT a
+    collective: under N > 1 it runs inside mspl_amd.dist.local_only()."""
     import torch
     from mspl_amd import models, training
     from tests.synth import synth_state_dict
@@ -268,6 +270,13 @@ def train_step_rate(dev, iters=10, world=1, rank=0):
     # the batch of 16 runs as 4 concurrent micro-batch graphs (same step: frozen BN, mean loss, atomic gradient sinks)
     lanes = int(os.environ.get('MSPL_TRAIN_LANES', '4'))
     step = training.GraphedTrainStep(m, x, y, torch.ones(5), ignore_idx=4, lanes=lanes)
+    return step, x, y
+
+
+def train_step_time(step, x, y, dev, iters=10, world=1, repeats=3):
+    """Timed part: `iters` steps between fences, `repeats` times, the median repetition (N > 1: one flat-bucket gradient all-reduce
+    per step inside the loop, MAX over ranks per repetition)."""
+    import torch
     import torch.distributed as dist
 
     def fence():
@@ -276,30 +285,82 @@ def train_step_rate(dev, iters=10, world=1, rank=0):
         torch.cuda.synchronize()
     for _ in range(2):
         step(x, y)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        loss = step(x, y)
-    fence()
-    dt = (time.perf_counter() - t0) / iters
+    samples = []
+    for _ in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss = step(x, y)
+        fence()
+        samples.append((time.perf_counter() - t0) / iters)
     in_sync = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor(samples, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        samples = [float(v) for v in t.tolist()]
         # data-parallel invariant: identical initial weights + averaged gradients => identical weights on every rank
         chk = step.optimizer.flat_p.double().sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool((hi - lo).abs().item() == 0.0)
-    return {'value': round(BATCH * world / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
+    dt = sorted(samples)[len(samples) // 2]
+    achieved = TRAIN_BYTES_PER_IMAGE * BATCH / dt / 1e9
+    return {'value': round(BATCH * world / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters, 'repeats': repeats,
+            'ms_per_step_min_max': [round(min(samples) * 1e3, 3), round(max(samples) * 1e3, 3)],
             'n_gpus': world, 'global_batch': BATCH * world,
             'micro_batch_lanes': step.lanes,
             'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay (%d concurrent micro-batch graphs) + ' % step.lanes +
                         ('one flat-bucket gradient all-reduce (%d floats, RCCL) + ' % step.optimizer.flat_g.numel() if world > 1 else '') +
                         'Adam kernel',
+            # forward + backward against the HBM roof: algorithmic bytes = 3 x the forward's (each layer's input and output are moved
+            # once by the forward, once by the data gradient, once by the weight gradient; BN / PReLU / add / cat fused = 0), DESIGN 7
+            'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_image': TRAIN_BYTES_PER_IMAGE, 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4)},
             'weights_identical_across_ranks': in_sync, 'loss_finite': bool(torch.isfinite(loss))}
+
+
+def train_step_rate(dev, iters=10, world=1, rank=0):
+    """BASELINE configs[2]'s other half, reported beside the headline: the uest train step (frozen-BN forward, fused
+    KLD + uncertainty-weighted CE, backward, Adam) of the 5-class target model, bs=16 at 256x480, as hipGraph replays
+    (+ the Adam kernel) per step.  Extra field; `value` stays the label-pass metric."""
+    step, x, y = train_step_build(dev, rank)
+    return train_step_time(step, x, y, dev, iters, world)
+
+
+def eval_step_rate(dev, iters=20):
+    """The evaluation step of the loop (utilities/train_eval_seg.py:249-324 val_seg_ue; uest_seg_multi_os.py:1150-1200 test()):
+    forward -> out + 0.5*aux -> weighted cross entropy -> MIOU areas of the 5-class target model, bs=16 at 256x480, one hipGraph
+    replay per batch (forward_lowres + the fused eval epilogue; full-resolution logits are never written).  Extra field."""
+    import torch
+    from mspl_amd import evaluation, models
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 9))
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((BATCH, 3, 256, 480), generator=g).to(dev)
+    y = torch.randint(0, 5, (BATCH, 256, 480), generator=g).to(dev)
+    ep = evaluation.EvalPass(m, 5, class_weights=torch.ones(5), ignore_idx=4, aux_weight=0.5, device=dev, use_graph=True)
+    for _ in range(3):
+        ep(x, y)
+    ep.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ep(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    iou, loss = ep.result(reduce=False)
+    return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_batch': round(dt * 1e3, 3), 'batches': iters,
+            'workload': 'val_seg_ue step, ESPDNet-UE s=2.0 C=5, bs=16 x 3 x 256 x 480 fp32: forward + out+0.5*aux + weighted CE + MIOU '
+                        'areas, one hipGraph replay per batch',
+            'loss_finite': bool(np_isfinite(loss)), 'pixels_counted': int(ep.areas[2].sum().item())}
+
+
+def np_isfinite(v):
+    import math
+    return math.isfinite(float(v))
 
 
 def supervised_step_rate(dev, iters=6):
@@ -457,14 +518,57 @@ def main():
             dist.destroy_process_group()
         return
 
-    # N > 1: the data-parallel train step on every rank (configs[3]: the gradient all-reduce over xGMI is the path's only
-    # data collective).  Every rank takes part; a failure is reported in the field instead of costing the label-pass line.
-    train_multi = None
+    # N > 1 (configs[3]: the same 3-source pipeline sharded over the GPUs): every rank runs the 3-source label pass and the
+    # evaluation step on its own shard (no collective inside: only the slowest rank's time is reduced afterwards) and the
+    # data-parallel train step (the gradient all-reduce over xGMI is the path's only data collective).  Whatever can fail on one
+    # rank alone runs WITHOUT collectives first; the ranks then agree on success with one all-reduce, so a rank that raised never
+    # leaves the others blocked in a collective it will not join.
+    multi = {}
     if world > 1 and not args.no_train:
+        from mspl_amd import dist as mdist
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        def per_rank(name, fn):
+            res, err = None, None
+            try:
+                with mdist.local_only():
+                    res = fn(dev)
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)[:300]
+            if not all_ok(err is None):
+                multi[name] = {'error': err or 'another rank failed', 'skipped_on_all_ranks': True}
+                return
+            t = torch.tensor([BATCH / res['value']], device=dev, dtype=torch.float64)      # seconds per batch on this rank
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res = dict(res, value=round(BATCH * world / float(t.item()), 1), n_gpus=world,
+                       note='every rank on its own shard, no data-path collective; value = images of all ranks / slowest rank\'s time')
+            multi[name] = res
+        if not args.no_three_source:
+            per_rank('three_source', three_source_rate)
+        per_rank('eval_step', eval_step_rate)
+        built, err = None, None
         try:
-            train_multi = train_step_rate(dev, world=world, rank=rank)
+            with mdist.local_only():
+                built = train_step_build(dev, rank)
         except Exception as e:      # noqa: BLE001
-            train_multi = {'error': repr(e)[:300]}
+            err = repr(e)[:300]
+        if all_ok(err is None):
+            step_, x_, y_ = built
+            # the set-up steps ran without the gradient exchange: put every rank back on rank 0's weights and optimizer state
+            for t_ in (step_.optimizer.flat_p, step_.optimizer.m, step_.optimizer.v):
+                dist.broadcast(t_, src=0)
+            from mspl_amd import layers as _L
+            _L.bump_param_epoch()
+            try:
+                multi['train_step'] = train_step_time(step_, x_, y_, dev, world=world)
+            except Exception as e:      # noqa: BLE001
+                multi['train_step'] = {'error': repr(e)[:300]}
+        else:
+            multi['train_step'] = {'error': err or 'another rank failed', 'skipped_on_all_ranks': True}
 
     # the same K steps with ONE pass in flight (lane 0 alone, back to back): the per-batch latency, reported beside the value
     single = None
@@ -705,8 +809,7 @@ def main():
             # per-kernel table of one label pass (us, MB, fraction of the HBM roof), from a rocprofv3 --kernel-trace --stats run of
             # `bench.py --profile-pass --in-flight 1` (no K2 re-issues in it) + the PMC traffic passes; tools/per_kernel.py
             out['per_kernel'] = json.load(open(pk))
-        if train_multi is not None:
-            out['train_step'] = train_multi
+        out.update(multi)
         def extra(name, fn, *a_):
             # an extra field that fails is reported inside the line; it never costs the headline
             try:
@@ -717,6 +820,7 @@ def main():
             extra('three_source', three_source_rate, dev)
         if world == 1 and not args.no_train:
             extra('train_step', train_step_rate, dev)
+            extra('eval_step', eval_step_rate, dev)
             extra('supervised_step', supervised_step_rate, dev)
         if world == 1 and not args.no_aspp:
             extra('aspp_head', aspp_head_rate, dev)

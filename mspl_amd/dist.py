@@ -12,8 +12,25 @@ import torch
 import torch.distributed as dist
 
 
+_LOCAL_ONLY = [False]
+
+
+class local_only(object):
+    """with local_only(): every helper of this module behaves as in a single process (no collective is issued) although a process
+    group exists.  For set-up work that may fail on ONE rank (graph capture, allocation): a rank that raises inside a collective
+    section leaves the others blocked in theirs; do the risky part locally, agree on success with one all-reduce, then enter the
+    collective section (bench.py --gpus N)."""
+
+    def __enter__(self):
+        self.prev = _LOCAL_ONLY[0]
+        _LOCAL_ONLY[0] = True
+
+    def __exit__(self, *exc):
+        _LOCAL_ONLY[0] = self.prev
+
+
 def world():
-    if dist.is_available() and dist.is_initialized():
+    if dist.is_available() and dist.is_initialized() and not _LOCAL_ONLY[0]:
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
