@@ -25,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
-from tests.synth import synth_eval_batches, synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
+from tests.synth import grad_sample_index, synth_eval_batches, synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
@@ -257,7 +257,17 @@ def gen_train():
             'depth_base_net.level3.1.proj_1x1.act.weight', 'aux_decoder.stages.0.weight',
             'merge_enc_dec_l3.wt_layer.1.weight', 'bu_br_l3.0.weight', 'base_net.level2_0.inp_reinf.1.bn.bias']
     pd = dict(m.named_parameters())
+    # a strided sample of EVERY gradient (up to ~64 elements per tensor, first and last element included): norms alone would pass a
+    # sign or permutation error inside a tensor
+    gs_val, gs_off = [], [0]
+    for _, p_ in m.named_parameters():
+        if p_.grad is not None:
+            flat = p_.grad.detach().reshape(-1)
+            idx = grad_sample_index(flat.numel())
+            gs_val.append(flat[idx].numpy())
+        gs_off.append(gs_off[-1] + (len(gs_val[-1]) if p_.grad is not None else 0))
     save('train_step', loss=loss.detach(), names=np.array(names), gnorm=gnorm, gsum=gsum, delta=delta,
+         gsample=np.concatenate(gs_val), gsample_off=np.array(gs_off, dtype=np.int64),
          keep=np.array(keep), **{'after_%d' % i: pd[k].detach() for i, k in enumerate(keep)})
 
 

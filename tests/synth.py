@@ -109,3 +109,12 @@ def synth_eval_batches(case):
             y = torch.where(void, torch.full_like(y, 255), y)
         out.append((x, y))
     return out
+
+
+def grad_sample_index(numel):
+    """Indices of the strided gradient sample kept in tests/golden/train_step.npz (shared by generator and test)."""
+    step = max(1, numel // 64)
+    idx = list(range(0, numel, step))
+    if idx[-1] != numel - 1:
+        idx.append(numel - 1)
+    return torch.tensor(idx, dtype=torch.int64)

@@ -124,9 +124,13 @@ def test_config3_train_step_bs16_256x480():
 def test_pipelined_label_pass_equals_single_lane(depth, group):
     """`depth` label passes in flight (PipelinedLabelPass, hipGraph lanes on their own streams; 3 = bench.py's default): the same
     label maps, uncertainty maps and class histogram as one pass at a time, batch by batch, at the BASELINE shape.  group > 1:
-    that many consecutive batches per launch (bench.py: 2); 7 batches leave a partly filled lane for flush()."""
+    that many consecutive batches per launch (bench.py: 2); 7 batches leave a partly filled lane for flush().
+    Bit equality is a CONTRACT here, not an accident of summation order: the reference pass is captured with the same launch
+    flags as the lanes (MSPL_LAUNCH_THROUGHPUT: K1 and K2 as two launches), so both sides run the same kernels on the same inputs;
+    images are independent, so neither the lane nor the batches-per-launch may change a bit.  (The fused K1+K2 form a lone pass
+    uses by default may differ from the two-launch form in the last bits: test_eesp_proj_dw_hff covers that with a tolerance.)"""
     import argparse
-    from mspl_amd import models, uest
+    from mspl_amd import models, ops, uest
     from tests.synth import synth_state_dict
     a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
     m = models.ESPDNetwithUncertaintyEstimation(a, classes=13, dataset='camvid', fix_pyr_plane_proj=True)
@@ -136,9 +140,10 @@ def test_pipelined_label_pass_equals_single_lane(depth, group):
     batches = [torch.randn((16, 3, 288, 480), generator=g).cuda() for _ in range(7)]
     ref = uest.SelfLabelPass(m, classes=13, use_graph=True)
     want = []
-    for b in batches:
-        lab, kld = ref(b)
-        want.append((lab.clone(), kld.clone()))
+    with ops.launch_flags(throughput=True):
+        for b in batches:
+            lab, kld = ref(b)
+            want.append((lab.clone(), kld.clone()))
     plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=13, use_graph=True), depth=depth, group=group)
     got = []
     for b in batches:
@@ -246,3 +251,56 @@ def test_aspp_dense_conv_full_size_properties():
                 ref = ref + (w[:, :, ky, kx].double() @ xi[:, yy, xx])
     ref = torch.relu(ref * scale.double() + shift.double())
     np.testing.assert_allclose(full[2, :, 0, 0].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_pipelined_static_inputs_after_partial_launch():
+    """PipelinedLabelPass.next_lane after an odd number of batches + flush() (a partly filled lane was labelled by a shorter launch):
+    the index must name the slot the NEXT batch is staged into -- lane (launches so far) % depth, slot 0 -- not a position derived from
+    the number of calls.  Writing a batch into static_inputs()[next_lane] and submitting that view must neither copy the batch (the
+    submit sees its own buffer) nor label another lane's data (round 2's index pointed at a slot whose launch had just been issued)."""
+    import argparse
+    from unittest import mock
+    from mspl_amd import models, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 5))
+    m = m.cuda().eval()
+    shape = (4, 3, 128, 160)
+    g = torch.Generator().manual_seed(31)
+    batches = [torch.randn(shape, generator=g).cuda() for _ in range(12)]
+    ref = uest.SelfLabelPass(m, classes=5, use_graph=False)
+    want = [ref(b)[0].clone() for b in batches]
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=5, use_graph=True), depth=3, group=2)
+    for b in batches[:6]:                    # every lane captures its full-group graph
+        plp(b)
+    list(plp.flush())
+    for b in batches[:5]:                    # odd: the third launch is partly filled
+        plp(b)
+    list(plp.flush())
+    xs = plp.static_inputs(shape)
+    assert all(x is not None for x in xs) and len(xs) == 6
+    big_copies = []
+    real_copy = torch.Tensor.copy_
+
+    def counting_copy(self, src, *a_, **kw):
+        if self.numel() >= batches[0].numel():
+            big_copies.append(tuple(self.shape))
+        return real_copy(self, src, *a_, **kw)
+    got, slots = [], []
+    for i, b in enumerate(batches[5:12]):
+        k = plp.next_lane
+        slots.append(k)
+        xs[k].copy_(b)                        # the caller fills the slot it was told about (on the current stream)
+        with mock.patch.object(torch.Tensor, 'copy_', counting_copy):
+            out = plp(xs[k])
+        if out is not None:
+            got.append(out[0].clone())
+    got += [o[0].clone() for o in plp.flush()]
+    torch.cuda.synchronize()
+    assert not big_copies, big_copies        # every submit found the batch already in its staging slot
+    # after 3 + 3 launches the next lane is 0: slots 0,1 (lane 0), 2,3 (lane 1), 4,5 (lane 2), then lane 0 again
+    assert slots == [0, 1, 2, 3, 4, 5, 0], slots
+    assert len(got) == 7
+    for l1, l0 in zip(got, want[5:12]):
+        assert torch.equal(l1, l0)

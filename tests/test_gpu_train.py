@@ -196,6 +196,17 @@ def test_train_step_vs_reference_golden(golden):
             got = float(p.grad.double().norm())
             assert abs(got - gn) <= 5e-3 * gn + 1e-6, (n, got, gn)
     assert n_with == 340
+    # element by element on a strided sample of every gradient (norms alone would pass a sign / permutation error inside a tensor)
+    from tests.synth import grad_sample_index
+    off = g['gsample_off']
+    for i, n in enumerate(names):
+        if g['gnorm'][i] < 0:
+            continue
+        p = params[n]
+        ref = torch.from_numpy(g['gsample'][off[i]:off[i + 1]])
+        got = p.grad.detach().reshape(-1).cpu()[grad_sample_index(p.numel())]
+        scale = float(g['gnorm'][i]) / max(1.0, p.numel() ** 0.5)          # typical element size of this gradient
+        assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 5e-3 * scale + 1e-7, (n, got[:4], ref[:4])
     opt = training.FlatAdam(m.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
     assert len(opt.params) == 340 and opt.flat_p.numel() == sum(p.numel() for p in opt.params)
     opt.step()
