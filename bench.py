@@ -183,13 +183,19 @@ def loader_io_rate(dev, iters=20):
                                  device=dev, group=2)
     pinned = torch.from_numpy(frames).pin_memory()
     pre288 = Preprocessor(size=(480, 288))
+    from mspl_amd.io import default_writer_workers
+    workers = default_writer_workers()                         # PNG encoding is the host-side limit of the chain: 12 of the box's 16 cores
     with tempfile.TemporaryDirectory() as d:
-        w = LabelWriter(d, workers=8)
+        w = LabelWriter(d, workers=workers)
         w.warm((BATCH, 288, 480))
 
         def chain(nb):
+            # the transform writes the network input straight into the static input slot of the lane that labels it (no copy);
+            # before a lane's first launch there is no slot yet and the pass stages the batch itself
+            xs = lp.static_inputs((BATCH, 3, 288, 480))
             for _ in range(nb):
-                r = lp(pre288(pinned)[0])
+                slot = xs[lp.next_lane] if xs else None
+                r = lp(pre288(pinned, out=slot)[0])
                 if r is not None:
                     w.submit(names, r[0])
             for r in lp.flush():
@@ -197,7 +203,7 @@ def loader_io_rate(dev, iters=20):
         chain(12)                                             # warm-up: graph capture on every lane, allocator steady state
         w._retire('all')
         torch.cuda.synchronize()
-        nb = 36
+        nb = 72
         t0 = time.perf_counter()
         chain(nb)
         torch.cuda.synchronize()
@@ -205,8 +211,9 @@ def loader_io_rate(dev, iters=20):
         w.close()
         t_all = time.perf_counter() - t0
     out['end_to_end'] = {'value': round(nb * BATCH / t_all, 1), 'unit': 'images/s', 'gpu_side_images_per_s': round(nb * BATCH / t_gpu, 1),
-                         'workload': 'pinned uint8 360x480 frames -> H2D -> Resize(480x288)+Normalize -> ESPDNet-UE C=13 label pass (3 batches in '
-                                     'flight) -> async D2H + PNG files, %d batches of %d' % (nb, BATCH)}
+                         'writer_workers': workers,
+                         'workload': 'pinned uint8 360x480 frames -> H2D -> Resize(480x288)+Normalize written into the lane\'s input slot -> ESPDNet-UE C=13 '
+                                     'label pass (3 launches in flight, 2 batches per launch) -> async D2H + PNG files, %d batches of %d' % (nb, BATCH)}
     return out
 
 

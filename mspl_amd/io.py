@@ -24,6 +24,20 @@ import torch
 
 from ._native import check, lib
 
+def host_cores():
+    """Cores this process may run on (the affinity mask where the platform has one: a container's share, not the machine)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def default_writer_workers(world=1):
+    """PNG encoding is the host-side limit of the label loop (18 400 images/s with 8 workers against 15 000 from the GPU): most of
+    this rank's share of the cores, at most 12."""
+    return max(4, min(12, host_cores() // max(1, min(world, 8)) - 2))
+
+
 MEAN = [0.485, 0.456, 0.406]      # transforms/classification/data_transforms.py:10-11
 STD = [0.229, 0.224, 0.225]
 
@@ -107,7 +121,7 @@ class Preprocessor(object):
             raise RuntimeError('mspl_amd: %s must be a uint8 tensor with %d dims, got %s %s' % (name, ndim, t.dtype, tuple(t.shape)))
         return t.to(self.device, non_blocking=True).contiguous()
 
-    def _bilinear(self, src, C, mean, std, flip):
+    def _bilinear(self, src, C, mean, std, flip, out=None):
         N, Hs, Ws = src.shape[:3]
         W, H = self.size
         yb, yk, ky = self._bilinear_tables(Hs, H)
@@ -116,14 +130,20 @@ class Preprocessor(object):
         if Ws != W:
             xb, xk, kx = self._bilinear_tables(Ws, W)
             tmp = torch.empty((N, Hs, W, C), dtype=torch.uint8, device=self.device)
-        out = torch.empty((N, C, H, W), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((N, C, H, W), dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (N, C, H, W) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+            raise RuntimeError('mspl_amd: Preprocessor out= must be a contiguous CUDA float32 tensor of shape %s, got %s %s'
+                               % ((N, C, H, W), tuple(out.shape), out.dtype))
         p = lambda t: None if t is None else t.data_ptr()
         check(lib.mspl_preprocess_u8_fwd(src.data_ptr(), N, Hs, Ws, C, H, W, p(xb), p(xk), kx, yb.data_ptr(), yk.data_ptr(), ky,
                                          p(mean), p(std), p(flip), p(tmp), out.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream))
         return out
 
-    def __call__(self, rgb, label=None, depth=None, flip=None):
+    def __call__(self, rgb, label=None, depth=None, flip=None, out=None):
+        """out: optional destination of the image tensor (N,3,H,W) -- e.g. the static input slot of a captured label pass
+        (PipelinedLabelPass.static_inputs()[next_lane]): the transform then writes the network input in place, no copy follows."""
         rgb = self._up(rgb, 'rgb', 4)
         if rgb.shape[3] != 3:
             raise RuntimeError('mspl_amd: rgb must be (N,H,W,3) uint8, got %s' % (tuple(rgb.shape),))
@@ -132,7 +152,7 @@ class Preprocessor(object):
             flip = torch.as_tensor(flip).to(torch.uint8).to(self.device).contiguous()
             if flip.numel() != N:
                 raise RuntimeError('mspl_amd: flip needs one flag per image')
-        x = self._bilinear(rgb, 3, self.mean if self.normalize else None, self.std if self.normalize else None, flip)
+        x = self._bilinear(rgb, 3, self.mean if self.normalize else None, self.std if self.normalize else None, flip, out)
         y = d = None
         if label is not None:
             label = self._up(label, 'label', 3)

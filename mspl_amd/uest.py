@@ -467,7 +467,7 @@ class PipelinedLabelPass:
 
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
-                                      use_graph=True, writer_workers=4, in_flight=3, pre_sharded=False, _label_pass=None,
+                                      use_graph=True, writer_workers=None, in_flight=3, pre_sharded=False, _label_pass=None,
                                       batches_per_launch=1):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
@@ -494,6 +494,9 @@ def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save
                                 device=device, use_graph=use_graph), depth=in_flight, device=device, group=batches_per_launch)
     p.reset()
     tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
+    if writer_workers is None:
+        from .io import default_writer_workers
+        writer_workers = default_writer_workers(world)
     writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)
     names, batch_sizes = [], []
     for b, batch in enumerate(testloader):
