@@ -5,6 +5,8 @@
 // p0 + 4h of row r of BOTH operands, element j of the two float4 is a valid (A, B) pair for one MFMA -- no LDS, no transposes,
 // eight pixels per iteration, every byte loaded is used.  Partial tiles are combined with float atomics (gw zeroed by the
 // launcher, or the parameter's gradient buffer when accumulating).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -14,37 +16,43 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct WgG {
     int N, G, M, K, P;          // images, groups, cout_g, cin_g, pixels per plane
     int tm, tk;                 // 32-tiles along M and K
-    int nslots, reps;           // waves per (tile, image) (multiple of 4: one workgroup = 4 slots of one tile), 64-pixel groups per wave
+    int gpi;                    // 64-pixel groups per image
+    int ngroups;                // N * gpi: the reduction range a tile's waves share
+    int nslots;                 // waves per tile (multiple of 4: one workgroup = 4 slots of one tile)
 };
 
-// One wave: `reps` groups of 64 pixels.  All 16 float4 of a group (8 per operand) are requested before the first MFMA, so a
-// wave exposes ONE memory latency per 32 MFMAs (the first version waited on memory every 8 MFMAs and ran at the speed of
-// the load latency).  The four waves of a workgroup hold four slices of the same tile: they are summed through LDS and
-// leave with one atomic per tile element.
+// One wave: the 64-pixel groups slot, slot + nslots, ... of the flattened (image, pixel group) range of its tile -- several
+// images per wave.  (Rounds 1-2: a wave saw ONE image, so the 18x30 planes of level 4 gave every wave a single group of 32 MFMAs
+// and every workgroup left with 1024 atomics: 2 M device atomics per launch; now a tile's waves number what fills the chip, not
+// what the plane size dictates: 740 -> 590 us per train step over the 33 launches.)  All 16 float4 of a group (8 per operand) are
+// requested before the first MFMA, so a wave exposes ONE memory latency per 32 MFMAs.  (A two-stage software pipeline over the
+// groups -- next group's requests before this group's MFMAs -- measured no faster: 24 us either way for the 512 -> 512 expansion
+// at 18x30, whose fp32 MFMA floor is 6.5 us.)  The four waves of a workgroup hold four slices of the same tile: they are summed
+// through LDS and leave with one atomic per tile element.
 __global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
                                                                  float* __restrict__ gw) {
     __shared__ float red[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int bslots = g.nslots >> 2;                                   // workgroups per (tile, image)
+    const int bslots = g.nslots >> 2;                                   // workgroups per tile
     const int64_t bid = blockIdx.x;
-    const int64_t tn = bid / bslots;                                    // (tile, image)
-    const int slot = (int)(bid - tn * bslots) * 4 + wave;
-    const int64_t tile = tn / g.N;
-    const int n = (int)(tn - tile * g.N);
+    const int64_t tile = bid / bslots;
+    const int slot = (int)(bid - tile * bslots) * 4 + wave;
     const int grp = (int)(tile / (g.tm * g.tk));
     const int tt = (int)(tile - (int64_t)grp * g.tm * g.tk);
     const int m0 = (tt / g.tk) * 32, k0 = (tt % g.tk) * 32;
     const bool am = m0 + r < g.M, bk = k0 + r < g.K;
     // rows outside the tile read row 0 of the tile (always valid); their products land in elements that are never stored
-    const float* ap = gy + ((size_t)n * g.G * g.M + (size_t)grp * g.M + m0 + (am ? r : 0)) * (size_t)g.P;
-    const float* bp = x + ((size_t)n * g.G * g.K + (size_t)grp * g.K + k0 + (bk ? r : 0)) * (size_t)g.P;
+    const float* ap0 = gy + ((size_t)grp * g.M + m0 + (am ? r : 0)) * (size_t)g.P;
+    const float* bp0 = x + ((size_t)grp * g.K + k0 + (bk ? r : 0)) * (size_t)g.P;
+    const size_t aimg = (size_t)g.G * g.M * g.P, bimg = (size_t)g.G * g.K * g.P;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int rep = 0; rep < g.reps; ++rep) {
-        const int p0 = (slot + rep * g.nslots) * 64;
-        if (p0 >= g.P) break;                                           // wave-uniform
+    for (int q = slot; q < g.ngroups; q += g.nslots) {                  // wave-uniform
+        const int n = q / g.gpi, p0 = (q - n * g.gpi) * 64;
+        const float* ap = ap0 + (size_t)n * aimg;
+        const float* bp = bp0 + (size_t)n * bimg;
         float4 a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -87,13 +95,19 @@ int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M,
     g.N = N; g.G = G; g.M = M; g.K = K; g.P = P;
     g.tm = ceil_div(M, 32); g.tk = ceil_div(K, 32);
     const int64_t tiles = (int64_t)G * g.tm * g.tk;
-    const int groups = ceil_div(P, 64);
-    // ~16k waves at most: more 64-pixel groups per wave when the plane is large
-    int reps = 1;
-    while (tiles * N * ceil_div(groups, reps) > 16384 && reps < groups) reps *= 2;
-    g.reps = reps;
-    g.nslots = (ceil_div(groups, reps) + 3) & ~3;
-    const int64_t blocks = tiles * N * (g.nslots >> 2);
+    g.gpi = ceil_div(P, 64);
+    if ((int64_t)N * g.gpi >= (1ll << 30)) return 1;
+    g.ngroups = N * g.gpi;
+    // waves per tile: enough to put ~3 waves on every SIMD (MSPL_WGRAD_WAVES, 3072), at least MSPL_WGRAD_MINREP pixel groups per
+    // wave when the range allows (each workgroup leaves with 1024 atomics), never more waves than groups
+    static const int target = getenv("MSPL_WGRAD_WAVES") ? atoi(getenv("MSPL_WGRAD_WAVES")) : 3072;
+    static const int minrep = getenv("MSPL_WGRAD_MINREP") ? atoi(getenv("MSPL_WGRAD_MINREP")) : 1;
+    int64_t ns = (target + tiles - 1) / tiles;
+    if (ns * minrep > g.ngroups) ns = g.ngroups / (minrep > 0 ? minrep : 1);
+    if (ns < 4) ns = 4;
+    if (ns > g.ngroups) ns = g.ngroups;
+    g.nslots = (int)((ns + 3) & ~3ll);
+    const int64_t blocks = tiles * (g.nslots >> 2);
     if (blocks >= (1ll << 31)) return 1;
     hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, gw);
     return 0;
