@@ -328,6 +328,9 @@ class FanOutFn(torch.autograd.Function):
         return out, None
 
 
+_FUSED_EESP_BWD = os.environ.get('MSPL_FUSED_EESP_BWD', '1') != '0'
+
+
 def _stack4(ws):
     """(4, n, 3, 3) tensor of the four depthwise branch weights: a VIEW when they sit back to back in one storage (the flat
     parameter buffer of FlatAdam / FlatSGD lays consecutive parameters out contiguously), else a torch.stack copy."""
@@ -394,17 +397,22 @@ class EESPFn(torch.autograd.Function):
         d_g2 = s_g2 if s_g2 is not None else acc[0]
         d_b2 = s_b2 if s_b2 is not None else acc[1]
         d_a2 = s_a2 if s_a2 is not None else acc[2]
-        gs = torch.empty((4, N, n, Ho, Wo), device=dev, dtype=torch.float32)
-        check(lib.mspl_hff_bn_prelu_suffix_bwd(_p(z2), _p(gy2), _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, Ho * Wo, _p(gs),
-                                               _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
-        # the four depthwise branches
         go1 = torch.empty_like(o1)
         wsinks = sk['w4']
         tmp = torch.zeros((4,) + ctx.wshape, device=dev, dtype=torch.float32) if any(t is None for t in wsinks) else None
         dst = [wsinks[k] if wsinks[k] is not None else tmp[k] for k in range(4)]
         ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dst])
         dil_c = (ctypes.c_int32 * 4)(*dil)
-        check(lib.mspl_eesp_dw_bwd(_p(gs), _p(o1), _p(w4), dil_c, stride, N, n, H, W, _p(go1), ptrs, _stream()))
+        if stride == 1 and _FUSED_EESP_BWD and lib.mspl_eesp_bwd_fused_fits(N, n, H, W, dil_c):
+            # one launch: BatchNorm/PReLU backward + suffix sum + both gradients of the four branches (no suffix-summed tensor in memory)
+            check(lib.mspl_eesp_bwd_fused(_p(z2), _p(gy2), _p(o1), _p(w4), dil_c, _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, H, W,
+                                          _p(go1), ptrs, _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
+        else:
+            gs = torch.empty((4, N, n, Ho, Wo), device=dev, dtype=torch.float32)
+            check(lib.mspl_hff_bn_prelu_suffix_bwd(_p(z2), _p(gy2), _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, Ho * Wo, _p(gs),
+                                                   _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
+            # the four depthwise branches
+            check(lib.mspl_eesp_dw_bwd(_p(gs), _p(o1), _p(w4), dil_c, stride, N, n, H, W, _p(go1), ptrs, _stream()))
         # proj_1x1's BatchNorm + PReLU and the convolution; the residual link's gradient rides on the data gradient's epilogue
         gc1, _, r_gp, r_bp, r_ap = _affine_backward(c1, sp, hp, ap, None, None, mp, ip, True, sk['p'], go1)
         gx = gwp = None

@@ -151,3 +151,209 @@ extern "C" int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4
     }
     return MSPL_OK;
 }
+
+namespace mspl {
+
+// ------------------------------------------------------------------------------------------------ stride-1 blocks, one launch
+// The whole backward between conv_1x1_exp's data gradient and proj_1x1's BatchNorm of a stride-1 EESP block in ONE kernel:
+//     gc_k  = gy_k * (u_k > 0 ? 1 : alpha_k) * scale_k,  u_k = z_k * scale_k + shift_k        br_after_cat's BatchNorm + PReLU backward
+//     G_k   = sum_{m >= k} gc_m                                                                the HFF suffix sum
+//     gx    = sum_k sum_taps w_k[tap] * G_k[. - d_k * (tap - 1)]                               data gradient of the four branches
+//     gw_k[tap] += sum G_k[.] * x[. + d_k * (tap - 1)]                                         their weight gradients
+//     d gamma / d beta / d alpha of br_after_cat
+// (four launches before: mspl_hff_bn_prelu_suffix_bwd, which wrote the 4n-channel suffix-summed gradient, and the two kernels
+// above, which read it back: 64 us per level-4 block for ~50 MB.)  A workgroup owns a band of rows of one (image, channel j):
+// the four branch planes' G_k and the block input x are staged in LDS with a zero halo of the largest dilation (the band's halo
+// rows are recomputed from gy / z, they are not exchanged), every thread then takes pixels of the band: 36 + 36 multiply-adds from
+// LDS per pixel.  Nothing but gy, z and x is read, nothing but gx is written.
+constexpr int FB_MAXD = 4;
+
+struct FbGeom {
+    int N, n, H, W;
+    int BH, bands;             // rows per band, bands per plane
+    int WT;                    // LDS row stride: W + 2 * FB_MAXD
+    int dil[4];
+};
+
+__global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                             const float* __restrict__ x, const float* __restrict__ w4,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ alpha, const float* __restrict__ bn_mean,
+                                                             const float* __restrict__ bn_inv, FbGeom g, float* __restrict__ gx,
+                                                             GwPtrs gw, float* __restrict__ gscale, float* __restrict__ gshift,
+                                                             float* __restrict__ galpha) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[4][12];
+    int b = blockIdx.x;
+    const int band = b % g.bands;  b /= g.bands;
+    const int j = b % g.n;
+    const int img = b / g.n;
+    const int H = g.H, W = g.W, WT = g.WT;
+    const int y0 = band * g.BH, y1 = min(y0 + g.BH, H);
+    const int BHT = g.BH + 2 * FB_MAXD;
+    const int tile = BHT * WT;
+    float* GS = smem;                       // [4][BHT][WT]
+    float* XS = smem + 4 * tile;            // [BHT][WT]
+    const int tid = threadIdx.x;
+    const size_t pl = (size_t)H * W;
+    const float* xp = x + ((size_t)img * g.n + j) * pl;
+    float sc[4], sh[4], al[4];
+    const bool act = alpha != nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ch = k * g.n + j;
+        sc[k] = scale ? scale[ch] : 1.f;  sh[k] = shift ? shift[ch] : 0.f;  al[k] = act ? alpha[ch] : 1.f;
+    }
+    float s_sc[4] = {0.f, 0.f, 0.f, 0.f}, s_sh[4] = {0.f, 0.f, 0.f, 0.f}, s_al[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- stage: G_k and x on the band + halo, zero outside the image
+    const size_t in0 = ((size_t)img * 4 * g.n + j) * pl, kin = (size_t)g.n * pl;
+    // (only positions inside the image are loaded: for an 18x30 plane the zero halo is 45 % of the tile)
+    for (int t = tid; t < 5 * tile; t += 256) smem[t] = 0.f;
+    __syncthreads();
+    const int ya = max(y0 - FB_MAXD, 0), yb = min(y1 + FB_MAXD, H);           // image rows staged: [ya, yb)
+    const int nin = (yb - ya) * W;
+    for (int t = tid; t < nin; t += 256) {
+        const int ri = t / W, xx = t - ri * W;
+        const int y = ya + ri;
+        const size_t o = (size_t)y * W + xx;
+        float zv[4], gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { zv[k] = z[in0 + k * kin + o]; gv[k] = gy[in0 + k * kin + o]; }
+        const float xr = xp[o];
+        __builtin_amdgcn_sched_barrier(0);
+        const bool own = y >= y0 && y < y1;
+        float gk[4], run = 0.f;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const float u = zv[k] * sc[k] + sh[k];
+            const bool pos = !act || u > 0.f;
+            const float gz = pos ? gv[k] : al[k] * gv[k];
+            if (own) {
+                if (!pos) s_al[k] += gv[k] * u;
+                s_sc[k] += gz * zv[k];
+                s_sh[k] += gz;
+            }
+            run += gz * sc[k];
+            gk[k] = run;
+        }
+        const int lt = (y - (y0 - FB_MAXD)) * WT + xx + FB_MAXD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) GS[k * tile + lt] = gk[k];
+        XS[lt] = xr;
+    }
+    __syncthreads();
+    // ---- data gradient: the band's pixels
+    float wk[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wk[k][q] = w4[((size_t)k * g.n + j) * 9 + q];
+    const int npx = (y1 - y0) * W;
+    float* op = gx + ((size_t)img * g.n + j) * pl + (size_t)y0 * W;
+    for (int p = tid; p < npx; p += 256) {
+        const int ry = p / W, cx = p - ry * W;
+        const int base = (ry + FB_MAXD) * WT + cx + FB_MAXD;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = g.dil[k];
+            const float* G = GS + k * tile + base;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc = fmaf(wk[k][ky * 3 + kx], G[-((ky - 1) * d * WT + (kx - 1) * d)], acc);
+        }
+        op[p] = acc;
+    }
+    // ---- weight gradients: thread = (tap, pixel group) -- ONE running sum per thread over every 7th pixel of the band, so the
+    // reduction is over 7 partial sums per tap instead of a 36-value shuffle reduction across 256 threads
+    const int tap = tid % 36, pgrp = tid / 36;                  // threads 252..255: no tap
+    float wsum = 0.f;
+    if (pgrp < 7) {
+        const int k = tap / 9, q = tap - k * 9, ky = q / 3, kx = q - ky * 3;
+        const int d = g.dil[k];
+        const int off = (ky - 1) * d * WT + (kx - 1) * d;
+        const float* G = GS + k * tile;
+        int ry = pgrp / W, cx = pgrp - ry * W;
+        for (int p = pgrp; p < npx; p += 7) {
+            const int base = (ry + FB_MAXD) * WT + cx + FB_MAXD;
+            wsum = fmaf(G[base], XS[base + off], wsum);
+            cx += 7;
+            while (cx >= W) { cx -= W; ++ry; }
+        }
+    }
+    // ---- reductions: 12 BatchNorm / PReLU sums by wave shuffles, the 36 x 7 weight-gradient partials through LDS
+    __shared__ float wred[7][36];
+    if (pgrp < 7) wred[pgrp][tap] = wsum;
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k * 3] = s_sc[k];  v[k * 3 + 1] = s_sh[k];  v[k * 3 + 2] = s_al[k]; }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float t = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6][i] = t;
+    }
+    __syncthreads();
+    auto tot = [&](int i) { return (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]); };
+    if (tid < 36) {
+        const int k = tid / 9, q = tid - k * 9;
+        const float t = ((wred[0][tid] + wred[1][tid]) + (wred[2][tid] + wred[3][tid])) + ((wred[4][tid] + wred[5][tid]) + wred[6][tid]);
+        atomicAdd(&gw.p[k][(size_t)j * 9 + q], t);
+    } else if (tid < 40) {
+        const int k = tid - 36, ch = k * g.n + j;
+        const float t_sc = tot(k * 3), t_sh = tot(k * 3 + 1);
+        if (gscale) atomicAdd(&gscale[ch], bn_inv ? (t_sc - bn_mean[ch] * t_sh) * bn_inv[ch] : t_sc);
+        if (gshift) atomicAdd(&gshift[ch], t_sh);
+        if (galpha && act) atomicAdd(&galpha[ch], tot(k * 3 + 2));
+    }
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+static size_t fb_plan(int N, int n, int H, int W, const int32_t* dil, FbGeom& g) {
+    if (N <= 0 || n <= 0 || H <= 0 || W <= 0 || !dil) return 0;
+    for (int k = 0; k < 4; ++k)
+        if (dil[k] < 1 || dil[k] > FB_MAXD) return 0;
+    g.N = N; g.n = n; g.H = H; g.W = W;
+    g.WT = W + 2 * FB_MAXD;
+    for (int k = 0; k < 4; ++k) g.dil[k] = dil[k];
+    // band height: the whole plane when the five haloed tiles fit 48 KB, else the largest band that does (>= 8 rows)
+    int bh = H;
+    while (bh > 8 && (size_t)5 * (bh + 2 * FB_MAXD) * g.WT * sizeof(float) > 48 * 1024) bh = (bh + 1) / 2;
+    g.BH = bh;
+    g.bands = ceil_div(H, bh);
+    const size_t lds = (size_t)5 * (bh + 2 * FB_MAXD) * g.WT * sizeof(float);
+    return lds <= 64 * 1024 ? lds : 0;
+}
+
+extern "C" int mspl_eesp_bwd_fused_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t* dil) {
+    FbGeom g;
+    return fb_plan(N, n, H, W, dil, g) > 0 && (int64_t)N * n * g.bands < (1ll << 31);
+}
+
+extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
+                                   const float* scale, const float* shift, const float* alpha, const float* bn_mean,
+                                   const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
+                                   float* gscale, float* gshift, float* galpha, void* stream) {
+    MSPL_REQUIRE(z && gy && x && w4 && dil && gx && gw, MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: null pointer");
+    MSPL_REQUIRE((bn_mean == nullptr) == (bn_inv == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: mean / inv must come together");
+    FbGeom g;
+    const size_t lds = fb_plan(N, n, H, W, dil, g);
+    MSPL_REQUIRE(lds > 0, MSPL_ERR_UNSUPPORTED, "eesp_bwd_fused: N=%d n=%d %dx%d is not covered (dilations 1..4, row of %d floats in LDS)", N, n,
+                 H, W, W + 2 * FB_MAXD);
+    GwPtrs gp;
+    for (int k = 0; k < 4; ++k) {
+        MSPL_REQUIRE(gw[k], MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: weight gradient %d is null", k);
+        gp.p[k] = gw[k];
+    }
+    const int64_t blocks = (int64_t)N * n * g.bands;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_bwd_fused: grid too large");
+    hipLaunchKernelGGL(eesp_bwd_fused_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, z, gy, x, w4, scale, shift, alpha,
+                       bn_mean, bn_inv, g, gx, gp, gscale, gshift, galpha);
+    MSPL_CHECK_LAUNCH("eesp_bwd_fused");
+    return MSPL_OK;
+}

@@ -287,14 +287,27 @@ def _concurrent_streams(n, device, candidates=12, spin_cycles=400000):
         return (time.perf_counter() - t0) * 1e3
 
     pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
-    spin_ms(pool[:1])                                   # first use of the spin kernel (module load)
-    one = min(spin_ms(pool[:1]) for _ in range(3))
+    # The spin kernel counts CYCLES: on an idle chip the first spins run at a low clock and take longer, and a baseline taken then makes
+    # two serialised spins at the boosted clock look like one (seen as a four-lane train step of 11.8 ms instead of 7.5 ms: all lanes
+    # on one queue).  So: clocks warmed up first, and the final choice VALIDATED against a baseline taken after it; a failed
+    # validation repeats the selection.
+    for _ in range(30):
+        spin_ms(pool[:1])
     chosen = [pool[0]]
-    for st in pool[1:]:
-        if len(chosen) == n:
+    for attempt in range(3):
+        one = min(spin_ms(pool[:1]) for _ in range(3))
+        chosen = [pool[0]]
+        for st in pool[1:]:
+            if len(chosen) == n:
+                break
+            if min(spin_ms(chosen + [st]) for _ in range(2)) < one * (1.0 + 0.5 * len(chosen)):
+                chosen.append(st)
+        if len(chosen) < n:
+            break                                       # fewer hardware queues than lanes: nothing to validate
+        together = min(spin_ms(chosen) for _ in range(3))
+        alone = min(spin_ms(chosen[:1]) for _ in range(3))
+        if together < 1.6 * alone:
             break
-        if min(spin_ms(chosen + [st]) for _ in range(2)) < one * (1.0 + 0.5 * len(chosen)):
-            chosen.append(st)
     while len(chosen) < n:
         chosen.append(torch.cuda.Stream(device=device))
     return chosen
