@@ -479,12 +479,17 @@ int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4, const int
  * backward): br_after_cat's BatchNorm + PReLU backward, the HFF suffix sum, the data gradient and the weight gradients of the four
  * dilated depthwise branches.  z (N,4n,H,W) = K2's raw concatenation, gy = dL/d(PReLU(BN(z))), x (N,n,H,W) = K2's input, w4 (4,n,3,3),
  * dil[4] in 1..4; scale/shift/alpha/bn_mean/bn_inv (4n) as mspl_hff_bn_prelu_suffix_bwd.  gx (N,n,H,W) overwritten; gw[4] (n,3,3),
- * gscale/gshift/galpha (4n) ACCUMULATED.  _fits: 1 when the haloed row band fits LDS. */
+ * gscale/gshift/galpha (4n) ACCUMULATED.  With proj_c (N,n,H,W) = proj_1x1's bare convolution result (x = PReLU(proj_c * proj_scale +
+ * proj_shift)), proj_1x1's BatchNorm + PReLU backward is applied before the store: gx is then dL/d(proj_c) and g_proj_scale /
+ * g_proj_shift / g_proj_alpha (n, ACCUMULATED; d gamma / d beta with proj_mean / proj_inv) its parameter gradients; proj_c NULL:
+ * gx = dL/dx.  _fits: 1 when the haloed row band fits LDS. */
 int mspl_eesp_bwd_fused_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t* dil);
 int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
                         const float* scale, const float* shift, const float* alpha, const float* bn_mean,
                         const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
-                        float* gscale, float* gshift, float* galpha, void* stream);
+                        float* gscale, float* gshift, float* galpha, const float* proj_c, const float* proj_scale,
+                        const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
+                        float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream);
 
 /* out = srcs[0] + ... + srcs[n-1] (1 <= n <= 8 equally shaped fp32 tensors of `count` elements, count % 4 == 0, 16-byte aligned; srcs
  * is a HOST array of device pointers): the gradient of a tensor with several consumers in one launch (autograd.FanOutFn). */

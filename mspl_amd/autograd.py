@@ -403,18 +403,29 @@ class EESPFn(torch.autograd.Function):
         dst = [wsinks[k] if wsinks[k] is not None else tmp[k] for k in range(4)]
         ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dst])
         dil_c = (ctypes.c_int32 * 4)(*dil)
+        r_gp = r_bp = r_ap = None
         if stride == 1 and _FUSED_EESP_BWD and lib.mspl_eesp_bwd_fused_fits(N, n, H, W, dil_c):
-            # one launch: BatchNorm/PReLU backward + suffix sum + both gradients of the four branches (no suffix-summed tensor in memory)
+            # one launch: BatchNorm/PReLU backward + suffix sum + both gradients of the four branches (no suffix-summed tensor in
+            # memory) + proj_1x1's BatchNorm/PReLU backward on the way out: what is written is dL/d(projection's convolution result)
+            s_gp, s_bp, s_ap = sk['p']
+            pacc = torch.zeros(3, n, device=dev) if (s_gp is None or s_bp is None or s_ap is None) else None
+            d_gp = s_gp if s_gp is not None else pacc[0]
+            d_bp = s_bp if s_bp is not None else pacc[1]
+            d_ap = s_ap if s_ap is not None else pacc[2]
+            gc1 = go1
             check(lib.mspl_eesp_bwd_fused(_p(z2), _p(gy2), _p(o1), _p(w4), dil_c, _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, H, W,
-                                          _p(go1), ptrs, _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
+                                          _p(gc1), ptrs, _p(d_g2), _p(d_b2), _p(d_a2), _p(c1), _p(sp), _p(hp), _p(ap), _p(mp), _p(ip),
+                                          _p(d_gp), _p(d_bp), _p(d_ap), _stream()))
+            r_gp, r_bp, r_ap = (None if s_gp is not None else d_gp), (None if s_bp is not None else d_bp), (None if s_ap is not None else d_ap)
         else:
             gs = torch.empty((4, N, n, Ho, Wo), device=dev, dtype=torch.float32)
             check(lib.mspl_hff_bn_prelu_suffix_bwd(_p(z2), _p(gy2), _p(sb), _p(hb), _p(a2), _p(mb), _p(ib), N, n, Ho * Wo, _p(gs),
                                                    _p(d_g2), _p(d_b2), _p(d_a2), _stream()))
             # the four depthwise branches
             check(lib.mspl_eesp_dw_bwd(_p(gs), _p(o1), _p(w4), dil_c, stride, N, n, H, W, _p(go1), ptrs, _stream()))
-        # proj_1x1's BatchNorm + PReLU and the convolution; the residual link's gradient rides on the data gradient's epilogue
-        gc1, _, r_gp, r_bp, r_ap = _affine_backward(c1, sp, hp, ap, None, None, mp, ip, True, sk['p'], go1)
+            # proj_1x1's BatchNorm + PReLU
+            gc1, _, r_gp, r_bp, r_ap = _affine_backward(c1, sp, hp, ap, None, None, mp, ip, True, sk['p'], go1)
+        # proj_1x1's convolution; the residual link's gradient rides on the data gradient's epilogue
         gx = gwp = None
         if ctx.needs_input_grad[0]:
             wt = _transposed_weights(wp, groups, 1)

@@ -175,15 +175,23 @@ struct FbGeom {
     int dil[4];
 };
 
+// Optional tail: proj_1x1's BatchNorm + PReLU backward applied to the data gradient before it is written (c = the projection's bare
+// convolution result): gx then IS dL/dc, and the three per-channel sums of channel j are this workgroup's own.
+struct FbProj {
+    const float* c;                                  // (N, n, H, W) or null: plain data gradient
+    const float *scale, *shift, *alpha, *mean, *inv; // n each (alpha / mean / inv nullable)
+    float *gscale, *gshift, *galpha;                 // n each, accumulated
+};
+
 __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __restrict__ z, const float* __restrict__ gy,
                                                              const float* __restrict__ x, const float* __restrict__ w4,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ alpha, const float* __restrict__ bn_mean,
                                                              const float* __restrict__ bn_inv, FbGeom g, float* __restrict__ gx,
                                                              GwPtrs gw, float* __restrict__ gscale, float* __restrict__ gshift,
-                                                             float* __restrict__ galpha) {
+                                                             float* __restrict__ galpha, FbProj pj) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float red[4][12];
+    __shared__ float red[4][15];
     int b = blockIdx.x;
     const int band = b % g.bands;  b /= g.bands;
     const int j = b % g.n;
@@ -250,6 +258,11 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
         for (int q = 0; q < 9; ++q) wk[k][q] = w4[((size_t)k * g.n + j) * 9 + q];
     const int npx = (y1 - y0) * W;
     float* op = gx + ((size_t)img * g.n + j) * pl + (size_t)y0 * W;
+    const float* cp = pj.c ? pj.c + ((size_t)img * g.n + j) * pl + (size_t)y0 * W : nullptr;
+    const float psc = (cp && pj.scale) ? pj.scale[j] : 1.f, psh = (cp && pj.shift) ? pj.shift[j] : 0.f;
+    const bool pact = cp && pj.alpha;
+    const float pal = pact ? pj.alpha[j] : 1.f;
+    float t_sc = 0.f, t_sh = 0.f, t_al = 0.f;
     for (int p = tid; p < npx; p += 256) {
         const int ry = p / W, cx = p - ry * W;
         const int base = (ry + FB_MAXD) * WT + cx + FB_MAXD;
@@ -262,6 +275,16 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) acc = fmaf(wk[k][ky * 3 + kx], G[-((ky - 1) * d * WT + (kx - 1) * d)], acc);
+        }
+        if (cp) {
+            const float cv = cp[p];
+            const float u = cv * psc + psh;
+            const bool pos = !pact || u > 0.f;
+            const float gz = pos ? acc : pal * acc;
+            if (!pos) t_al += acc * u;
+            t_sc += gz * cv;
+            t_sh += gz;
+            acc = gz * psc;
         }
         op[p] = acc;
     }
@@ -285,11 +308,12 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
     // ---- reductions: 12 BatchNorm / PReLU sums by wave shuffles, the 36 x 7 weight-gradient partials through LDS
     __shared__ float wred[7][36];
     if (pgrp < 7) wred[pgrp][tap] = wsum;
-    float v[12];
+    float v[15];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { v[k * 3] = s_sc[k];  v[k * 3 + 1] = s_sh[k];  v[k * 3 + 2] = s_al[k]; }
+    v[12] = t_sc;  v[13] = t_sh;  v[14] = t_al;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 15; ++i) {
         float t = v[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
@@ -307,6 +331,11 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
         if (gscale) atomicAdd(&gscale[ch], bn_inv ? (t_sc - bn_mean[ch] * t_sh) * bn_inv[ch] : t_sc);
         if (gshift) atomicAdd(&gshift[ch], t_sh);
         if (galpha && act) atomicAdd(&galpha[ch], tot(k * 3 + 2));
+    } else if (tid == 40 && pj.c) {
+        const float a_sc = tot(12), a_sh = tot(13);
+        if (pj.gscale) atomicAdd(&pj.gscale[j], pj.inv ? (a_sc - pj.mean[j] * a_sh) * pj.inv[j] : a_sc);
+        if (pj.gshift) atomicAdd(&pj.gshift[j], a_sh);
+        if (pj.galpha && pact) atomicAdd(&pj.galpha[j], tot(14));
     }
 }
 
@@ -338,8 +367,11 @@ extern "C" int mspl_eesp_bwd_fused_fits(int32_t N, int32_t n, int32_t H, int32_t
 extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
                                    const float* scale, const float* shift, const float* alpha, const float* bn_mean,
                                    const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
-                                   float* gscale, float* gshift, float* galpha, void* stream) {
+                                   float* gscale, float* gshift, float* galpha, const float* proj_c, const float* proj_scale,
+                                   const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
+                                   float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream) {
     MSPL_REQUIRE(z && gy && x && w4 && dil && gx && gw, MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: null pointer");
+    MSPL_REQUIRE((proj_mean == nullptr) == (proj_inv == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: proj mean / inv must come together");
     MSPL_REQUIRE((bn_mean == nullptr) == (bn_inv == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: mean / inv must come together");
     FbGeom g;
     const size_t lds = fb_plan(N, n, H, W, dil, g);
@@ -352,8 +384,11 @@ extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float*
     }
     const int64_t blocks = (int64_t)N * n * g.bands;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_bwd_fused: grid too large");
+    FbProj pj;
+    pj.c = proj_c; pj.scale = proj_scale; pj.shift = proj_shift; pj.alpha = proj_alpha; pj.mean = proj_mean; pj.inv = proj_inv;
+    pj.gscale = g_proj_scale; pj.gshift = g_proj_shift; pj.galpha = g_proj_alpha;
     hipLaunchKernelGGL(eesp_bwd_fused_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, z, gy, x, w4, scale, shift, alpha,
-                       bn_mean, bn_inv, g, gx, gp, gscale, gshift, galpha);
+                       bn_mean, bn_inv, g, gx, gp, gscale, gshift, galpha, pj);
     MSPL_CHECK_LAUNCH("eesp_bwd_fused");
     return MSPL_OK;
 }
