@@ -258,7 +258,8 @@ def three_source_rate(dev, iters=20):
     return out
 
 
-TRAIN_BYTES_PER_IMAGE = 3 * 306.9e6      # forward + data-gradient + weight-gradient passes over SURVEY 8(d)'s 306.9 MB/image (C=5, 256x480)
+TRAIN_BYTES_PER_IMAGE = 820.5e6          # DESIGN.md section 7 / tools/train_bytes.py: forward (305.7 MB, = SURVEY 8(d)'s 306.9) + data-gradient + weight-gradient
+                                         # passes per image in SURVEY 8(d)'s accounting (weighted layers 3x their forward bytes, weightless ones 2x), C=5, 256x480
 
 
 def train_step_build(dev, rank=0):
@@ -320,8 +321,8 @@ def train_step_time(step, x, y, dev, iters=10, world=1, repeats=3):
             'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay (%d concurrent micro-batch graphs) + ' % step.lanes +
                         ('one flat-bucket gradient all-reduce (%d floats, RCCL) + ' % step.optimizer.flat_g.numel() if world > 1 else '') +
                         'Adam kernel',
-            # forward + backward against the HBM roof: algorithmic bytes = 3 x the forward's (each layer's input and output are moved
-            # once by the forward, once by the data gradient, once by the weight gradient; BN / PReLU / add / cat fused = 0), DESIGN 7
+            # forward + backward against the HBM roof: every weighted layer's input and output are moved once by the forward, once by the
+            # data gradient, once by the weight gradient (weightless layers twice; BN / PReLU / add / cat fused = 0): tools/train_bytes.py
             'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_image': TRAIN_BYTES_PER_IMAGE, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4)},
             'weights_identical_across_ranks': in_sync, 'loss_finite': bool(torch.isfinite(loss))}
@@ -659,12 +660,30 @@ def main():
         'recorded %d K2 launches / %d bytes, the model walk gives %d / %d' % (k2_launches, k2_bytes, model_launches, model_bytes))
 
     # ---- the same launches timed IN the pass: one eager label pass, the stream parked behind a spin kernel (so the host's launch
-    # cadence is out of the picture), a HIP event pair around every K2 launch; the cost of an empty event pair, measured the same
-    # way, is subtracted.  This is the number rocprofv3's in-pass average must agree with (profiles/r03_*_inflight1.csv): inputs
-    # come from the producer kernel through L2 / Infinity Cache / HBM as in the real pass, not from 20 warm re-issues.
-    def k2_in_pass(mult, passes=3):
+    # cadence is out of the picture), a HIP event pair around every K2 launch.  An event pair adds its own time to what it brackets;
+    # that overhead is calibrated PER SHAPE on the isolated kernel: (event pair around ONE warm launch) - (back-to-back time per
+    # launch of the same kernel, measured above), and subtracted.  This is the number rocprofv3's in-pass average must agree with
+    # (profiles/r03_kernel_stats_inflight1.csv): inputs come from the producer kernel through L2 / Infinity Cache / HBM as in the
+    # real pass, not from 20 warm re-issues.
+    def pair_overhead():
+        ovh = []
+        for (a_, kw), b2b in zip(calls, k2_ms):
+            ts = []
+            for _ in range(5):
+                real(*a_, **kw)
+                torch.cuda._sleep(2_000_000)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                real(*a_, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ovh.append(max(0.0, sorted(ts)[len(ts) // 2] - b2b))
+        return ovh
+
+    def k2_in_pass(mult, ovh, passes=3):
         xin = x if mult == 1 else torch.cat([x] * mult, 0)
-        per_pass, calib = [], []
+        per_pass = []
         rec = []
 
         def timed_k2(*a_, **kw):
@@ -682,26 +701,25 @@ def main():
                 for _ in range(passes):
                     del rec[:]
                     torch.cuda._sleep(40_000_000)
-                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    c0.record()
-                    c1.record()
                     eager(xin)
                     torch.cuda.synchronize()
-                    calib.append(c0.elapsed_time(c1))
                     per_pass.append([e0.elapsed_time(e1) for e0, e1 in rec])
         finally:
             L.ops.eesp_dw_hff = real
-        ovh = sorted(calib)[len(calib) // 2]
         n = len(per_pass[0])
-        med = [sorted(pp[i] for pp in per_pass)[len(per_pass) // 2] - ovh for i in range(n)]
-        return med, ovh
+        return [sorted(pp[i] for pp in per_pass)[len(per_pass) // 2] - ovh[i] for i in range(n)]
     in_pass = {}
     if rank == 0:
-        for mult in (1, group) if group > 1 else (1,):
+        try:
+            ovh = pair_overhead()
+        except Exception as e_:      # noqa: BLE001
+            ovh = None
+            in_pass[1] = {'error': repr(e_)[:200]}
+        for mult in ((1, group) if group > 1 else (1,)) if ovh is not None else ():
             try:
-                med, ovh = k2_in_pass(mult)
+                med = k2_in_pass(mult, ovh)
                 avg_s = sum(med) / len(med) * 1e-3
-                in_pass[mult] = {'avg_launch_us': round(avg_s * 1e6, 3), 'event_pair_overhead_us': round(ovh * 1e3, 3),
+                in_pass[mult] = {'avg_launch_us': round(avg_s * 1e6, 3), 'event_pair_overhead_us': round(sum(ovh) / len(ovh) * 1e3, 3),
                                  'achieved': round(mult * k2_bytes_of(calls) / len(med) / avg_s / 1e9, 1),
                                  'per_launch_us': [round(v * 1e3, 2) for v in med]}
             except Exception as e_:      # noqa: BLE001
@@ -739,16 +757,30 @@ def main():
             if os.path.exists(os.path.join(ROOT, 'profiles', n)):
                 return n
         return None
-    tname = newest(['r02_k2_hbm_traffic.json', 'r01_k2_hbm_traffic.json'])
+    tname = newest(['r03_k2_hbm_traffic.json', 'r02_k2_hbm_traffic.json', 'r01_k2_hbm_traffic.json'])
     if tname:
         k2_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', tname)))['avg_traffic_bytes_per_launch'])
         k2_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % tname
     # measured HBM bytes of one whole pass (every kernel; tools/pass_traffic.py, same PMC recipe)
     path_traffic, path_traffic_src = None, None
-    pname = newest(['r02_pass_hbm_traffic.json', 'r01_m_pass_hbm_traffic.json'])
+    pname = newest(['r03_pass_hbm_traffic.json', 'r02_pass_hbm_traffic.json', 'r01_m_pass_hbm_traffic.json'])
     if pname:
         path_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', pname)))['total_MB_per_image'] * 1e6)
         path_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)' % pname
+    # the same kernels' average duration in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --profile-pass
+    # --in-flight 1` (label passes only): the figure the live in-pass measurement has to agree with
+    k2_rocprof_us, k2_rocprof_src = None, None
+    cname = newest(['r03_kernel_stats_inflight1.csv', 'r02_b_kernel_stats_inflight1.csv'])
+    if cname:
+        import csv
+        tot_ns, tot_calls = 0.0, 0
+        for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', cname))):
+            if 'eesp_dw_hff_kernel' in row['Name'] or 'eesp_dw_direct_kernel' in row['Name']:
+                tot_ns += float(row['TotalDurationNs'])
+                tot_calls += int(row['Calls'])
+        if tot_calls:
+            k2_rocprof_us = round(tot_ns / tot_calls / 1e3, 3)
+            k2_rocprof_src = 'profiles/%s (%d K2 launches)' % (cname, tot_calls)
     avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
     achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
 
@@ -786,10 +818,12 @@ def main():
                          'traffic_source': k2_traffic_src,
                          'algorithmic_bytes_per_launch': int(k2_bytes / k2_launches), 'accounting_note': k2_note,
                          'avg_launch_us': ip1.get('avg_launch_us', round(avg_launch_s * 1e6, 3)),
-                         'timing': ('HIP event pair around each K2 launch of one eager pass at batch 16 (stream parked behind a spin kernel, '
-                                    'empty-pair overhead subtracted, median of 3 passes)' if 'achieved' in ip1 else
+                         'timing': ('HIP event pair around each K2 launch of one eager pass at batch 16 (stream parked behind a spin kernel; the '
+                                    'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 3 passes); '
+                                    'rocprofv3 in the same pass: rocprof_avg_launch_us' if 'achieved' in ip1 else
                                     'isolated re-issues (in-pass measurement failed: %s)' % ip1.get('error')),
-                         'event_pair_overhead_us': ip1.get('event_pair_overhead_us'), 'per_launch_us': ip1.get('per_launch_us')},
+                         'event_pair_overhead_us': ip1.get('event_pair_overhead_us'), 'per_launch_us': ip1.get('per_launch_us'),
+                         'rocprof_avg_launch_us': k2_rocprof_us, 'rocprof_source': k2_rocprof_src},
             'roofline_isolated': {'kernel': 'same 13 launches, each re-issued 20x back to back on warm tensors (best of 3)',
                                   'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                   'frac': round(achieved / HBM_PEAK_GBS, 4), 'avg_launch_us': round(avg_launch_s * 1e6, 3)},
@@ -811,7 +845,7 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        pk = os.path.join(ROOT, 'profiles', 'r02_per_kernel.json')
+        pk = os.path.join(ROOT, 'profiles', newest(['r03_per_kernel.json', 'r02_per_kernel.json']) or 'none')
         if os.path.exists(pk):
             # per-kernel table of one label pass (us, MB, fraction of the HBM roof), from a rocprofv3 --kernel-trace --stats run of
             # `bench.py --profile-pass --in-flight 1` (no K2 re-issues in it) + the PMC traffic passes; tools/per_kernel.py

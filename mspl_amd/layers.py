@@ -499,9 +499,11 @@ class DownSampler(nn.Module):
             return scale.contiguous(), shift.contiguous(), rw
         return cached(self, 'epi%d' % int(with_reinf), deps, build)
 
-    def _forward_train(self, input, input2):
+    def _forward_train(self, input, input2, alias=None):
+        # (alias: a second autograd alias of `input` from the caller's fan_out, so that the gradients of all consumers of the
+        # tensor are summed by ONE launch instead of pairwise ATen adds)
         avg_out = ag.avgpool(input)
-        eesp_out = self.eesp(input)
+        eesp_out = self.eesp(input if alias is None else alias)
         out = torch.cat([avg_out, eesp_out], 1)           # data movement only
         reinf = None
         if input2 is not None:
@@ -514,9 +516,9 @@ class DownSampler(nn.Module):
             reinf = self.inp_reinf(img)
         return ag.affine_prelu(out, None, None, self.act.weight, residual=reinf)
 
-    def forward(self, input, input2=None):
+    def forward(self, input, input2=None, _alias=None):
         if _training_path():
-            return self._forward_train(input, input2)
+            return self._forward_train(input, input2, _alias)
         N, _, H, W = input.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         out = torch.empty((N, self.nout, Ho, Wo), device=input.device, dtype=torch.float32)
@@ -726,10 +728,10 @@ class EfficientPWConv(nn.Module):
         self.out_size = nout
         self.in_size = nin
 
-    def forward(self, x):
+    def forward(self, x, _alias=None):
         if _training_path():
             gate = ag.gap_gate(x, self.wt_layer[1].weight)
-            return ag.channel_scale(self.expansion_layer(x), gate)
+            return ag.channel_scale(self.expansion_layer(x if _alias is None else _alias), gate)
         sums = _recall_plane_sums(x)
         if sums is not None:
             gate = ops.gate_from_sums(sums, self.wt_layer[1].weight, x.shape[2] * x.shape[3])

@@ -148,6 +148,20 @@ class _SegBase(nn.Module):
         elif pyr is None:
             pyr = ImagePyramid(x.detach())
         l1 = b.level1(x)
+        if _training_path():
+            # every encoder output has four consumers (the next DownSampler's pool and EESP, the skip connection's gate and 3x3):
+            # four aliases whose gradients ONE launch sums (autograd.fan_out) instead of three pairwise ATen adds per level
+            a1 = ag.fan_out(l1, 4)
+            l2 = b.level2_0(a1[0], pyr if image_for_l2 else None, _alias=a1[1])
+            a2 = ag.fan_out(l2, 4)
+            l3 = b.level3_0(a2[0], pyr, _alias=a2[1])
+            for i, layer in enumerate(b.level3):
+                l3 = (layer if i == 0 else l3_tail[i])(l3)
+            a3 = ag.fan_out(l3, 4)
+            l4 = b.level4_0(a3[0], pyr, _alias=a3[1])
+            for layer in b.level4:
+                l4 = layer(l4)
+            return a1[2:], a2[2:], a3[2:], l4
         l2 = b.level2_0(l1, pyr if image_for_l2 else None)
         l3 = b.level3_0(l2, pyr)
         for i, layer in enumerate(b.level3):
@@ -194,7 +208,14 @@ class _SegBase(nn.Module):
         aux = None
         # the three skip connections depend on the encoder only, the auxiliary head on one decoder stage only: both
         # are issued on side streams (layers.fork / join) and overlap the main decoder chain
-        with fork(1, (l1, l2, l3)) as f:
+        if isinstance(l1, tuple):                                # training path: (gate alias, 3x3 alias) pairs from _encode's fan_out
+            pw2 = self.merge_enc_dec_l2(l3[0], _alias=l3[1])
+            pw3 = self.merge_enc_dec_l3(l2[0], _alias=l2[1])
+            pw4 = self.merge_enc_dec_l4(l1[0], _alias=l1[1])
+            e2 = e3 = e4 = None
+            l1, l2, l3 = l1[0], l2[0], l3[0]
+        else:
+          with fork(1, (l1, l2, l3)) as f:
             pw2 = self.merge_enc_dec_l2(l3);  e2 = f.mark()      # each skip connection is awaited on its own event:
             pw3 = self.merge_enc_dec_l3(l2);  e3 = f.mark()      # stage k of the decoder starts when pw_k is ready, not
             pw4 = self.merge_enc_dec_l4(l1);  e4 = f.mark()      # when the whole side stream has drained
