@@ -770,6 +770,94 @@ __global__ __launch_bounds__(256) void conv1x1_valu_kernel(const float* __restri
     }
 }
 
+// Thin projections on large maps (the decoder's 32 -> 16 and 16 -> 13 at 144x240): at most 16 output channels per group and a
+// short K.  The 32-row MFMA tile is half empty there and its staging dominates (57 us for 106 MB); on the vector unit the whole
+// job is 0.6 GFLOP -- nothing -- so the kernel is a pure stream: one float4 of pixels per lane and input channel, the weight
+// column w[0..15][k] broadcast from LDS as four 16-byte reads, 64 FMAs.  UNR input planes are requested ahead of their use.
+template <int MT, int UNR>
+__global__ __launch_bounds__(256) void conv1x1_thin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           PwSmall g, Epi e, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [G][K][MT], rows past M zero
+    const int nw = g.G * g.K * MT;
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const int m = i % MT, k = (i / MT) % g.K, grp = i / (MT * g.K);
+        wl[i] = m < g.M ? w[((size_t)grp * g.M + m) * g.K + k] : 0.f;
+    }
+    __syncthreads();
+    int slab = blockIdx.z * gridDim.y + blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (slab >= g.N * g.G || q >= g.Q) return;
+    const int grp = slab % g.G;
+    const int img = slab / g.G;
+    const int p0 = q * 4;
+    const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.K) * (size_t)g.HW + p0;
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+    const float* wk = wl + (size_t)grp * g.K * MT;
+    for (int k0 = 0; k0 < g.K; k0 += UNR) {                       // K % UNR == 0 (launcher)
+        float4 xv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) xv[u] = *reinterpret_cast<const float4*>(xg + (size_t)(k0 + u) * g.HW);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int m4 = 0; m4 < MT; m4 += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(wk + (k0 + u) * MT + m4);
+                const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    acc[m4 + mm][0] = fmaf(ww[mm], xv[u].x, acc[m4 + mm][0]);
+                    acc[m4 + mm][1] = fmaf(ww[mm], xv[u].y, acc[m4 + mm][1]);
+                    acc[m4 + mm][2] = fmaf(ww[mm], xv[u].z, acc[m4 + mm][2]);
+                    acc[m4 + mm][3] = fmaf(ww[mm], xv[u].w, acc[m4 + mm][3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < g.M) {                                            // uniform; no `break`, so the loop unrolls and acc stays in registers
+            const int cabs = e.coff + grp * g.M + m;
+            const EpiCh ec = epi_channel(e, cabs);
+            if (e.raw) store_out4(e.raw + epi_offset(e, img, cabs, p0), make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
+            store_out4(out + epi_offset(e, img, cabs, p0), epi_apply4(e, ec, acc[m], img, cabs, p0));
+        }
+    }
+}
+
+// 0 = launched.  Shapes: M <= 16 per group, K in 8..64 (multiple of 8), planes a multiple of 4 pixels, >= 400 workgroups.
+static int launch_thin_try(const float* x, const float* w, int N, int Cin, int Cout, int groups, int HW, const Epi& e, float* out,
+                           hipStream_t s) {
+    static const int enabled = getenv("MSPL_PW_THIN") ? atoi(getenv("MSPL_PW_THIN")) : 1;
+    const int K = Cin / groups, M = Cout / groups;
+    // measured (tools/bench_ops.py, bs 16): 32 -> 16 at 144x240 26.1 -> 23.0 us, 16 -> 13 18.3 -> 15.6, 128 -> 32 g4 at 72x120
+    // 23.9 -> 18.9; with fewer than ~2 workgroups per CU (48 -> 16 at 72x120: 144) the MFMA kernel's finer tiles win (13 vs 20 us)
+    if (!enabled || M > 16 || K < 8 || K > 64 || (K & 7) != 0 || (HW & 3) != 0 ||
+        (int64_t)N * groups * ceil_div(HW / 4, 256) < 400)
+        return 1;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)e.raw & 15) || ((uintptr_t)e.pre_add & 15) ||
+        ((uintptr_t)e.residual & 15) || ((uintptr_t)e.reinf_r & 15) || ((uintptr_t)e.gate & 15))
+        return 1;
+    PwSmall g;
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.K = K; g.M = M; g.HW = HW;
+    g.Q = HW / 4;
+    g.mtiles = 1;
+    const int mt = M <= 8 ? 8 : 16;
+    const size_t lds = (size_t)groups * K * mt * sizeof(float);
+    if (lds > 48 * 1024) return 1;
+    const int64_t slabs = (int64_t)N * groups;
+    if (slabs >= 65535ll * 65535ll) return 1;
+    const int gy = slabs < 65535 ? (int)slabs : 65535;
+    dim3 grid((unsigned)ceil_div(g.Q, 256), (unsigned)gy, (unsigned)ceil_div64(slabs, gy)), blk(256);
+    if (mt == 8) hipLaunchKernelGGL((conv1x1_thin_kernel<8, 8>), grid, blk, lds, s, x, w, g, e, out);
+    else hipLaunchKernelGGL((conv1x1_thin_kernel<16, 8>), grid, blk, lds, s, x, w, g, e, out);
+    return 0;
+}
+
 // Launch of the tile-pipelined kernel (K % 32 == 0 or K in {16, 24}, aligned weights, small feature maps).
 static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, const mspl_epilogue_t* ep, float* out,
                        hipStream_t s) {
@@ -938,6 +1026,10 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     PwGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.G = groups; g.K = Cin / groups; g.M = Cout / groups; g.HW = HW;
+    if (launch_thin_try(x, w, N, Cin, Cout, groups, HW, e, out, s) == 0) {
+        MSPL_CHECK_LAUNCH("conv1x1(thin)");
+        return MSPL_OK;
+    }
     if ((g.K < 16 || (g.K & 1)) && (size_t)Cout * g.K * 4 <= 48 * 1024) return launch_small(x, w, N, Cin, Cout, groups, HW, e, out, s);
     MSPL_REQUIRE((g.K & 1) == 0, MSPL_ERR_UNSUPPORTED, "conv1x1: odd K=%d per group with %d output channels is not supported", g.K, Cout);
 

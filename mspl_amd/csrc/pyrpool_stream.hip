@@ -188,22 +188,32 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         xin[j] = cx >= 0 && cx < w;
         xoff[j] = (unsigned)min(max(cx, 0), w - 1) * 4u;
     }
-    auto load_row = [&](int r, float (&v)[PXL + 4]) {
-        const bool rin = r >= 0 && r < h;                                                   // uniform
+    // Rows / columns outside the image: the address is clamped (always a valid read) and the value is multiplied by 0 when it
+    // ENTERS THE WINDOW, one iteration after it was requested.  (Rounds 1-2 selected `inside ? value : 0` next to the load: hipcc
+    // put the loads behind branches on the uniform row test and waited for each pair on the spot -- three exposed L2 round trips
+    // per row and wave.)
+    float xm[PXL + 4];
+#pragma unroll
+    for (int j = 0; j < PXL + 4; ++j) xm[j] = xin[j] ? 1.f : 0.f;
+    auto load_row_raw = [&](int r, float (&v)[PXL + 4]) {
         const char* row = reinterpret_cast<const char*>(xpl + (size_t)min(max(r, 0), h - 1) * w);
 #pragma unroll
-        for (int j = 0; j < PXL + 4; ++j) {
-            const float t = *reinterpret_cast<const float*>(row + xoff[j]);
-            v[j] = (rin && xin[j]) ? t : 0.f;
-        }
+        for (int j = 0; j < PXL + 4; ++j) v[j] = *reinterpret_cast<const float*>(row + xoff[j]);
+    };
+    auto mask_row = [&](int r, const float (&raw)[PXL + 4], float (&v)[PXL + 4]) {
+        const float rm = (r >= 0 && r < h) ? 1.f : 0.f;                                     // uniform
+#pragma unroll
+        for (int j = 0; j < PXL + 4; ++j) v[j] = raw[j] * (rm * xm[j]);
     };
 
     float xw[5][PXL + 4];
-    // rows br-2 .. br+2 for the first branch row br = ys - 1: rows ys-3 .. ys+1; row ys+2 is prefetched as "next"
+    // rows br-2 .. br+2 for the first branch row br = ys - 1: rows ys-3 .. ys+1
 #pragma unroll
-    for (int rr = 0; rr < 5; ++rr) load_row(ys - 3 + rr, xw[rr]);
-    float xn[PXL + 4];
-    load_row(ys + 2, xn);
+    for (int rr = 0; rr < 5; ++rr) {
+        float t[PXL + 4];
+        load_row_raw(ys - 3 + rr, t);
+        mask_row(ys - 3 + rr, t, xw[rr]);
+    }
     // low-resolution values of the NEXT branch row, requested one row ahead: [map][column][ya/xa, ya/xb, yb/xa, yb/xb]
     float en[2][PXL][4];
     float enwy0[2], enwy1[2];
@@ -247,6 +257,9 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                 for (int q = 0; q < 4; ++q) ecur[i][j][q] = en[i][j][q];
         }
         if (br < ye) load_e(br + 1);                       // next row's low-resolution values fly during this row's arithmetic
+        float xn[PXL + 4];
+        load_row_raw(br + 3, xn);                          // the row that enters the window at the end of this iteration
+        __builtin_amdgcn_sched_barrier(0);
         if (rowin) {
             const float* A0 = &At[0][(br - (ys - 1)) * 24];
             const float* A1 = &At[1][(br - (ys - 1)) * 24];
@@ -314,14 +327,12 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
                 }
             }
         }
-        // ---- slide the x window (row br+3 becomes the prefetched one)
+        // ---- slide the x window (row br+3, requested at the top of this iteration, enters it)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int j = 0; j < PXL + 4; ++j) xw[rr][j] = xw[rr + 1][j];
-#pragma unroll
-        for (int j = 0; j < PXL + 4; ++j) xw[4][j] = xn[j];
-        if (br + 1 <= ye) load_row(br + 4, xn);           // for branch row br+2 (its window ends at br+4)
+        mask_row(br + 3, xn, xw[4]);
         // ---- output row y = br - 1 is complete
         const int y = br - 1;
         if (y >= ys) {

@@ -100,7 +100,9 @@ def test_eesp_dw_unsupported_dilation_raises():
     # many pixel tiles: several tiles per wave (the ring runs across tiles), 48 rows in a 64-row weight tile, odd pixel count
     (1, 32, 16, 1, 288, 720), (1, 64, 96, 2, 160, 320), (3, 24, 8, 1, 191, 201),
     # few output channels per group on small maps: the split-K form (EESP reduce projections at levels 3 / 4, pyramid projections)
-    (2, 512, 128, 4, 18, 30), (3, 256, 64, 4, 36, 60), (2, 128, 20, 1, 7, 11)])
+    (2, 512, 128, 4, 18, 30), (3, 256, 64, 4, 36, 60), (2, 128, 20, 1, 7, 11),
+    # thin projections on large maps: the streaming vector-unit form (<= 16 output channels per group, >= 400 workgroups)
+    (12, 32, 16, 1, 144, 240), (8, 32, 24, 4, 144, 240), (12, 16, 13, 1, 144, 240)])
 def test_conv1x1_epilogues(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
