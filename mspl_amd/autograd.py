@@ -67,6 +67,10 @@ class collect_conv_weights(object):
         _WT_COLLECT[0] = self.prev
 
 
+def _align4(n):
+    return (n + 3) & ~3
+
+
 class WeightTransposer(object):
     def __init__(self, collected):
         import numpy as np
@@ -78,7 +82,9 @@ class WeightTransposer(object):
             items.append((w, groups, k))
         self.items = items
         dev = items[0][0].device if items else torch.device('cuda')
-        self.flat = torch.empty(max(sum(w.numel() for w, _, _ in items), 1), device=dev, dtype=torch.float32)
+        # every copy starts at a multiple of 4 floats: the 1x1 kernels read weights as 16-byte vectors (an unaligned weight
+        # tensor drops the data-gradient convolution to the slower generic kernel)
+        self.flat = torch.empty(max(sum(_align4(w.numel()) for w, _, _ in items), 1), device=dev, dtype=torch.float32)
         raw = np.zeros((max(len(items), 1), 10), dtype=np.int32)        # struct WtSeg (train.hip): 2 pointers + 6 int32 = 40 bytes
         blocks, self.lookup, off = [], {}, 0
         for i, (w, groups, k) in enumerate(items):
@@ -89,7 +95,7 @@ class WeightTransposer(object):
             raw[i, 4:10] = (groups, cin_g, cout_g, k, w.numel(), 0)
             self.lookup[w.data_ptr()] = (dst.view(groups * cin_g, cout_g, k, k), groups, k, tuple(w.shape))
             blocks.extend((i, b) for b in range(0, w.numel(), 256))
-            off += w.numel()
+            off += _align4(w.numel())
         self.seg = torch.from_numpy(raw).to(dev)
         self.blk = torch.tensor(blocks if blocks else [(0, 0)], dtype=torch.int32).to(dev)
         self.nblocks = len(blocks)

@@ -96,9 +96,13 @@ class GradBucket:
         if not self.params:
             raise RuntimeError('GradBucket: no parameter has a gradient yet (run one backward first)')
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        # Every parameter starts at a multiple of ALIGN floats (16 bytes): the HIP kernels read weights as 16-byte vectors and
+        # fall back to slower forms for unaligned tensors (a 13-element PReLU slope in front of a convolution weight would
+        # misalign everything behind it).  The padding elements are zero in both buffers and stay zero under SGD / Adam.
+        n = sum(self._padded(p.numel()) for p in self.params)
+        self.numel_params = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev) if with_params else None
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev) if with_params else None
         self.offsets = []
         off = 0
         with torch.no_grad():
@@ -112,7 +116,21 @@ class GradBucket:
                     pv.copy_(p.data)
                     p.data = pv
                 self.offsets.append(off)
-                off += k
+                off += self._padded(k)
+
+    ALIGN = 4
+
+    @classmethod
+    def _padded(cls, k):
+        return (k + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
+    def span(self, first, count):
+        """[lo, hi) of the flat buffers covering parameters first .. first+count-1 (with their padding)."""
+        if count <= 0:
+            lo = self.offsets[first] if first < len(self.offsets) else self.flat.numel()
+            return lo, lo
+        last = first + count - 1
+        return self.offsets[first], self.offsets[last] + self._padded(self.params[last].numel())
 
     def numel(self):
         return self.flat.numel()

@@ -49,11 +49,10 @@ class FlatSGD:
         self.bucket = mdist.GradBucket(flat, with_params=True)            # the flat layout shared with FlatAdam and the all-reduce
         self.flat_p, self.flat_g = self.bucket.flat_p, self.bucket.flat
         self.buf = torch.zeros_like(self.flat_p)
-        off = 0
+        first = 0
         for g in self.param_groups:
-            g['_lo'] = off
-            off += sum(p.numel() for p in g['params'])
-            g['_hi'] = off
+            g['_lo'], g['_hi'] = self.bucket.span(first, len(g['params']))
+            first += len(g['params'])
         self.params = flat
         self.step_count = 0
 

@@ -43,7 +43,10 @@ def _check_flat_optimizers(rank, world):
             groups = [{'params': list(net[2].parameters()), 'lr': 0.1}, {'params': list(net[0].parameters()) + [unused], 'lr': 0.01}]
             opt = supervised.FlatSGD(groups, lr=0.1, momentum=0.9)
             order = list(net[2].parameters()) + list(net[0].parameters())
-            assert [(g['_lo'], g['_hi']) for g in opt.param_groups] == [(0, 10), (10, 26)]
+            pad = lambda k: (k + 3) // 4 * 4                      # every parameter starts at a multiple of 16 bytes
+            n2, n0 = (sum(pad(p.numel()) for p in net[i].parameters()) for i in (2, 0))
+            assert [(g['_lo'], g['_hi']) for g in opt.param_groups] == [(0, n2), (n2, n2 + n0)]
+            assert all(o % 4 == 0 for o in opt.bucket.offsets)
         assert opt.bucket.params == order and unused.grad is None and opt.flat_g is opt.bucket.flat
         assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))       # values preserved by the re-pointing
         assert all(p.data_ptr() == opt.flat_p[o:].data_ptr() and p.grad.data_ptr() == opt.flat_g[o:].data_ptr()

@@ -208,7 +208,8 @@ def test_train_step_vs_reference_golden(golden):
         scale = float(g['gnorm'][i]) / max(1.0, p.numel() ** 0.5)          # typical element size of this gradient
         assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 5e-3 * scale + 1e-7, (n, got[:4], ref[:4])
     opt = training.FlatAdam(m.parameters(), lr=c['lr'], weight_decay=c['weight_decay'])
-    assert len(opt.params) == 340 and opt.flat_p.numel() == sum(p.numel() for p in opt.params)
+    assert len(opt.params) == 340 and opt.bucket.numel_params == sum(p.numel() for p in opt.params) <= opt.flat_p.numel()
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in opt.params)      # 16-byte vector loads of weights
     opt.step()
     torch.cuda.synchronize()
     for i, k in enumerate(str(s) for s in g['keep']):
