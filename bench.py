@@ -203,7 +203,7 @@ def loader_io_rate(dev, iters=20):
         chain(12)                                             # warm-up: graph capture on every lane, allocator steady state
         w._retire('all')
         torch.cuda.synchronize()
-        nb = 72
+        nb = 288                                              # ~0.35 s: long enough that pipeline fill / drain and the clock ramp stop mattering
         t0 = time.perf_counter()
         chain(nb)
         torch.cuda.synchronize()

@@ -69,9 +69,20 @@ int encode_png(const uint8_t* img, int H, int W, int level, std::vector<uint8_t>
             for (int x = 0; x < W; ++x) r[1 + x] = (uint8_t)(cur[x] - up[x]);
         }
     }
-    uLongf cap = compressBound((uLong)raw.size());
+    // Z_RLE: after the "Up" filter a label map is long runs of zeros with isolated boundary bytes; run-length matching finds all
+    // of that structure at a fraction of the default strategy's hash-chain search time (zlib.h recommends it for PNG data).  The
+    // stream is ordinary deflate: any PNG reader decodes it.
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, Z_RLE) != Z_OK) return -1;
+    uLongf cap = deflateBound(&zs, (uLong)raw.size());
     std::vector<uint8_t> z(cap);
-    if (compress2(z.data(), &cap, raw.data(), (uLong)raw.size(), level) != Z_OK) return -1;
+    zs.next_in = raw.data();  zs.avail_in = (uInt)raw.size();
+    zs.next_out = z.data();  zs.avail_out = (uInt)cap;
+    const int zrc = deflate(&zs, Z_FINISH);
+    cap = zs.total_out;
+    deflateEnd(&zs);
+    if (zrc != Z_STREAM_END) return -1;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     out.clear();
     out.reserve(cap + 64);
