@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include <mutex>
 
@@ -633,10 +634,247 @@ static int launch_direct(const float* x, const float* w, int N, int n, int H, in
     return MSPL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming form, stride 2 (round 3).  The direct form above re-reads every input row through L1 once per output row that uses it:
+// 44 16-byte loads per lane for 8 x 4 outputs at 144x240 -> 72x120, ~18 L1 reads per input element.  Alone that launch runs at
+// 3.1 TB/s; with three label passes in flight (what the headline measures) the same launch takes 180 us instead of 74 us: the
+// CU's one L1 / texture-address path is the resource the co-running kernels fight over (profiles/r03_kernel_stats_inflight3.csv:
+// 11.5 % of all kernel time).  Here every input element is loaded ONCE: a lane owns 8 adjacent input columns (4 output columns)
+// of one plane and walks down the rows; the 4 halo columns on either side come from the neighbouring lanes (v_mov_dpp wave_shr /
+// wave_shl); an input row is consumed the moment it arrives -- it contributes to the (at most five) output rows that use it,
+// which are carried in a ring of accumulators -- so there is no row window in registers and no LDS.  Per accumulator the
+// contributions arrive by ascending input row = kernel row 0, 1, 2, each as (kx = 0, 1, 2): the order of the other two forms,
+// bit-identical results.
+//   step t (input rows 2t, 2t+1):  even row 2t  -> output rows t-2 (d=4,ky=2) t-1 (d=2,ky=2) t (ky=1, all d) t+1 (d=2,ky=0) t+2 (d=4,ky=0)
+//                                  output row t-2 is complete: hierarchical sums, folded BN + PReLU, four 16-byte stores
+//                                  odd row 2t+1 -> output rows t-1 (d=3,ky=2) t (d=1,ky=2) t+1 (d=1,ky=0) t+2 (d=3,ky=0)
+// Units (image, row segment) of the SAME channel share a wave (SUB = 64 / (W/8 + 1) of them, one dead lane between two units whose
+// out-of-range loads return zeros = the zero padding the DPP exchange needs), so weights and epilogue constants are scalar loads.
+// Rows outside the plane / dead lanes: buffer loads with an offset beyond the descriptor's range (zeros, no traffic, no select).
+struct S2Geom {
+    int N, n, H, W, Ho, Wo;
+    int LPR, SLOT, SUB;          // lanes per input row (W / 8), lanes per unit slot (LPR + 1), units per wave
+    int SEG, nseg, upc, wpc;     // output rows per unit, units per plane, units and waves per channel
+    unsigned total;              // waves
+    unsigned in_bytes, out_bytes;
+    int wt;
+};
+
+__device__ __forceinline__ float s2_from_left(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float s2_from_right(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+template <class DS, bool WT>
+__global__ __launch_bounds__(256) void eesp_dw_stream2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ escale, const float* __restrict__ eshift,
+                                                              const float* __restrict__ ealpha, int ctot, int coff, S2Geom g,
+                                                              float* __restrict__ out) {
+    static_assert(DS::maxd() <= 4, "accumulator ring of five output rows");
+    const int lane = threadIdx.x & 63;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wid >= g.total) return;                                   // wave-uniform; no barrier in this kernel
+    const int c = wid / g.wpc, wic = wid - c * g.wpc;            // uniform
+    const int slot = lane / g.SLOT, cl = lane - slot * g.SLOT;
+    const int unit = wic * g.SUB + slot;
+    const bool live = slot < g.SUB && cl < g.LPR && unit < g.upc;
+    const int uc = live ? unit : 0;
+    const int img = uc / g.nseg, sgi = uc - img * g.nseg;
+    const int ys = sgi * g.SEG, ye = min(ys + g.SEG, g.Ho);
+    // plane constants (wave-uniform: scalar loads)
+    float wk[4][9], sc[4], sh[4], al[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wk[k][q] = w[((size_t)k * g.n + c) * 9 + q];
+        const int cabs = coff + k * g.n + c;
+        sc[k] = escale ? escale[cabs] : 1.f;  sh[k] = eshift ? eshift[cabs] : 0.f;  al[k] = ealpha ? ealpha[cabs] : 1.f;
+    }
+    const bool has_act = ealpha != nullptr;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)g.out_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)g.W * 4u, orow_bytes = (unsigned)g.Wo * 4u;
+    const unsigned ibase = (unsigned)((((size_t)img * g.n + c) * g.H) * (size_t)g.W * 4u) + (unsigned)cl * 32u;
+    const unsigned obase = (unsigned)((((size_t)img * ctot + coff + c) * g.Ho) * (size_t)g.Wo * 4u) + (unsigned)cl * 16u;
+    const unsigned okstride = (unsigned)((size_t)g.n * g.Ho * g.Wo * 4u);
+    constexpr unsigned OOR = 0x80000000u;
+
+    auto request = [&](int r, dd_u32x4& a, dd_u32x4& b) {           // input row r of this lane's unit: columns 8 cl .. 8 cl + 7
+        const unsigned off = (live && r >= 0 && r < g.H) ? ibase + (unsigned)r * row_bytes : OOR;
+        a = __builtin_amdgcn_raw_buffer_load_b128(irsrc, (int)off, 0, 0);
+        b = __builtin_amdgcn_raw_buffer_load_b128(irsrc, (int)(off + 16u), 0, 0);       // (OOR + 16 is out of range too)
+    };
+    auto widen = [&](const dd_u32x4& a, const dd_u32x4& b, float (&r)[16]) {
+        r[4] = __uint_as_float(a.x); r[5] = __uint_as_float(a.y); r[6] = __uint_as_float(a.z); r[7] = __uint_as_float(a.w);
+        r[8] = __uint_as_float(b.x); r[9] = __uint_as_float(b.y); r[10] = __uint_as_float(b.z); r[11] = __uint_as_float(b.w);
+        r[0] = s2_from_left(r[8]); r[1] = s2_from_left(r[9]); r[2] = s2_from_left(r[10]); r[3] = s2_from_left(r[11]);
+        r[12] = s2_from_right(r[4]); r[13] = s2_from_right(r[5]); r[14] = s2_from_right(r[6]); r[15] = s2_from_right(r[7]);
+    };
+
+    float acc[5][4][4];                                           // [output row t-2 .. t+2][branch][column]
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q][k][j] = 0.f;
+
+    // the rows of step t + 2 are requested while step t is computed (two steps = 8 KB per wave in flight: with one step the
+    // launch ran at 4.5 TB/s, short of bytes in flight)
+    dd_u32x4 ea, eb, oa, ob, fa, fb, pa, pb;
+    request(2 * (ys - 2), ea, eb);
+    request(2 * (ys - 2) + 1, oa, ob);
+    request(2 * (ys - 1), fa, fb);
+    request(2 * (ys - 1) + 1, pa, pb);
+    const int steps = g.SEG + 4;                                  // uniform
+    // One step; R = how far the ring has turned: the accumulators of output row t - 2 + q live in acc[(q + R) % 5].  The loop below
+    // is unrolled over the ring's period, so "the ring moves on" is a renaming, not 64 register moves per step.
+    auto step = [&](auto rc, int i) {
+        constexpr int R = decltype(rc)::value % 5, P = decltype(rc)::value & 1;
+        const int t = ys - 2 + i;
+        float re[16], ro[16];
+        // two request buffers taken in turn: the one consumed now is refilled with the rows of step t + 2 (no register copies: a copy
+        // of a register with a load in flight waits for the load)
+        const int rn = i + 2 < steps ? 2 * t + 4 : -2;            // (steps past the unit's last one request nothing)
+        if (P == 0) {
+            widen(ea, eb, re);  widen(oa, ob, ro);
+            request(rn, ea, eb);  request(rn + 1, oa, ob);
+        } else {
+            widen(fa, fb, re);  widen(pa, pb, ro);
+            request(rn, fa, fb);  request(rn + 1, pa, pb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- even input row 2t
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int d = DS::d(k), off = d * (ky - 1);
+                if (off & 1) continue;                            // compile time
+                const int q = (2 - off / 2 + R) % 5;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cj = 4 + 2 * j;
+                    acc[q][k][j] = fmaf(wk[k][ky * 3], re[cj - d], acc[q][k][j]);
+                    acc[q][k][j] = fmaf(wk[k][ky * 3 + 1], re[cj], acc[q][k][j]);
+                    acc[q][k][j] = fmaf(wk[k][ky * 3 + 2], re[cj + d], acc[q][k][j]);
+                }
+            }
+        // ---- output row t - 2 is complete
+        {
+            constexpr int q0 = R % 5;
+            const int yo = t - 2;
+            const bool ok = live && i >= 4 && yo < ye;
+            const unsigned o0 = ok ? obase + (unsigned)yo * orow_bytes : OOR;
+            float prev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[q0][k][j] + prev[j];
+                    prev[j] = a;
+                    float q = fmaf(a, sc[k], sh[k]);
+                    if (has_act) q = q > 0.f ? q : al[k] * q;
+                    v[j] = q;
+                    acc[q0][k][j] = 0.f;                          // becomes output row t + 3 of the next step
+                }
+                const dd_u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                const unsigned oo = ok ? o0 + (unsigned)k * okstride : OOR;
+                __builtin_amdgcn_raw_buffer_store_b128(dv, orsrc, (int)oo, 0, WT ? 16 : 0);      // 16 = sc1 (write-through, as the other forms)
+            }
+        }
+        // ---- odd input row 2t + 1 (its output rows t-1 .. t+2 are slots 1 .. 4: slot 0 was just retired)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int d = DS::d(k), off = d * (ky - 1);
+                if (!(off & 1)) continue;                         // compile time
+                const int q = (2 + (1 - off) / 2 + R) % 5;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cj = 4 + 2 * j;
+                    acc[q][k][j] = fmaf(wk[k][ky * 3], ro[cj - d], acc[q][k][j]);
+                    acc[q][k][j] = fmaf(wk[k][ky * 3 + 1], ro[cj], acc[q][k][j]);
+                    acc[q][k][j] = fmaf(wk[k][ky * 3 + 2], ro[cj + d], acc[q][k][j]);
+                }
+            }
+    };
+    // 10 steps per trip = lcm(ring period 5, request buffers 2), all of them unconditional: with a branch per step the compiler's
+    // s_waitcnt placement merges the paths and ends up draining the previous step's stores before every step (1.0 us per step instead
+    // of 0.5).  Steps past the unit's last one compute on zeros and store nothing; the launcher picks SEG with (SEG + 4) % 10 == 0.
+#pragma unroll 1
+    for (int i = 0; i < steps; i += 10) {
+        step(std::integral_constant<int, 0>(), i);
+        step(std::integral_constant<int, 1>(), i + 1);
+        step(std::integral_constant<int, 2>(), i + 2);
+        step(std::integral_constant<int, 3>(), i + 3);
+        step(std::integral_constant<int, 4>(), i + 4);
+        step(std::integral_constant<int, 5>(), i + 5);
+        step(std::integral_constant<int, 6>(), i + 6);
+        step(std::integral_constant<int, 7>(), i + 7);
+        step(std::integral_constant<int, 8>(), i + 8);
+        step(std::integral_constant<int, 9>(), i + 9);
+    }
+}
+
+// Returns MSPL_OK when launched, 1 when the shape is left to the other forms.
+template <class DS>
+static int launch_stream2(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out, hipStream_t s) {
+    const char* menv = getenv("MSPL_DW_STREAM");                 // 0 off, 1 auto, 2 whenever the shape allows; read per call (tests switch it)
+    const int mode = menv ? atoi(menv) : 1;
+    if (!mode || DS::maxd() > 4) return 1;
+    if ((W & 7) != 0 || W / 8 > 63 || H < 8) return 1;
+    if (e.pre_add || e.residual || e.reinf_r || e.gate || e.raw) return 1;
+    S2Geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.n = n; g.H = H; g.W = W;
+    g.Ho = (H - 1) / 2 + 1;  g.Wo = W / 2;
+    const size_t in_bytes = (size_t)N * n * H * W * sizeof(float), out_bytes = (size_t)N * e.ctot * g.Ho * g.Wo * sizeof(float);
+    if (in_bytes >= (1ull << 31) || out_bytes >= (1ull << 31)) return 1;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 15)) return 1;
+    g.in_bytes = (unsigned)in_bytes;  g.out_bytes = (unsigned)out_bytes;
+    g.LPR = W / 8;  g.SLOT = g.LPR + 1;  g.SUB = 64 / g.SLOT;
+    if (g.SUB < 1) return 1;
+    // Rows per unit.  The kernel runs 10 steps per loop trip, so SEG + 4 is a multiple of 10 (6, 16, 26, ...); a unit reads 8 halo
+    // rows on top of its 2 * SEG, so long units are cheaper -- as long as ~3 waves per CU remain (measured, tools/bench_ops.py k2,
+    // MSPL_DW_SSEG sweep: 144x240 n=24 batch 16: SEG 6 / 16 / 26 / 36 = 25.0 / 20.9 / 23.6 / 28.4 us (960 waves at 16), batch 32:
+    // 42.5 / 38.2 / 46.3 / 36.5 us (768 waves at 36); 72x120 n=32 batch 16: 9.6 / 15.6 / 21.5 / 27.3 us (768 waves at 6); the direct
+    // form: 30.9, 55.7 and 10.5 us).
+    static const int dbg_seg = getenv("MSPL_DW_SSEG") ? atoi(getenv("MSPL_DW_SSEG")) : 0;
+    auto waves_of = [&](int sg) { return (int64_t)n * ceil_div64((int64_t)N * ceil_div(g.Ho, sg), g.SUB); };
+    int seg = 6;
+    for (int sg = 16; sg - 10 < g.Ho; sg += 10)
+        if (waves_of(std::min(sg, g.Ho)) >= 700) seg = sg;
+    if (dbg_seg > 0) seg = dbg_seg;
+    seg = std::min(seg, g.Ho);
+    if (mode == 1 && waves_of(seg) < 700) return 1;              // too few planes: the other forms
+    g.SEG = seg;  g.nseg = ceil_div(g.Ho, seg);
+    g.upc = N * g.nseg;  g.wpc = ceil_div(g.upc, g.SUB);
+    const int64_t waves = (int64_t)n * g.wpc;
+    if (waves >= (1ll << 31)) return 1;
+    g.total = (unsigned)waves;
+    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    g.wt = dbg_wt;
+    if (g.wt) hipLaunchKernelGGL((eesp_dw_stream2_kernel<DS, true>), dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, s, x, w, e.scale, e.shift,
+                                 e.alpha, e.ctot, e.coff, g, out);
+    else hipLaunchKernelGGL((eesp_dw_stream2_kernel<DS, false>), dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, s, x, w, e.scale, e.shift,
+                            e.alpha, e.ctot, e.coff, g, out);
+    MSPL_CHECK_LAUNCH("eesp_dw_hff(streaming, stride 2)");
+    return MSPL_OK;
+}
+
 template <int STRIDE, class DS>
 static int launch(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out,
                   hipStream_t s) {
     constexpr int MAXD = DS::maxd();
+    if (STRIDE == 2) {
+        const int rc = launch_stream2<DS>(x, w, N, n, H, W, e, out, s);
+        if (rc <= 0) return rc;
+    }
     {
         const int rc = launch_direct<STRIDE, DS>(x, w, N, n, H, W, e, out, s);
         if (rc <= 0) return rc;

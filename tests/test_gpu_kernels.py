@@ -40,6 +40,39 @@ def test_eesp_dw_hff(dil, stride, shape):
     close(raw, torch.cat(outs, 1))
 
 
+@pytest.mark.parametrize('dil', [[1, 2, 3, 4], [1, 1, 2, 3]])
+@pytest.mark.parametrize('shape', [(2, 3, 144, 240), (3, 5, 70, 248), (5, 2, 37, 120), (1, 2, 9, 504), (2, 4, 64, 8)])
+def test_eesp_dw_hff_stride2_streaming_form(dil, shape, monkeypatch):
+    """The register-streaming stride-2 kernel (forced: these planes are too few for its automatic choice) against the same
+    reference, and bit-identical to the direct / tiled forms (same summation order per accumulator)."""
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, n, H, W = shape
+    x = rnd(*shape, seed=1)
+    w = rnd(4, n, 3, 3, seed=2, scale=0.3)
+    scale, shift, alpha = rnd(4 * n, seed=3).abs() + 0.5, rnd(4 * n, seed=4) * 0.1, rnd(4 * n, seed=5).abs() * 0.3
+    outs = []
+    for k in range(4):
+        o = F.conv2d(x, w[k].unsqueeze(1), None, 2, dil[k], dil[k], n)
+        outs.append(o if k == 0 else o + outs[-1])
+    ref = F.prelu(torch.cat(outs, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha)
+    ep = Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV))
+    monkeypatch.setenv('MSPL_DW_STREAM', '0')
+    base = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
+    monkeypatch.setenv('MSPL_DW_STREAM', '2')
+    got = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
+    raw = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2)
+    # into a channel slice of a wider destination
+    dst = torch.full((N, 4 * n + 3, got.shape[2], got.shape[3]), -5.0, device=DEV)
+    sc2, sh2, al2 = torch.ones(4 * n + 3), torch.zeros(4 * n + 3), torch.ones(4 * n + 3)
+    sc2[2:2 + 4 * n], sh2[2:2 + 4 * n], al2[2:2 + 4 * n] = scale, shift, alpha
+    ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, Epi(sc2.to(DEV), sh2.to(DEV), al2.to(DEV)), out=(dst, 2))
+    close(got, ref)
+    close(raw, torch.cat(outs, 1))
+    assert torch.equal(got, base)
+    assert torch.equal(dst[:, 2:2 + 4 * n], got) and torch.all(dst[:, :2] == -5.0) and torch.all(dst[:, 2 + 4 * n:] == -5.0)
+
+
 @pytest.mark.parametrize('cfg', [(2, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 128, 4, 16, 30, [1, 1, 2, 3]), (2, 256, 64, 4, 18, 30, [1, 2, 3, 4]),
                                  (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4]),
                                  (32, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 64, 4, 20, 36, [1, 1, 2, 3])])
