@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import dist as mdist
+from . import ops
 from ._native import check, lib
 from .ops import _f32, _p, _stream
 from .uest import _GraphedPassMixin, _lowres
@@ -157,13 +158,69 @@ class EvalPass(EvalSums, _GraphedPassMixin):
                           torch.tensor([float(self.batches)], dtype=torch.float64, device=self.device)])
 
 
+class PipelinedEvalPass(EvalSums):
+    """`depth` EvalPass lanes taken in turn, each on a stream of its own with its own hipGraph, static inputs and accumulators: the
+    evaluation step of consecutive batches overlaps on the GPU the way the label pass's lanes do (one graph replay alone leaves the
+    chip half idle: its kernels are small and run one after the other).  The lanes never share an accumulator, so nothing races;
+    `sums()` adds them up (integer areas: exact; the loss sums are float64 sums of per-batch means either way)."""
+
+    def __init__(self, model, num_classes, depth=3, **kw):
+        from .uest import _concurrent_streams
+        kw.setdefault('use_graph', True)
+        self.lanes = [EvalPass(model, num_classes, **kw) for _ in range(max(1, int(depth)))]
+        self.device = self.lanes[0].device
+        self.K = self.lanes[0].K
+        self.streams = _concurrent_streams(len(self.lanes), self.device) if len(self.lanes) > 1 else [None]
+        self._next = 0
+
+    @property
+    def batches(self):
+        return sum(l.batches for l in self.lanes)
+
+    def reset(self):
+        self._join()
+        for l in self.lanes:
+            l.reset()
+
+    def _join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            if st is not None:
+                cur.wait_stream(st)
+
+    def __call__(self, images, labels, depth=None):
+        i = self._next
+        self._next = (i + 1) % len(self.lanes)
+        lane, st = self.lanes[i], self.streams[i]
+        if st is None:
+            return lane(images, labels, depth)
+        images = images.to(self.device)
+        labels = labels.to(self.device)
+        depth = None if depth is None else depth.to(self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))          # the caller's batch is complete before the lane copies it
+        with torch.cuda.stream(st), ops.launch_flags(throughput=True):      # launch shapes for kernels that share the GPU (see uest.py)
+            out = lane(images, labels, depth)
+        for t in (images, labels, depth):
+            if t is not None:
+                t.record_stream(st)
+        return out
+
+    def sums(self):
+        self._join()
+        total = self.lanes[0].sums()
+        for l in self.lanes[1:]:
+            total = total + l.sums()
+        return total
+
+
 def val_seg_ue(model, dataset_loader, criterion=None, num_classes=21, device='cuda', use_depth=False, add_criterion=None,
-               greenhouse_use_trav=False, use_graph=True, pre_sharded=False, _eval_pass=None):
+               greenhouse_use_trav=False, use_graph=True, pre_sharded=False, _eval_pass=None, lanes=3):
     """Drop-in for utilities/train_eval_seg.py:249-324: returns (iou, average loss) ((iou, 0) without a criterion).
 
     criterion: a SegmentationLoss-like object -- its `class_wts` / `class_weights` and `ignore_idx` are read (loss_type 'ce'); None
     evaluates the MIOU only.  add_criterion (the NID term of the supervised loop) has no fused form and is refused.
-    One process per GPU: rank r takes batches b == r (mod world) unless the loader is pre_sharded; every rank returns the same result."""
+    One process per GPU: rank r takes batches b == r (mod world) unless the loader is pre_sharded; every rank returns the same result.
+    lanes: evaluation steps in flight on the GPU (PipelinedEvalPass; 1 = one graph replay after the other)."""
     if add_criterion is not None:
         raise NotImplementedError('mspl_amd: val_seg_ue(add_criterion=...) is not on the path (the shipped scripts pass None)')
     cw = ign = None
@@ -175,8 +232,14 @@ def val_seg_ue(model, dataset_loader, criterion=None, num_classes=21, device='cu
             cw = getattr(criterion, 'class_weights', None)
         ign = getattr(criterion, 'ignore_idx', 255)
     # (_eval_pass: an EvalSums stand-in with EvalPass's call signature, for host-logic tests without a GPU)
-    ep = _eval_pass if _eval_pass is not None else EvalPass(model, num_classes, class_weights=cw, ignore_idx=255 if ign is None else ign,
-                                                           aux_weight=0.5, device=device, use_graph=use_graph)
+    if _eval_pass is not None:
+        ep = _eval_pass
+    elif use_graph and lanes > 1:
+        ep = PipelinedEvalPass(model, num_classes, depth=lanes, class_weights=cw, ignore_idx=255 if ign is None else ign, aux_weight=0.5,
+                               device=device)
+    else:
+        ep = EvalPass(model, num_classes, class_weights=cw, ignore_idx=255 if ign is None else ign, aux_weight=0.5, device=device,
+                      use_graph=use_graph)
     rank, world = mdist.world()
     for b, batch in enumerate(dataset_loader):
         if world > 1 and not pre_sharded and b % world != rank:

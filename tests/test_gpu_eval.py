@@ -111,3 +111,35 @@ def test_eval_pass_graph_equals_eager_and_reset():
     c = ev.EvalPass(m, C, ignore_idx=4, device=DEV)
     c(xs[0], ys[0])
     assert torch.equal(b.areas, c.areas)
+
+
+def test_pipelined_eval_pass_equals_one_lane():
+    """Three evaluation steps in flight (PipelinedEvalPass, what val_seg_ue runs) give the sums of one lane: areas exactly, the loss sums
+    to float64 rounding; batches of two shapes (a short last batch), reset, and the tensors handed in may be reused at once."""
+    from mspl_amd import evaluation as ev
+    C = 5
+    m, _ = _model(C, 'greenhouse', 72)
+    g = torch.Generator().manual_seed(10)
+    shapes = [(4, 64, 96)] * 7 + [(2, 64, 96)]
+    xs = [torch.randn(n, 3, h, w, generator=g) for n, h, w in shapes]
+    ys = [torch.randint(0, C, (n, h, w), generator=g) for n, h, w in shapes]
+    one = ev.EvalPass(m, C, class_weights=torch.rand(C, generator=g) + 0.5, ignore_idx=4, device=DEV, use_graph=True)
+    three = ev.PipelinedEvalPass(m, C, depth=3, class_weights=one.cw, ignore_idx=4, device=DEV)
+    buf_x, buf_y = torch.empty(4, 3, 64, 96, device=DEV), torch.empty(4, 64, 96, dtype=torch.int64, device=DEV)
+    for rep in range(2):
+        for x, y in zip(xs, ys):
+            one(x.to(DEV), y.to(DEV))
+            n = x.shape[0]
+            buf_x[:n].copy_(x)                      # the same device buffers every batch: the lane must have taken its copy before
+            buf_y[:n].copy_(y)                      # the next batch overwrites them
+            three(buf_x[:n], buf_y[:n])
+        a, b = one.sums().cpu().numpy(), three.sums().cpu().numpy()
+        assert three.batches == one.batches == len(xs)
+        assert np.array_equal(a[:3 * (C - 1)], b[:3 * (C - 1)]) and a[-1] == b[-1] and a[-2] == b[-2]
+        assert abs(a[-3] - b[-3]) <= 1e-12 * abs(a[-3])
+        i1, l1 = one.result(reduce=False)
+        i3, l3 = three.result(reduce=False)
+        assert np.array_equal(i1, i3) and abs(l1 - l3) <= 1e-12 * abs(l1)
+        one.reset()
+        three.reset()
+        assert three.batches == 0 and float(three.sums().abs().sum()) == 0.0

@@ -14,7 +14,7 @@ d, out = sys.argv[1], sys.argv[2]
 
 def k2_values(counter):
     rows = csv.DictReader(open('%s/%s_counter_collection.csv' % (d, counter)))
-    return [float(r['Counter_Value']) for r in rows if ('eesp_dw_hff' in r['Kernel_Name'] or 'eesp_dw_direct' in r['Kernel_Name']) and r['Counter_Name'] == counter]
+    return [float(r['Counter_Value']) for r in rows if any(k in r['Kernel_Name'] for k in ('eesp_dw_hff', 'eesp_dw_direct', 'eesp_dw_stream2')) and r['Counter_Name'] == counter]
 
 
 f, w = k2_values('FETCH_SIZE'), k2_values('WRITE_SIZE')
