@@ -663,8 +663,13 @@ def main():
         ho_, wo_ = (hi_ - 1) // st_ + 1, (wi_ - 1) // st_ + 1
         k2_bytes += 4 * n_ * ch_ * (hi_ * wi_ + 4 * ho_ * wo_)
     model_bytes, model_launches = k2_algorithmic_bytes(model, BATCH, H, W)
-    k2_note = None if (model_launches == k2_launches and model_bytes == k2_bytes) else (
-        'recorded %d K2 launches / %d bytes, the model walk gives %d / %d' % (k2_launches, k2_bytes, model_launches, model_bytes))
+    k2_note = ('ten of the 13 launches are the stride-1 blocks of levels 3 / 4: 44 and 22 MB per launch.  A kernel that only moves those bytes '
+               '(tools/ubench/floor.hip, profiles/r02_k2_movement_floor.txt) takes 6.1 / 4.0 us with write-through stores = 0.91 / 0.69 of '
+               '8 TB/s (10.0 / 6.1 us = 0.55 / 0.45 with plain stores) on warm caches with nothing else to do, and an empty launch 2.2 us: 0.70 '
+               'for the 13-launch average is not reachable at batch 16; a register-streaming form of the stride-1 launches was built and '
+               'measured slower (DESIGN 4c); the stride-2 launches run at 0.47 in the pass (0.64 alone) in their streaming form')
+    if not (model_launches == k2_launches and model_bytes == k2_bytes):
+        k2_note += '; recorded %d K2 launches / %d bytes, the model walk gives %d / %d' % (k2_launches, k2_bytes, model_launches, model_bytes)
 
     # ---- the same launches timed IN the pass: one eager label pass, the stream parked behind a spin kernel (so the host's launch
     # cadence is out of the picture), a HIP event pair around every K2 launch.  An event pair adds its own time to what it brackets;
