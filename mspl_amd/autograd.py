@@ -370,8 +370,9 @@ class EESPFn(torch.autograd.Function):
         c1 = torch.empty((N, n, H, W), device=x.device, dtype=torch.float32)
         o1 = ops.conv1x1(x, wp, groups, Epi(fp['scale'], fp['shift'], ap, raw_out=c1))
         w4 = _stack4((w0, w1, w2, w3))
-        z2 = ops.eesp_dw_hff(o1, w4, dil, stride)
-        y2 = ops.pointwise(z2, Epi(fb['scale'], fb['shift'], a2))
+        # K2 writes the hierarchical sums (what br_after_cat's backward reads) and their BN + PReLU in one launch
+        z2 = torch.empty((N, 4 * n, (H - 1) // stride + 1, (W - 1) // stride + 1), device=x.device, dtype=torch.float32)
+        y2 = ops.eesp_dw_hff(o1, w4, dil, stride, Epi(fb['scale'], fb['shift'], a2, raw_out=z2))
         Cout = we.shape[0]
         c3 = torch.empty((N, Cout) + tuple(z2.shape[2:]), device=x.device, dtype=torch.float32)
         y = ops.conv1x1(y2, we, groups, Epi(fe['scale'], fe['shift'], am, residual=x if residual else None, raw_out=c3))

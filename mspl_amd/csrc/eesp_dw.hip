@@ -99,6 +99,7 @@ struct DwItemCtx {
     char* ob;                       // first output plane of the tile (branch 0)
     float* out;                     // destination tensor (base of the write-through descriptor)
     __amdgpu_buffer_rsrc_t orsrc;
+    char* rawb;                     // training forward: the sums BEFORE the folded BN + PReLU go here too (same layout as ob), or null
 };
 
 // The arithmetic of a tile that sits in LDS (shared by the tiled kernel and the fused projection + K2 kernel, eesp_front.hip).
@@ -194,6 +195,15 @@ __device__ __forceinline__ void dw_compute_items(const float* __restrict__ tile,
                         float q = fmaf(a[r][j], ec.x, ec.y);
                         if (has_act) q = q > 0.f ? q : ec.z * q;
                         v[j] = q;
+                    }
+                    if (c.rawb) {                                 // uniform; what br_after_cat's backward reads (training forward)
+                        float* rd = reinterpret_cast<float*>(c.rawb + kk * kstride + voff);
+                        if (o16) *reinterpret_cast<float4*>(rd) = make_float4(a[r][0], a[r][1], a[r][2], a[r][3]);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (xb + j < c.Wo) rd[j] = a[r][j];
+                        }
                     }
                     float* dst = reinterpret_cast<float*>(ob + kk * kstride + voff);
                     if (o16 && c.wt) {
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(PERSIST ? 256 : 1024, PERSIST ? 3 : 4) void eesp_dw
             cx.y0 = y0; cx.mag_xs = g.mag_xs; cx.wt = g.wt; cx.o16 = o16; cx.o8 = o8; cx.has_act = has_act; cx.kstride = kstride;
             cx.ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
             cx.out = out; cx.orsrc = orsrc;
+            cx.rawb = e.raw ? reinterpret_cast<char*>(e.raw + ((size_t)img * e.ctot + c0) * (size_t)hw) : nullptr;     // (ctot == 4n, coff == 0)
             dw_compute_items<STRIDE, DS>(tile, wl, el, cx, tid, nthr);
         }
         if (PERSIST) __syncthreads();                  // every wave is done reading the tile before the next one is written
@@ -538,6 +549,12 @@ __global__ __launch_bounds__(512, 2) void eesp_dw_direct_kernel(const float* __r
                     v[j] = q;
                 }
                 if (!yok) continue;
+                if (e.raw) {                                      // uniform; training forward (un-sliced destination: same offsets)
+                    float* rd = reinterpret_cast<float*>(reinterpret_cast<char*>(e.raw + ((size_t)img * e.ctot + c0) * (size_t)hw) + k * kstride + voff);
+                    if (o16) *reinterpret_cast<float4*>(rd) = make_float4(a[ry][k][0], a[ry][k][1], a[ry][k][2], a[ry][k][3]);
+                    else if (xs * 4 + 2 < g.Wo) { rd[0] = a[ry][k][0]; rd[1] = a[ry][k][1]; rd[2] = a[ry][k][2]; rd[3] = a[ry][k][3]; }
+                    else { rd[0] = a[ry][k][0]; rd[1] = a[ry][k][1]; }
+                }
                 float* dst = reinterpret_cast<float*>(ob + k * kstride + voff);
                 const int boff = (int)(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(out));
                 const dd_u32x4 dv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
@@ -1167,6 +1184,7 @@ __global__ __launch_bounds__(512) void eesp_proj_dw_kernel(const float* __restri
     cx.kstride = (size_t)g.n * hw * sizeof(float);
     cx.ob = reinterpret_cast<char*>(out + ((size_t)img * e.ctot + e.coff + c0) * (size_t)hw);
     cx.out = out;
+    cx.rawb = nullptr;
     cx.orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)g.N * e.ctot * hw * sizeof(float)), 0x00020000);
     dw_compute_items<1, DS>(tile, wl, el, cx, tid, nthr);
 }
@@ -1276,7 +1294,7 @@ extern "C" int mspl_eesp_dw_hff_fwd(const float* x, const float* w, const int32_
                  "eesp_dw_hff: bad shape N=%d n=%d H=%d W=%d", N, n, H, W);
     MSPL_REQUIRE(stride == 1 || stride == 2, MSPL_ERR_UNSUPPORTED, "eesp_dw_hff: stride %d (1 or 2)", stride);
     MSPL_REQUIRE((int64_t)4 * H * W < (1ll << 29), MSPL_ERR_BAD_SHAPE, "eesp_dw_hff: plane %dx%d too large", H, W);
-    if (int rc = check_epi(ep, 4 * n, "eesp_dw_hff")) return rc;
+    if (int rc = check_epi(ep, 4 * n, "eesp_dw_hff", true)) return rc;      // raw_out: the training forward keeps the pre-BN sums
     MSPL_REQUIRE(!ep || (!ep->pre_add && !ep->residual && !ep->reinf_r && !ep->gate), MSPL_ERR_UNSUPPORTED,
                  "eesp_dw_hff: only scale/shift/alpha epilogue terms are supported (br_after_cat)");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;

@@ -38,6 +38,10 @@ def test_eesp_dw_hff(dil, stride, shape):
     close(got, ref)
     raw = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, stride)       # no epilogue
     close(raw, torch.cat(outs, 1))
+    # training forward: activated output and the bare sums from ONE launch (raw_out)
+    keep = torch.full_like(raw, 7.0)
+    both = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, stride, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), raw_out=keep))
+    assert torch.equal(both, got) and torch.equal(keep, raw)
 
 
 @pytest.mark.parametrize('dil', [[1, 2, 3, 4], [1, 1, 2, 3]])
