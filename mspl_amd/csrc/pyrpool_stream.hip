@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
     // per-lane C tables and never touches LDS tables of columns again.
     __shared__ __attribute__((aligned(16))) float At[2][(P3_SEGMAX + 2) * 24];        // [up branch][row][ky][8]
     __shared__ float Gt[2][3][PXL][5][64];                                             // [up branch][kx][column][tap][lane]
+    // merge_layer.2's 45 weights of the wave's plane, [branch][12] (9 used): read back with three broadcast 16-byte LDS reads per
+    // branch and row.  As 45 scalar registers (rounds 1-2) they did not fit next to the other plane constants: 44 spilled SGPRs,
+    // 32 v_readlane per row step (412 -> 382 vector instructions per row; same box, three launches in flight: 16 400 -> 16 700 images/s).
+    __shared__ __attribute__((aligned(16))) float Wm[4][5][12];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned bid = blockIdx.x;
     const int sgi = bid % g.nseg;  bid /= g.nseg;
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         }
     // (4) wave-uniform constants of this plane (scalar loads)
     const float* wsame = sw2 + (size_t)c * 9;
-    const float* wm = merge_w + (size_t)c * 45;
+    if (lane < 45) Wm[wave][lane / 9][lane % 9] = merge_w[(size_t)c * 45 + lane];      // (a wave's LDS operations execute in order: no barrier)
+    const float4* wmq = reinterpret_cast<const float4*>(&Wm[wave][0][0]);
     float bsc[5], bsh[5], bal[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) { bsc[i] = br_scale[i * g.P + c]; bsh[i] = br_shift[i * g.P + c]; bal[i] = br_alpha[i * g.P + c]; }
@@ -315,10 +320,12 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < PXL; ++j) bx[1 + j] = bv[i][j];
             bx[PXL + 1] = p3_from_right(bv[i][0]);
+            const float4 q0 = wmq[i * 3], q1 = wmq[i * 3 + 1], q2 = wmq[i * 3 + 2];
+            const float wv[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
             for (int r = 0; r < 3; ++r) {                   // acc[r] <-> output row br-1+r <-> kernel row ky = 2 - r
                 const int ky = 2 - r;
-                const float w0 = wm[i * 9 + ky * 3], w1 = wm[i * 9 + ky * 3 + 1], w2 = wm[i * 9 + ky * 3 + 2];
+                const float w0 = wv[ky * 3], w1 = wv[ky * 3 + 1], w2 = wv[ky * 3 + 2];
 #pragma unroll
                 for (int j = 0; j < PXL; ++j) {
                     acc[r][j] = fmaf(w0, bx[j], acc[r][j]);
