@@ -693,7 +693,7 @@ def main():
             ovh.append(max(0.0, sorted(ts)[len(ts) // 2] - b2b))
         return ovh
 
-    def k2_in_pass(mult, ovh, passes=3):
+    def k2_in_pass(mult, ovh, passes=7):
         xin = x if mult == 1 else torch.cat([x] * mult, 0)
         per_pass = []
         rec = []
@@ -831,7 +831,7 @@ def main():
                          'algorithmic_bytes_per_launch': int(k2_bytes / k2_launches), 'accounting_note': k2_note,
                          'avg_launch_us': ip1.get('avg_launch_us', round(avg_launch_s * 1e6, 3)),
                          'timing': ('HIP event pair around each K2 launch of one eager pass at batch 16 (stream parked behind a spin kernel; the '
-                                    'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 3 passes); '
+                                    'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 7 passes); '
                                     'rocprofv3 in the same pass: rocprof_avg_launch_us' if 'achieved' in ip1 else
                                     'isolated re-issues (in-pass measurement failed: %s)' % ip1.get('error')),
                          'event_pair_overhead_us': ip1.get('event_pair_overhead_us'), 'per_launch_us': ip1.get('per_launch_us'),
