@@ -364,6 +364,40 @@ struct RsG { int N, C, Hi, Wi, Ho, Wo; float sh, sw; unsigned mHi, mWi, mHo, mWo
 // n / d for n * d < 2^32 with m = ceil(2^32 / d) (d == 1: m overflows to 0, handled)
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
 
+// Even planes, rows of whole 16-byte strips: a thread turns a 2 x 5 patch of the output gradient (two float4 + their right neighbours)
+// into the 2 x 8 block of the input gradient under it -- even rows / columns are covered by one output, odd ones by two (the gather of
+// the kernel below, written out: same order of additions) -- with 16-byte loads and stores instead of one pixel per thread
+// (56 -> 15 us at 32 x 128x240).
+__global__ __launch_bounds__(256) void avgpool3x3s2_bwd_vec_kernel(const float* __restrict__ gy, RsG g, int XS, float* __restrict__ gx) {
+    const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.N * g.C || s >= g.Ho * XS) return;
+    const int k = s / XS, m0 = (s - k * XS) * 4;             // output row, first output column
+    const float* r0 = gy + (size_t)t * g.Ho * g.Wo + (size_t)k * g.Wo + m0;
+    const bool hasr = m0 + 4 < g.Wo, hasd = k + 1 < g.Ho;
+    const float4 a4 = *reinterpret_cast<const float4*>(r0);
+    const float ar = hasr ? r0[4] : 0.f;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);  float br = 0.f;
+    if (hasd) { b4 = *reinterpret_cast<const float4*>(r0 + g.Wo);  br = hasr ? r0[g.Wo + 4] : 0.f; }
+    const float a[5] = {a4.x, a4.y, a4.z, a4.w, ar}, b[5] = {b4.x, b4.y, b4.z, b4.w, br};
+    float e[8], o[8];                                        // input rows 2k (even) and 2k+1 (odd), columns 2 m0 .. 2 m0 + 7
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // the gather visits (oy, ox) in ascending order starting from 0: 0 + g[k][m] (+ g[k][m+1]) (+ g[k+1][m]) (+ g[k+1][m+1])
+        e[2 * j] = (0.f + a[j]) * (1.0f / 9.0f);
+        o[2 * j] = hasd ? ((0.f + a[j]) + b[j]) * (1.0f / 9.0f) : (0.f + a[j]) * (1.0f / 9.0f);
+        const bool hr = j < 3 || hasr;                       // the last odd column of a row has no right neighbour output
+        e[2 * j + 1] = hr ? ((0.f + a[j]) + a[j + 1]) * (1.0f / 9.0f) : (0.f + a[j]) * (1.0f / 9.0f);
+        o[2 * j + 1] = hasd ? (hr ? ((((0.f + a[j]) + a[j + 1]) + b[j]) + b[j + 1]) * (1.0f / 9.0f) : ((0.f + a[j]) + b[j]) * (1.0f / 9.0f))
+                            : (hr ? ((0.f + a[j]) + a[j + 1]) * (1.0f / 9.0f) : (0.f + a[j]) * (1.0f / 9.0f));
+    }
+    float* d = gx + (size_t)t * g.Hi * g.Wi + (size_t)(2 * k) * g.Wi + 2 * m0;
+    *reinterpret_cast<float4*>(d) = make_float4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(e[4], e[5], e[6], e[7]);
+    *reinterpret_cast<float4*>(d + g.Wi) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(d + g.Wi + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 __global__ __launch_bounds__(256) void avgpool3x3s2_bwd_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total) {
     const int t = blockIdx.z * gridDim.y + blockIdx.y;      // plane n*C + c
     const int pi = blockIdx.x * 256 + threadIdx.x;
@@ -919,6 +953,13 @@ extern "C" int mspl_avgpool3x3s2_bwd(const float* gy, int32_t N, int32_t C, int3
     const int64_t total = (int64_t)N * C * H * W;
     MSPL_REQUIRE((int64_t)H * W * W < (1ll << 32), MSPL_ERR_BAD_SHAPE, "avgpool3x3s2_bwd: plane too large for 32-bit index arithmetic");
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
+    if ((H & 1) == 0 && (W & 7) == 0 && ((((uintptr_t)gy) | ((uintptr_t)gx)) & 15) == 0) {      // whole 16-byte strips on both sides
+        const int XS = g.Wo / 4;
+        hipLaunchKernelGGL(avgpool3x3s2_bwd_vec_kernel, dim3((unsigned)ceil_div(g.Ho * XS, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)),
+                           dim3(256), 0, (hipStream_t)stream, gy, g, XS, gx);
+        MSPL_CHECK_LAUNCH("avgpool3x3s2_bwd(16-byte strips)");
+        return MSPL_OK;
+    }
     hipLaunchKernelGGL(avgpool3x3s2_bwd_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd)), dim3(256), 0,
                        (hipStream_t)stream, gy, g, gx, total);
     MSPL_CHECK_LAUNCH("avgpool3x3s2_bwd");

@@ -126,6 +126,8 @@ def test_resample_fns():
     from mspl_amd import autograd as ag
     x = rnd(2, 3, 15, 21, seed=1)
     check_op(lambda a: ag.avgpool(a), lambda a: F.avg_pool2d(a, 3, 2, 1), [x])
+    for shp in ((2, 3, 16, 24), (1, 2, 6, 8), (2, 5, 34, 40)):          # even planes, rows of whole 16-byte strips: the vectorised backward
+        check_op(lambda a: ag.avgpool(a), lambda a: F.avg_pool2d(a, 3, 2, 1), [rnd(*shp, seed=3)])
     check_op(lambda a: ag.bilinear(a, (30, 42)), lambda a: F.interpolate(a, (30, 42), mode='bilinear', align_corners=True), [x])
     check_op(lambda a: ag.bilinear(a, (7, 9)), lambda a: F.interpolate(a, (7, 9), mode='bilinear', align_corners=True), [x])
     check_op(lambda a: ag.adaptive_avgpool(a, (5, 5)), lambda a: F.adaptive_avg_pool2d(a, (5, 5)), [x])
