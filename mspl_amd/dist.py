@@ -29,6 +29,28 @@ class local_only(object):
         _LOCAL_ONLY[0] = self.prev
 
 
+_FORCE = [False]
+
+
+class force_collectives(object):
+    """with force_collectives(): the helpers issue their collective even when the group has ONE rank (where it is the identity).
+    Lets a one-GPU box execute the RCCL code path of the product (backend "nccl", device buffers) -- tests/test_gpu_rccl.py."""
+
+    def __enter__(self):
+        self.prev = _FORCE[0]
+        _FORCE[0] = True
+
+    def __exit__(self, *exc):
+        _FORCE[0] = self.prev
+
+
+def collective_needed():
+    """True when a helper must issue its collective: more than one rank, or a forced one-rank group."""
+    if not (dist.is_available() and dist.is_initialized()) or _LOCAL_ONLY[0]:
+        return False
+    return dist.get_world_size() > 1 or _FORCE[0]
+
+
 def world():
     if dist.is_available() and dist.is_initialized() and not _LOCAL_ONLY[0]:
         return dist.get_rank(), dist.get_world_size()
@@ -45,7 +67,7 @@ def shard_indices(n_items, rank=None, world_size=None):
 
 def reduce_histogram(hist):
     """Sum the per-rank int64 class histograms in place (the label pass's only collective)."""
-    if world()[1] > 1:
+    if collective_needed():
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
 
@@ -53,7 +75,7 @@ def reduce_histogram(hist):
 def gather_lists(local_items):
     """Rank-ordered concatenation of per-rank python lists (image / label path lists of update_image_list)."""
     _, w = world()
-    if w == 1:
+    if not collective_needed():
         return list(local_items)
     out = [None] * w
     dist.all_gather_object(out, list(local_items))
@@ -70,14 +92,14 @@ def all_reduce_mean(flat):
     """Average a flat tensor over the ranks in place (sum / world): the train step's only collective, RCCL over xGMI on
     GPUs.  Equals the reference's mean of per-replica mean losses (utilities/train_eval_seg.py:202) for equal shards."""
     _, w = world()
-    if w > 1:
+    if collective_needed():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(w)
     return flat
 
 
 def barrier():
-    if world()[1] > 1:
+    if collective_needed():
         dist.barrier()
 
 

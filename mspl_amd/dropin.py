@@ -89,8 +89,11 @@ def _alias(name, **attrs):
     return mod
 
 
-def install_dropin(force=False):
-    """Register the alias modules.  Refuses to shadow already-imported reference modules unless force=True."""
+def install_dropin(force=False, script=None):
+    """Register the alias modules.  Refuses to shadow already-imported reference modules unless force=True.
+    script: the globals() (or module object) of uest_seg_multi_os.py -- the functions the script defines itself (get_output,
+    merge_outputs, update_image_list, generate_pseudo_label, generate_pseudo_label_multi_model) are rebound there too
+    (mspl_amd.script.patch_script; call after the script's own definitions)."""
     from . import layers as L, models as M, uest as U
     names = ['nn_layers', 'model', 'loss_fns']
     if not force:
@@ -131,3 +134,6 @@ def install_dropin(force=False):
     _alias('loss_fns.segmentation_loss', PixelwiseKLD=S.PixelwiseKLD,
            UncertaintyWeightedSegmentationLoss=S.UncertaintyWeightedSegmentationLoss,
            SegmentationLoss=S.SegmentationLoss, NIDLoss=S.NIDLoss)
+    if script is not None:
+        from .script import patch_script
+        patch_script(script)

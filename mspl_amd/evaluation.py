@@ -58,7 +58,7 @@ class EvalSums(object):
         of the reference loop (union per batch = pred + mask - inter + 1e-6, so the 1e-6 counts once per batch).  With
         torch.distributed initialised and reduce=True the sums of all ranks are added first (one all-reduce)."""
         s = self.sums()
-        if reduce and mdist.world()[1] > 1:
+        if reduce and mdist.collective_needed():
             torch.distributed.all_reduce(s, op=torch.distributed.ReduceOp.SUM)
         s = s.cpu().numpy()
         K = self.K

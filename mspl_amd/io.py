@@ -258,7 +258,10 @@ class LabelWriter(object):
         bufs = [self._staging(tuple(shape)) for _ in range(max(0, n))]
         self._free.setdefault(tuple(shape), []).extend(bufs)
 
-    def submit(self, names, labels):
+    def submit(self, names, labels, stream=None):
+        """stream: issue the device -> host copy on THIS stream, straight from `labels` (no snapshot, no side stream).  For callers
+        whose `labels` is only ever overwritten by work queued later on that same stream (a PipelinedLabelPass lane's static output
+        and the lane's stream): stream order then protects the copy, and the copy needs no hardware queue of its own."""
         if labels.dtype != torch.uint8 or labels.dim() != 3 or labels.shape[0] != len(names):
             raise RuntimeError('mspl_amd: LabelWriter.submit expects (N,H,W) uint8 labels and N names, got %s %s / %d names'
                                % (labels.dtype, tuple(labels.shape), len(names)))
@@ -266,7 +269,13 @@ class LabelWriter(object):
             raise RuntimeError('mspl_amd: LabelWriter is closed')
         paths = [self.label_path(n) for n in names]
         event, staged = None, None
-        if labels.is_cuda:
+        if labels.is_cuda and stream is not None:
+            host = staged = self._staging(tuple(labels.shape))
+            with torch.cuda.stream(stream):
+                host.copy_(labels, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(stream)
+        elif labels.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=labels.device)
             host = staged = self._staging(tuple(labels.shape))

@@ -425,7 +425,7 @@ class PipelinedLabelPass:
         def part(t, j):
             return t[j * B:(j + 1) * B] if (torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == count * B) else t
         for j in range(count):
-            self._pending.append((tuple(part(t, j) for t in out) if isinstance(out, (tuple, list)) else part(out, j), ev))
+            self._pending.append((tuple(part(t, j) for t in out) if isinstance(out, (tuple, list)) else part(out, j), ev, i))
 
     def submit(self, images):
         self._n += 1
@@ -437,7 +437,7 @@ class PipelinedLabelPass:
             out, ev = self._launch(i, images)
             if torch.is_tensor(images) and images.is_cuda:
                 images.record_stream(self.streams[i])
-            self._pending.append((out, ev))
+            self._pending.append((out, ev, i))
             return
         bshape = tuple(images.shape)
         if self._staged is not None and self._staged[2] != bshape:
@@ -459,29 +459,116 @@ class PipelinedLabelPass:
         if self._staged[1] == self.group:
             self._launch_staged()
 
-    def pop(self):
+    @property
+    def next_stream(self):
+        """Stream of the lane the next submitted batch goes to.  Work issued on it BEFORE the submit (the upload and the loader
+        transform of that batch, written into static_inputs()[next_lane]) is ordered behind the lane's previous launch and ahead of
+        the next one without an event, and uses no hardware queue beyond the lanes' own."""
+        if self._staged is not None:
+            return self.streams[self._staged[0]]
+        return self.streams[self._lane_no % self.depth]
+
+    def pop(self, on_lane=False):
+        """Oldest batch's outputs.  on_lane=False: the current stream waits for them.  on_lane=True: returns (outputs, lane stream)
+        and waits for nothing -- the consumer queues its work on that stream (LabelWriter.submit(..., stream=)): it then runs right
+        behind the launch that produced the outputs and ahead of the lane's next launch, which is what overwrites them."""
         if not self._pending and self._staged is not None:
             self._launch_staged()
-        out, ev = self._pending.pop(0)
+        out, ev, i = self._pending.pop(0)
+        if on_lane:
+            return out, self.streams[i]
         torch.cuda.current_stream(self.device).wait_event(ev)
         return out
 
-    def __call__(self, images):
+    def __call__(self, images, on_lane=False):
         self.submit(images)
         waiting = len(self._pending) + (self._staged[1] if self._staged is not None else 0)
-        return self.pop() if waiting >= self.depth * self.group else None
+        return self.pop(on_lane) if waiting >= self.depth * self.group else None
 
-    def flush(self):
+    def flush(self, on_lane=False):
         if self._staged is not None:
             self._launch_staged()
         while self._pending:
-            yield self.pop()
+            yield self.pop(on_lane)
+
+
+def _label_loop(p, testloader, save_path, labels_of, class_weighting, use_depth, device, writer_workers, pre_sharded, transform,
+                eager_input):
+    """Loop + files + list + class weights shared by the two label functions (uest_seg_multi_os.py:783-828 and :889-954 are the same
+    code around different loop bodies).  `p`: PipelinedLabelPass interface; labels_of(result) -> the (N,H,W) uint8 maps of one batch.
+    transform(image, out=slot) -> network input: the loader may then yield decoded uint8 frames (N,Hs,Ws,3), host or device, and the
+    transform (mspl_amd.io.Preprocessor) writes the network input straight into the static input slot of the lane that labels it."""
+    import os.path as osp
+    from . import dist as mdist
+    from .io import LabelWriter, default_writer_workers, update_image_list
+    rank, world = mdist.world()
+    p.reset()
+    tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
+    if writer_workers is None:
+        writer_workers = default_writer_workers(world)
+    writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)
+    names, batch_sizes = [], []
+    slots = {}
+    # A real PipelinedLabelPass: everything around a batch runs on the stream of the lane that labels it -- upload + transform ahead of
+    # the launch, the device -> host copy of the maps behind it.  No extra stream means no extra hardware queue: HIP has four, the three
+    # lanes use three, and a loader stream or a writer stream that lands on a lane's queue waits behind that lane's whole launch.
+    on_lane = isinstance(p, PipelinedLabelPass)
+
+    def consume(r):
+        if on_lane:
+            writer.submit(names.pop(0), labels_of(r[0]), stream=r[1])
+        else:
+            writer.submit(names.pop(0), labels_of(r))
+    for b, batch in enumerate(testloader):
+        if world > 1 and not pre_sharded and b % world != rank:
+            continue
+        image = batch[0]
+        names.append(list(batch[-2]))
+        batch_sizes.append(len(names[-1]))
+        if transform is not None:
+            slot = None
+            if hasattr(p, 'static_inputs'):
+                W, H = transform.size
+                shape = (image.shape[0], 3, H, W)
+                xs = slots.get(shape)
+                if not xs or any(x is None for x in xs):            # a lane has no graph (hence no slot) before its first launch
+                    xs = slots[shape] = p.static_inputs(shape)
+                slot = xs[p.next_lane] if xs else None
+            if on_lane:
+                with torch.cuda.stream(p.next_stream):
+                    image = transform(image, out=slot)
+            else:
+                image = transform(image, out=slot)
+            image = image[0] if isinstance(image, tuple) else image
+        elif not (image.is_cuda or eager_input):
+            image = image.to(device, non_blocking=True)
+        out = p(image, on_lane=True) if on_lane else p(image)
+        if out is not None:
+            consume(out)
+    for out in (p.flush(on_lane=True) if on_lane else p.flush()):
+        consume(out)
+    lists = writer.close()
+    hist = p.hist
+    if mdist.collective_needed():
+        # per-batch records in this rank's order -> loader order (batch b came from rank b % world), then flattened
+        recs, at = [], 0
+        for n in batch_sizes:
+            recs.append(tuple(l[at:at + n] for l in lists))
+            at += n
+        merged_recs = mdist.gather_lists(recs)
+        lists = tuple([x for r in merged_recs for x in r[k]] for k in range(len(lists)))
+        hist = mdist.reduce_histogram(hist.clone())
+    if rank == 0:
+        update_image_list(tgt_train_lst, *lists)
+    mdist.barrier()                                     # the list file exists before any rank builds its train loader from it
+    weights = torch.from_numpy(class_weights_from_histogram(hist.cpu().numpy(), class_weighting)).float().to(hist.device)
+    return tgt_train_lst, weights
 
 
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
                                       use_graph=True, writer_workers=None, in_flight=3, pre_sharded=False, _label_pass=None,
-                                      batches_per_launch=1):
+                                      batches_per_launch=1, transform=None):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
 
@@ -497,48 +584,31 @@ def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save
     weights.  pre_sharded=True: the caller's loader already yields this rank's batches only (e.g. a sampler over
     dist.shard_indices) -- use it when skipping a foreign batch is not free (the loader decodes it first).
     `_label_pass`: an object with PipelinedLabelPass's interface, for host-logic tests.  batches_per_launch: PipelinedLabelPass's
-    `group` (consecutive loader batches labelled by one launch; worth ~5 % at batch 16)."""
-    import os.path as osp
-    from . import dist as mdist
-    from .io import LabelWriter, update_image_list
-    rank, world = mdist.world()
+    `group` (consecutive loader batches labelled by one launch; worth ~5 % at batch 16).  transform: see _label_loop."""
     p = _label_pass if _label_pass is not None else PipelinedLabelPass(
         lambda: PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy,
                                 device=device, use_graph=use_graph), depth=in_flight, device=device, group=batches_per_launch)
-    p.reset()
-    tgt_train_lst = osp.join(save_path, 'tgt_train.lst')
-    if writer_workers is None:
-        from .io import default_writer_workers
-        writer_workers = default_writer_workers(world)
-    writer = LabelWriter(osp.join(save_path, 'pred'), workers=writer_workers, use_depth=use_depth)
-    names, batch_sizes = [], []
-    for b, batch in enumerate(testloader):
-        if world > 1 and not pre_sharded and b % world != rank:
-            continue
-        image = batch[0]
-        names.append(list(batch[-2]))
-        batch_sizes.append(len(names[-1]))
-        merged = p(image if (image.is_cuda or _label_pass is not None) else image.to(device, non_blocking=True))
-        if merged is not None:
-            writer.submit(names.pop(0), merged)
-    for merged in p.flush():
-        writer.submit(names.pop(0), merged)
-    lists = writer.close()
-    hist = p.hist
-    if world > 1:
-        # per-batch records in this rank's order -> loader order (batch b came from rank b % world), then flattened
-        recs, at = [], 0
-        for n in batch_sizes:
-            recs.append(tuple(l[at:at + n] for l in lists))
-            at += n
-        merged_recs = mdist.gather_lists(recs)
-        lists = tuple([x for r in merged_recs for x in r[k]] for k in range(len(lists)))
-        hist = mdist.reduce_histogram(hist.clone())
-    if rank == 0:
-        update_image_list(tgt_train_lst, *lists)
-    mdist.barrier()                                     # the list file exists before any rank builds its train loader from it
-    weights = torch.from_numpy(class_weights_from_histogram(hist.cpu().numpy(), class_weighting)).float().to(hist.device)
-    return tgt_train_lst, weights
+    return _label_loop(p, testloader, save_path, lambda out: out, class_weighting, use_depth, device, writer_workers, pre_sharded,
+                       transform, _label_pass is not None)
+
+
+def generate_pseudo_label(model, testloader, save_path, classes=GREENHOUSE_CLASSES, class_weighting='normal', use_depth=False,
+                          device='cuda', use_graph=True, writer_workers=None, in_flight=3, batches_per_launch=2, pre_sharded=False,
+                          _label_pass=None, transform=None):
+    """uest_seg_multi_os.py:730-830 end to end, the single-model relabelling of every self-training round (called at :527-528):
+    loader -> get_output (`softmax(pred + 0.5 aux)`, :795) -> argmax (:798) -> `class_array` (:800-801) -> `<save_path>/pred/<image_name>.png`
+    (:803-811) -> path lists (:813-816) -> update_image_list (:820) -> class weights (:822-828); returns (tgt_train_lst, class_weights).
+
+    The loop body is SelfLabelPass (forward + fused epilogue: up-sampling of both heads, argmax of pred + 0.5 aux -- softmax is
+    monotone, the probabilities are never written -- and the class histogram), `in_flight` launches of `batches_per_launch` loader
+    batches each overlap on the GPU, the PNG files are written by LabelWriter's native threads.  Loader tuples, rank sharding,
+    `pre_sharded`, `_label_pass` and `transform` as in generate_pseudo_label_multi_model.  The reference's loader is batch size 1
+    (:746); BatchNorm is in eval mode, so any batch size gives the same maps."""
+    p = _label_pass if _label_pass is not None else PipelinedLabelPass(
+        lambda: SelfLabelPass(model, classes=classes, device=device, use_graph=use_graph, with_kld=False),
+        depth=in_flight, device=device, group=batches_per_launch)
+    return _label_loop(p, testloader, save_path, lambda out: out[0] if isinstance(out, (tuple, list)) else out, class_weighting,
+                       use_depth, device, writer_workers, pre_sharded, transform, _label_pass is not None)
 
 
 class SelfLabelPass(_GraphedPassMixin):

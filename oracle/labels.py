@@ -80,6 +80,32 @@ def class_weights_from_histogram(class_array, policy='normal'):
     return np.ones(len(class_array))
 
 
+def generate_pseudo_label(forward, loader, classes, save_pred_path, class_weighting='normal', use_depth=False):
+    """uest_seg_multi_os.py:783-828, the single-model relabelling loop, image by image like the reference (its loader is batch size
+    1, :746; a larger batch is walked element by element here): get_output -> argmax (:798) -> class_array (:800-801) -> path lists
+    (:803-816) -> class weights (:822-828).  forward(image (1,3,H,W)) -> (pred, pred_aux) logits at full resolution.  Returns
+    (image_path_list, label_path_list, depth_path_list, [uint8 (H,W) maps], class_weights float64) -- the PNG files the reference
+    writes at :811 hold exactly those maps."""
+    image_paths, label_paths, depth_paths, maps = [], [], [], []
+    class_array = np.zeros(classes)
+    for batch in loader:
+        image, names = batch[0], batch[-2]
+        for k in range(image.shape[0]):
+            main, aux = forward(image[k:k + 1])
+            prob, _ = get_output(main, aux)
+            amax = np.asarray(np.argmax(prob[0].numpy().transpose(1, 2, 0), axis=2), dtype=np.uint8)      # [0]: :688
+            for i in range(classes):
+                class_array[i] += (amax == i).sum()
+            path_name = names[k]
+            image_name = path_name.split('/')[-1].rsplit('.', 1)[0]
+            maps.append(amax)
+            image_paths.append(path_name)
+            label_paths.append('%s/%s.png' % (save_pred_path, image_name))
+            if use_depth:
+                depth_paths.append(path_name.replace('color', 'depth'))
+    return image_paths, label_paths, depth_paths, maps, class_weights_from_histogram(class_array, class_weighting)
+
+
 def uw_seg_loss(pred, target, u_weight, class_weights, ignore_idx=None):
     """UncertaintyWeightedSegmentationLoss.forward, loss_fns/segmentation_loss.py:155-175.
 

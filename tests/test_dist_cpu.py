@@ -121,6 +121,38 @@ def _check_sharded_label_function(rank, world, tmp):
             assert np.array_equal(arr, all_labels[bi][j].numpy())
 
 
+def _check_sharded_self_label_function(rank, world, tmp):
+    """generate_pseudo_label (uest_seg_multi_os.py:730-830) under world 2 with a stub pass that returns SelfLabelPass's (labels, kld)
+    pairs and depth paths in the list: rank r labels batches b == r (mod world); list lines in loader order with the third column
+    (:815-816), one histogram all-reduce, both ranks return the oracle loop's class weights."""
+    import numpy as np
+    from mspl_amd import io as mio, uest
+    from oracle import imageio as oio, labels as olab
+    g = torch.Generator().manual_seed(12)
+    sizes = [1, 3, 2, 2, 1, 2, 1]
+    batches, k = [], 0
+    for n in sizes:
+        names = ['/data/color/im_%03d.png' % (k + i) for i in range(n)]
+        batches.append((torch.randn(n, 5, 8, 12, generator=g), None, None, names, None))
+        k += n
+
+    class Stub(_StubPipelinedPass):
+        def _label(self, images):
+            lab = images.argmax(1).to(torch.uint8)        # the batch IS the logits: forward = identity for both heads
+            self.hist += torch.bincount(lab.flatten().to(torch.int64), minlength=5)
+            return lab, torch.zeros(lab.shape)
+    save = tmp + '/self'
+    lst, w = uest.generate_pseudo_label(None, iter(batches), save, use_depth=True, writer_workers=2, _label_pass=Stub())
+    ri, rl, rd, rmaps, rw = olab.generate_pseudo_label(lambda x: (x, torch.zeros_like(x)), batches, 5, save + '/pred', 'normal', True)
+    assert np.allclose(w.numpy(), rw.astype(np.float32), rtol=1e-6), (w, rw)
+    assert mio.read_image_list(lst, use_depth=True, check_files=False) == (ri, rl, rd)
+    assert rd[0] == '/data/depth/im_000.png'
+    at = np.cumsum([0] + sizes)
+    for bi in [i for i in range(len(batches)) if i % world == rank]:
+        for j in range(sizes[bi]):
+            assert np.array_equal(oio.png_decode_gray8(open(rl[at[bi] + j], 'rb').read()), rmaps[at[bi] + j])
+
+
 def _check_sharded_eval(rank, world):
     """evaluation.val_seg_ue under world 2 with a CPU stand-in for the device pass: rank r evaluates batches b == r (mod world), ONE
     all-reduce of the sums, every rank returns what the reference loop gives on the whole loader (oracle.labels.val_seg_ue)."""
@@ -214,6 +246,7 @@ def _worker(rank, world, port, q, tmp):
         assert w1.grad.data_ptr() == b.flat.data_ptr()      # grads are views of the flat bucket
         _check_flat_optimizers(rank, world)
         _check_sharded_label_function(rank, world, tmp)
+        _check_sharded_self_label_function(rank, world, tmp)
         _check_sharded_eval(rank, world)
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001

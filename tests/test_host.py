@@ -223,6 +223,25 @@ def test_dropin_overlays_real_modules(tmp_path, monkeypatch):
             monkeypatch.delattr(builtins, '_mspl_fake_greenhouse_runs')
 
 
+def test_patch_script_binds_the_script_level_functions():
+    """The five functions uest_seg_multi_os.py defines itself (:669-956) are rebound in the script's namespace; the adapters keep
+    the reference's positional signatures (:730-731, :832-833)."""
+    import inspect
+    from mspl_amd import io as mio, script
+    ns = {'main': 1}
+    assert script.patch_script(ns) == ['generate_pseudo_label', 'generate_pseudo_label_multi_model', 'get_output', 'merge_outputs',
+                                       'update_image_list']
+    assert ns['main'] == 1 and ns['get_output'] is uest.get_output and ns['update_image_list'] is mio.update_image_list
+    ref_tail = ['device', 'save_path', 'round_idx', 'tgt_num', 'label_2_id', 'valid_labels', 'args', 'logger', 'class_encoding', 'writer']
+    assert list(inspect.signature(ns['generate_pseudo_label']).parameters)[:11] == ['model'] + ref_tail
+    assert list(inspect.signature(ns['generate_pseudo_label_multi_model']).parameters)[:12] == ['model_list', 'os_data_list'] + ref_tail
+    import argparse
+    with pytest.raises(RuntimeError, match='eval-training'):
+        ns['generate_pseudo_label'](None, 'cuda', '/nonexistent', 0, args=argparse.Namespace(eval_training=True, classes=5))
+    with pytest.raises(RuntimeError, match='greenhouse'):
+        ns['generate_pseudo_label'](None, 'cuda', '/nonexistent', 0, args=argparse.Namespace(eval_training=False, classes=5, dataset='camvid'))
+
+
 def test_espdnetue_seg_loader(tmp_path):
     """espdnet_ue.py:384-452: the older factory (pyr_plane_proj = min(classes//2, 16); whole-file load without a shape filter)."""
     a = argparse.Namespace(s=2.0, channels=3, num_classes=1000, classes=5, dataset='greenhouse', dense_fuse=False,

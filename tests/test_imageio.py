@@ -248,3 +248,141 @@ def test_generate_pseudo_label_batches_per_launch(tmp_path):
     assert outs[0][0] == outs[1][0] and len(outs[0][2]) == sum(sizes)
     assert np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+def _self_label_case(a_seed=71, C=5):
+    import argparse
+    from mspl_amd import models
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=C, dataset='greenhouse', fix_pyr_plane_proj=True)
+    sd = synth_state_dict(m.state_dict(), a_seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def _check_against_oracle_loop(sd, frames, names, size, lst, cw, save, use_depth, classes=5):
+    """Files, list and weights of a generate_pseudo_label run against the oracle's statement of uest_seg_multi_os.py:783-828."""
+    from mspl_amd.io import read_image_list
+    from oracle import labels as olab
+    from oracle import net as onet
+
+    def fwd(x):
+        with torch.no_grad():
+            return onet.espdnet_ue_forward(sd, x)
+    ref_loader = [(torch.stack([torch.from_numpy(oio.val_transform(f, size=size)[0]) for f in fb]), None, n, 0.0)
+                  for fb, n in zip(frames, names)]
+    ri, rl, rd, rmaps, rw = olab.generate_pseudo_label(fwd, ref_loader, classes, '%s/pred' % save, 'normal', use_depth)
+    images, labels, depths = read_image_list(lst, use_depth=use_depth, check_files=False)
+    assert images == ri and labels == rl and depths == rd          # same lines, same order as the reference's list file
+    hist = np.zeros(classes)
+    for path, want in zip(labels, rmaps):
+        got = oio.png_decode_gray8(open(path, 'rb').read())
+        assert got.shape == want.shape and (got != want).mean() < 2e-3      # fp32 near-ties between two forwards; the rest equal
+        hist += np.bincount(got.ravel(), minlength=classes)[:classes]
+    # the integer / float64 stage is exact given the maps that were written
+    assert np.allclose(cw.cpu().numpy(), olab.class_weights_from_histogram(hist).astype(np.float32), rtol=1e-6)
+    assert np.allclose(cw.cpu().numpy()[1:], rw.astype(np.float32)[1:], rtol=2e-2) and float(cw[0]) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('use_graph,use_depth', [(False, False), (True, True)])
+def test_generate_pseudo_label_end_to_end(tmp_path, use_graph, use_depth):
+    """The single-model relabelling function (uest_seg_multi_os.py:730-830) end to end: PNG bytes, list lines and order, class
+    weights against the oracle's statement of :783-828; ragged loader (the lanes wrap and the last launch is partly filled)."""
+    from mspl_amd import uest
+    from mspl_amd.io import Preprocessor
+    m, sd = _self_label_case()
+    pre = Preprocessor(size=(64, 48))
+    sizes = [2, 2, 2, 2, 2, 2, 1]
+    frames = [np.stack([synth_image_u8(72, 96, 170 + 4 * b + i)[0] for i in range(n)]) for b, n in enumerate(sizes)]
+    names = [['/d/color/s_%d_%d.jpg' % (b, i) for i in range(n)] for b, n in enumerate(sizes)]
+    tup = (lambda x, n: (x, None, None, n, 0.0)) if use_depth else (lambda x, n: (x, None, n, 0.0))
+    loader = [tup(pre(torch.from_numpy(f))[0], n) for f, n in zip(frames, names)]
+    lst, cw = uest.generate_pseudo_label(m, loader, str(tmp_path), use_graph=use_graph, use_depth=use_depth)
+    assert lst == os.path.join(str(tmp_path), 'tgt_train.lst') and cw.is_cuda and cw.dtype == torch.float32
+    _check_against_oracle_loop(sd, frames, names, (64, 48), lst, cw, str(tmp_path), use_depth)
+    if use_depth:
+        assert open(lst).readline().rstrip().split(',')[2] == '/d/depth/s_0_0.jpg'
+
+
+@pytest.mark.gpu
+def test_generate_pseudo_label_transform_into_lane_slots(tmp_path):
+    """Loader of decoded uint8 frames + transform=Preprocessor: the network input is written straight into the static input slot of
+    the lane that labels it.  Same files as the tensor loader, and after the lanes' first launches no batch is copied."""
+    from mspl_amd import uest
+    from mspl_amd.io import Preprocessor
+    m, sd = _self_label_case(72)
+    pre = Preprocessor(size=(64, 48))
+    frames = [np.stack([synth_image_u8(72, 96, 270 + 4 * b + i)[0] for i in range(2)]) for b in range(13)]
+    names = [['/d/color/t_%d_%d.jpg' % (b, i) for i in range(2)] for b in range(13)]
+    outs = []
+    for k, kw in enumerate([dict(), dict(transform=pre)]):
+        d = tmp_path / ('v%d' % k)
+        d.mkdir()
+        if k == 0:
+            loader = [(pre(torch.from_numpy(f))[0], None, n, 0.0) for f, n in zip(frames, names)]
+        else:
+            loader = [(torch.from_numpy(f), None, n, 0.0) for f, n in zip(frames, names)]
+        lst, cw = uest.generate_pseudo_label(m, loader, str(d), in_flight=2, batches_per_launch=2, **kw)
+        files = sorted(os.listdir(str(d / 'pred')))
+        outs.append((open(lst).read().replace(str(d), ''), cw.cpu().numpy(), {f: open(str(d / 'pred' / f), 'rb').read() for f in files}))
+    assert outs[0][0] == outs[1][0] and len(outs[0][2]) == 26
+    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    _check_against_oracle_loop(sd, frames, names, (64, 48), str(tmp_path / 'v1' / 'tgt_train.lst'),
+                               torch.from_numpy(outs[1][1]), str(tmp_path / 'v1'), False)
+
+
+@pytest.mark.gpu
+def test_script_level_generate_pseudo_label_reference_signature(tmp_path, monkeypatch):
+    """patch_script(): the script's own call `generate_pseudo_label(model, device, save_path, round_idx, tgt_num, label_2_id,
+    valid_labels, args, logger, class_encoding, writer)` (uest_seg_multi_os.py:527) with a loader built from args through the
+    reference's dataset class (a stand-in package on sys.path plays data_loader.segmentation.greenhouse)."""
+    import argparse
+    import sys
+    import mspl_amd
+    from mspl_amd import script
+    from tests.test_host import _purge_reference_names
+    m, sd = _self_label_case(73)
+    frames = [synth_image_u8(48, 64, 370 + i)[0] for i in range(5)]
+    np.save(str(tmp_path / 'frames.npy'), np.stack(frames))
+    (tmp_path / 'data_loader' / 'segmentation').mkdir(parents=True)
+    (tmp_path / 'data_loader' / '__init__.py').write_text('')
+    (tmp_path / 'data_loader' / 'segmentation' / '__init__.py').write_text('')
+    (tmp_path / 'data_loader' / 'segmentation' / 'greenhouse.py').write_text(
+        'import numpy as np, torch\n'
+        'from oracle import imageio as oio\n'
+        'class GreenhouseRGBDSegmentation(torch.utils.data.Dataset):\n'
+        '    def __init__(self, list_name, train=True, use_traversable=False, use_depth=False):\n'
+        '        assert train is False and use_depth is False\n'
+        '        self.frames = np.load(list_name)\n'
+        '    def __len__(self):\n'
+        '        return len(self.frames)\n'
+        '    def __getitem__(self, i):\n'
+        '        x = torch.from_numpy(oio.val_transform(self.frames[i], size=(64, 48))[0])\n'
+        '        return x, torch.zeros(48, 64, dtype=torch.int64), "/t/color/img_%02d.png" % i, 0.0\n')
+    monkeypatch.syspath_prepend(str(tmp_path))
+    _purge_reference_names()
+    try:
+        ns = {'generate_pseudo_label': None, 'merge_outputs': None}
+        mspl_amd.install_dropin(script=ns)
+        assert ns['generate_pseudo_label'] is script.generate_pseudo_label and ns['merge_outputs'] is mspl_amd.uest.merge_outputs
+        args = argparse.Namespace(classes=5, dataset='greenhouse', data_tgt_train_list=str(tmp_path / 'frames.npy'),
+                                  use_traversable=False, use_depth=False, pin_memory=False, class_weighting='normal',
+                                  eval_training=False, label_batch_size=2)
+        logged = []
+
+        class Log:
+            def info(self, s):
+                logged.append(s)
+        save = str(tmp_path / 'run')
+        lst, cw = ns['generate_pseudo_label'](m, 'cuda', save, 3, 5, None, None, args, Log(), None, None)
+        assert 'round 3' in logged[0]
+        names = [['/t/color/img_%02d.png' % i for i in range(b, min(b + 2, 5))] for b in range(0, 5, 2)]
+        fb = [np.stack(frames[b:b + 2]) for b in range(0, 5, 2)]
+        _check_against_oracle_loop(sd, fb, names, (64, 48), lst, cw, save, False)
+        args.eval_training = True
+        with pytest.raises(RuntimeError, match='eval-training'):
+            ns['generate_pseudo_label'](m, 'cuda', save, 3, 5, None, None, args, Log(), None, None)
+    finally:
+        _purge_reference_names()
