@@ -123,6 +123,24 @@ int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* psca
                               const float* w, const int32_t dil[4], int32_t N, int32_t Cin, int32_t n, int32_t groups,
                               int32_t H, int32_t W, const mspl_epilogue_t* ep, float* out, void* stream);
 
+/* K2 + K3 in one launch for stride-1 EESP blocks (nn_layers/eesp.py:68-93: the four dilated depthwise 3x3 of the reduced tensor +
+ * HFF + cat + br_after_cat, then conv_1x1_exp (grouped 1x1, 4 groups) + BatchNorm + residual link + module_act).  The 4n-channel
+ * concatenation never exists in memory: a workgroup computes the branch values of a band of rows chunk by chunk of reduced channels
+ * into LDS and feeds them to the matrix cores as the B operand of the expansion.  Results are bit-identical to
+ * mspl_eesp_dw_hff_fwd followed by mspl_conv1x1_fwd.
+ *   r (N,n,H,W): proj_1x1's output.  packed: mspl_eesp_dw_exp_pack_floats(n) floats written by mspl_eesp_dw_exp_pack from
+ *   w4 (4,n,3,3), br_after_cat's folded scale/shift and PReLU slope (4n each) and conv_1x1_exp's weight (4n, n) -- the caller
+ *   caches it per weight version.  ep: scale/shift (conv_1x1_exp's folded BN), alpha (module_act) and residual (the block's
+ *   input, (N,4n,H,W)) are all required; nothing else may be set.  out (N,4n,H,W).
+ * Covered (mspl_eesp_dw_exp_fits returns 1): (n, W, dil) = (128, 30, {1,1,2,3}) or (64, 60, {1,2,3,4}), any H; callers run the
+ * two-launch form otherwise (_fwd / _pack return MSPL_ERR_UNSUPPORTED). */
+int mspl_eesp_dw_exp_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t dil[4], uint32_t launch_flags);
+int64_t mspl_eesp_dw_exp_pack_floats(int32_t n);
+int mspl_eesp_dw_exp_pack(const float* w4, const float* bscale, const float* bshift, const float* balpha, const float* wexp,
+                          int32_t n, int32_t H, int32_t W, const int32_t dil[4], float* packed, void* stream);
+int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H, int32_t W,
+                         const mspl_epilogue_t* ep, float* out, void* stream);
+
 /* AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) + epilogue.
  *     Replaces nn_layers/eesp.py:115,128 and the image pyramid of :136-140.
  */

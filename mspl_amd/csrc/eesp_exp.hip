@@ -1,0 +1,491 @@
+// K2 + K3 in one launch for the stride-1 EESP blocks (levels 3 / 4 of the encoder).
+//
+// Reference arithmetic: nn_layers/eesp.py:68-93 -- four CDilated depthwise 3x3 convolutions of the reduced tensor with the
+// hierarchical sum out_k = conv_k + out_{k-1}, torch.cat, br_after_cat (BatchNorm + PReLU), conv_1x1_exp (grouped 1x1, 4
+// groups: group g reads exactly branch g of all n reduced channels) + BatchNorm, + input (residual link), module_act (PReLU).
+//
+// Why fused: the concatenation (4n channels) is written by K2 and read back by K3 and both launches are single rounds of
+// workgroups bounded by latency (K2 12-13 us, K3 20-28 us for 7 us of matrix work at 18x30 x 512 channels x 16 images).  Here
+// the branch values never leave the CU: a workgroup owns a band of TH rows of one image (TH * W <= 64 pixels) and GPW of the four
+// groups, walks the reduced channels in chunks of KC and per chunk
+//   (L) moves the chunk's rows (+- MAXD halo rows, zero outside the image) global -> registers -> zero-haloed LDS rows, two chunks
+//       ahead of the matrix stage,
+//   (D) computes the depthwise branches for the NEXT chunk on the vector unit: a wave takes one channel at a time, lane = pixel,
+//       taps are ds_read_b32 with immediate offsets, the 36 weights + 12 BN/PReLU constants of the channel sit in scalar
+//       registers (one packed 192-byte record per channel, s_load), same operation order as eesp_dw.hip (bit-identical values),
+//       and writes them as the B operand of the matrix stage, [group][k][pixel] in LDS,
+//   (M) multiplies the CURRENT chunk on the matrix cores: wave = (group, 32 output rows) x 64 pixels, v_mfma_f32_32x32x2_f32 with
+//       k ascending exactly like conv1x1_pipe_kernel (bit-identical sums); the A operand (expansion weights) streams from a
+//       pre-packed copy in global memory, one chunk ahead, two 16-byte loads per lane and chunk (no weight staging, no barrier
+//       for it),
+// with ONE barrier per chunk; the vector work of (D) runs in the shadow of the other waves' MFMAs.  Epilogue as in K3: folded BN,
+// + residual, PReLU, 8-byte stores.
+// Algorithmic bytes: read r (n HW) + residual (4n HW), write 4n HW: 4 * 9n * HW per image (the unfused pair: 4 * 17n * HW).
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "common.hpp"
+
+namespace mspl {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int D0, int D1, int D2, int D3>
+struct XDil {
+    static constexpr int d(int k) { return k == 0 ? D0 : k == 1 ? D1 : k == 2 ? D2 : D3; }
+    static constexpr int maxd() { return D3 > D2 ? (D3 > D1 ? (D3 > D0 ? D3 : D0) : (D1 > D0 ? D1 : D0))
+                                                 : (D2 > D1 ? (D2 > D0 ? D2 : D0) : (D1 > D0 ? D1 : D0)); }
+};
+
+__device__ __forceinline__ int xe_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+constexpr int XE_REC = 48;      // floats per packed channel record: per branch k: w[9], scale, shift, alpha
+
+// ------------------------------------------------------------------ packing (once per weight version; cached by the caller)
+// dwp[c][k][12]: branch k's 3x3 weights of reduced channel c, then br_after_cat's folded scale / shift / PReLU slope of the
+// concatenated channel k*n + c.  ap: the expansion weights in the lane order of the A operand, chunked by KC:
+// ap[(((g*RTPG + rt)*NCHUNK + ch)*64 + lane)*(KC/2) + i] = w[g*n + rt*32 + (lane & 31)][ch*KC + 2*i + (lane >> 5)].
+__global__ void eesp_exp_pack_kernel(const float* __restrict__ w4, const float* __restrict__ bscale, const float* __restrict__ bshift,
+                                     const float* __restrict__ balpha, const float* __restrict__ wexp, int n, int KC,
+                                     float* __restrict__ dwp, float* __restrict__ ap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * XE_REC) {
+        const int c = i / XE_REC, f = i - c * XE_REC;
+        const int k = f / 12, e = f - k * 12;
+        float v;
+        if (e < 9) v = w4[((size_t)k * n + c) * 9 + e];
+        else if (e == 9) v = bscale[k * n + c];
+        else if (e == 10) v = bshift[k * n + c];
+        else v = balpha[k * n + c];
+        dwp[i] = v;
+    }
+    const int total = 4 * n * n;
+    if (i < total) {
+        const int half_kc = KC / 2, nchunk = n / KC, rtpg = n / 32;
+        int t = i;
+        const int ii = t % half_kc;  t /= half_kc;
+        const int lane = t % 64;     t /= 64;
+        const int ch = t % nchunk;   t /= nchunk;
+        const int rt = t % rtpg;
+        const int g = t / rtpg;
+        const int row = g * n + rt * 32 + (lane & 31);
+        const int k = ch * KC + 2 * ii + (lane >> 5);
+        ap[i] = wexp[(size_t)row * n + k];
+    }
+}
+
+// ------------------------------------------------------------------ the fused kernel
+// Measured on the way (in-kernel s_memrealtime timelines, tools/xe_stamp.sh): a split into four matrix waves + four depthwise
+// waves per workgroup (one of each per SIMD) does NOT overlap the two kinds of work -- the depthwise waves' step got 1.2 us
+// longer exactly while the matrix waves' 1.1 us of v_mfma_f32_32x32x2_f32 ran: the fp32 MFMA runs at the vector rate and holds
+// the SIMD's vector issue.  So every wave does both, and a step costs (vector work) + (matrix work) per SIMD.
+template <int NCH, int W, int TH, int KC, int GPW, class DS, int VAR>
+__global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __restrict__ r, const float* __restrict__ dwp,
+                                                             const float* __restrict__ ap, const float* __restrict__ escale,
+                                                             const float* __restrict__ eshift, const float* __restrict__ ealpha,
+                                                             const float* __restrict__ res, float* __restrict__ out,
+                                                             int H, int bands, int nwg, int dbg, unsigned long long* __restrict__ stamps) {
+    constexpr int MAXD = DS::maxd();
+    constexpr int ROWS = TH + 2 * MAXD;
+    constexpr int P = 4;                       // zero columns on either side of a staged row (>= MAXD, even: 8-byte aligned rows)
+    constexpr int RS = W + 2 * P;
+    constexpr int NCHUNK = NCH / KC;
+    constexpr int RTPG = NCH / 32;             // 32-row tiles per group
+    constexpr int NPW = 4 / GPW;               // workgroups per band
+    constexpr int PXV = TH * W;                // pixels of a band
+    constexpr int HW2 = W / 2;
+    constexpr int ITEMS = KC * ROWS * HW2;     // float2 items of a staged chunk
+    constexpr int IPT = (ITEMS + 511) / 512;
+    constexpr int CPW = KC / 8;                // channels per wave and chunk in the depthwise stage
+    constexpr int A4 = KC / 8;                 // float4 of A per lane and chunk
+    constexpr int WREC4 = KC * XE_REC / 4;     // float4 of a chunk's depthwise records
+    static_assert(GPW * RTPG == 8, "eight waves: (group, row tile)");
+    static_assert(PXV <= 64 && (W % 2) == 0 && MAXD <= P, "band geometry");
+    static_assert(KC % 8 == 0 && NCH % KC == 0 && NCHUNK >= 2 && WREC4 <= 512, "chunking");
+
+    __shared__ __attribute__((aligned(16))) float rt_[2][KC * ROWS * RS];
+    __shared__ __attribute__((aligned(16))) float bb_[2][GPW * KC * 64];
+    __shared__ __attribute__((aligned(16))) float wd_[2][KC * XE_REC];   // the chunk's depthwise weights + BN / PReLU constants
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, half = lane >> 5;
+
+#ifdef MSPL_DEBUG_STAMPS
+    unsigned long long st[12];
+    int nst = 0;
+    auto stamp = [&]() { if (stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[nst] = __builtin_amdgcn_s_memrealtime(); } ++nst; };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
+
+    int lid = xe_xcd_remap(blockIdx.x, nwg);
+    const int gs = lid % NPW;  lid /= NPW;
+    const int band = lid % bands;
+    const int img = lid / bands;
+    const int y0 = band * TH;
+    const int HW = H * W;
+    const int g_first = gs * GPW;
+
+    const int gl = wave / RTPG, rtile = wave % RTPG;     // matrix stage: this wave's group (local) and row tile
+    const int g = g_first + gl;
+
+    // ---- staging (L): chunk c of the reduced tensor, rows y0 - MAXD .. y0 + TH - 1 + MAXD of KC channels, and the chunk's
+    // depthwise records.  An item's place in the chunk is the same for every chunk: computed once.
+    const float* rimg = r + (size_t)img * NCH * HW;
+    const int glin0 = (y0 - MAXD) * HW2;                 // float2 index of the first staged row inside a plane (may be negative)
+    constexpr bool PRE = (VAR & 2) != 0;
+    constexpr bool SGW = (VAR & 1) != 0;
+    int soff[PRE ? IPT : 1], doff[PRE ? IPT : 1];        // source offset (floats, inside the chunk) / LDS offset; -1: zero, nothing
+    if (PRE) {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int i = tid + 512 * q;
+            const int ic = i < ITEMS ? i : 0;
+            const int j = ic / (ROWS * HW2);
+            const int rem = ic - j * (ROWS * HW2);
+            const int row = rem / HW2, c2 = rem - row * HW2;
+            const int gl2 = glin0 + rem;
+            const bool ok = gl2 >= 0 && gl2 < H * HW2;
+            soff[q] = ok ? j * HW + 2 * gl2 : -1;
+            doff[q] = i < ITEMS ? (j * ROWS + row) * RS + P + 2 * c2 : -1;
+        }
+    }
+    float2 sv[IPT];
+    float4 wrec;
+    auto load_chunk = [&](int c) {
+        if (dbg & 4) return;
+        const float* rc = rimg + (size_t)c * KC * HW;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            if (PRE) {
+                const float2 v = *reinterpret_cast<const float2*>(rc + (soff[q] < 0 ? 0 : soff[q]));
+                sv[q] = soff[q] < 0 ? make_float2(0.f, 0.f) : v;
+            } else {
+                const int i = tid + 512 * q;
+                const int ic = i < ITEMS ? i : 0;
+                const int j = ic / (ROWS * HW2);
+                const int rem = ic - j * (ROWS * HW2);
+                const int gl2 = glin0 + rem;
+                const bool ok = gl2 >= 0 && gl2 < H * HW2;
+                const int gc = ok ? gl2 : 0;
+                const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + 2 * gc);
+                sv[q] = ok ? v : make_float2(0.f, 0.f);
+            }
+        }
+        if (!SGW) wrec = *reinterpret_cast<const float4*>(dwp + (size_t)c * KC * XE_REC + 4 * (tid < WREC4 ? tid : 0));
+    };
+    auto store_chunk = [&](float* dst, float* wdst) {
+        if (dbg & 4) return;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            if (PRE) {
+                if (doff[q] >= 0) *reinterpret_cast<float2*>(dst + doff[q]) = sv[q];
+            } else {
+                const int i = tid + 512 * q;
+                if (i < ITEMS) {
+                    const int j = i / (ROWS * HW2);
+                    const int rem = i - j * (ROWS * HW2);
+                    const int row = rem / HW2, c2 = rem - row * HW2;
+                    *reinterpret_cast<float2*>(dst + (j * ROWS + row) * RS + P + 2 * c2) = sv[q];
+                }
+            }
+        }
+        if (!SGW && tid < WREC4) *reinterpret_cast<float4*>(wdst + 4 * tid) = wrec;
+    };
+
+    // ---- depthwise stage (D): lane = pixel of the band; a wave takes CPW channels of the chunk, one at a time, two branches at a
+    // time: their 24 constants (broadcast 16-byte LDS reads) and taps are requested together, then evaluated in eesp_dw.hip's order
+    const int pxc = lane < PXV ? lane : PXV - 1;
+    const int ty = (TH > 1) ? pxc / W : 0;
+    const int tx = pxc - ty * W;
+    const int tapbase = (ty + MAXD) * RS + P + tx;
+    const int nbr = g_first + GPW;                                     // uniform: a workgroup needs branches 0 .. its last group
+    auto dw_stage_s = [&](int c, const float* src, float* dst) {       // constants through scalar loads (one 192-byte record per channel)
+        if (dbg & 1) return;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const int j = wave + 8 * u;
+            const float* rec = dwp + (size_t)(c * KC + j) * XE_REC;     // uniform
+            float wv[XE_REC];
+#pragma unroll
+            for (int i = 0; i < XE_REC; ++i) wv[i] = rec[i];
+            const float* tp = src + j * (ROWS * RS) + tapbase;
+            float prev = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= nbr) break;
+                const int d = DS::d(k);
+                float a = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* rowp = tp + (ky - 1) * d * RS;
+                    a = fmaf(wv[k * 12 + ky * 3 + 0], rowp[-d], a);
+                    a = fmaf(wv[k * 12 + ky * 3 + 1], rowp[0], a);
+                    a = fmaf(wv[k * 12 + ky * 3 + 2], rowp[d], a);
+                }
+                a += prev;
+                prev = a;
+                if (k >= g_first) {
+                    float q = fmaf(a, wv[k * 12 + 9], wv[k * 12 + 10]);
+                    q = q > 0.f ? q : wv[k * 12 + 11] * q;
+                    dst[((k - g_first) * KC + j) * 64 + lane] = q;
+                }
+            }
+        }
+    };
+    auto dw_stage = [&](const float* src, const float* wsrc, float* dst) {
+        if (dbg & 1) return;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+            const int j = wave + 8 * u;
+            const float4* wp4 = reinterpret_cast<const float4*>(wsrc + j * XE_REC);
+            const float* tp = src + j * (ROWS * RS) + tapbase;
+            float prev = 0.f, centre = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2) {
+                if (kp < nbr) {
+                    float wv[24];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const float4 t4 = wp4[kp * 3 + i];
+                        wv[4 * i] = t4.x; wv[4 * i + 1] = t4.y; wv[4 * i + 2] = t4.z; wv[4 * i + 3] = t4.w;
+                    }
+                    float tap[2][9];
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int d = DS::d(kp + kk);
+                        if (kk > 0 && DS::d(kp) == d) {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) tap[1][i] = tap[0][i];
+                        } else {
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const float* rowp = tp + (ky - 1) * d * RS;
+                                tap[kk][ky * 3 + 0] = rowp[-d];
+                                tap[kk][ky * 3 + 1] = (ky == 1 && (kp + kk) > 0) ? centre : rowp[0];
+                                tap[kk][ky * 3 + 2] = rowp[d];
+                            }
+                            if (kp + kk == 0) centre = tap[0][4];
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int k = kp + kk;
+                        float a = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) a = fmaf(wv[kk * 12 + i], tap[kk][i], a);
+                        a += prev;                                      // hierarchical feature fusion (nn_layers/eesp.py:72-76)
+                        prev = a;
+                        if (k >= g_first) {
+                            float q = fmaf(a, wv[kk * 12 + 9], wv[kk * 12 + 10]);
+                            q = q > 0.f ? q : wv[kk * 12 + 11] * q;
+                            dst[((k - g_first) * KC + j) * 64 + lane] = q;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- matrix stage (M)
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const float4* apw = reinterpret_cast<const float4*>(ap) + ((size_t)((g * RTPG + rtile) * NCHUNK) * 64 + lane) * A4;
+    float4 a_cur[A4], a_nxt[A4];
+    auto load_a = [&](int c, float4 (&dst)[A4]) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) dst[i] = apw[(size_t)c * 64 * A4 + i];
+    };
+    auto mm_stage = [&](const float* src, const float4 (&av)[A4]) {
+        if (dbg & 2) return;
+        const float* bp = src + (gl * KC + half) * 64 + 2 * li;
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i) {
+            const float2 b2 = *reinterpret_cast<const float2*>(bp + 2 * i * 64);
+            const float4 a4 = av[i >> 2];
+            const float a = (i & 3) == 0 ? a4.x : (i & 3) == 1 ? a4.y : (i & 3) == 2 ? a4.z : a4.w;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2.y, acc1, 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: zero the halo columns of both row buffers (never overwritten), chunk 0 -> LDS, branches of chunk 0
+    load_chunk(0);
+    load_a(0, a_cur);
+    for (int i = tid; i < 2 * KC * ROWS * 2 * P; i += 512) {
+        const int c8 = i % (2 * P);
+        const int rr = i / (2 * P);                              // (buffer, channel, row) flattened
+        (&rt_[0][0])[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
+    }
+    store_chunk(rt_[0], wd_[0]);
+    load_chunk(1);
+    __syncthreads();
+    stamp();
+    if (SGW) dw_stage_s(0, rt_[0], bb_[0]); else dw_stage(rt_[0], wd_[0], bb_[0]);
+    store_chunk(rt_[1], wd_[1]);
+    __syncthreads();
+    stamp();
+
+    // residual / output addressing of the epilogue (lane: pixels 2 li, 2 li + 1 of the band; rows (r & 3) + 8 (r >> 2) + 4 half)
+    const int rows_here = (H - y0) < TH ? (H - y0) : TH;
+    const bool pok = 2 * li < rows_here * W;
+    const int ch0 = g * NCH + rtile * 32 + 4 * half;
+    const size_t obase = ((size_t)img * 4 * NCH + ch0) * HW + (size_t)y0 * W + 2 * li;
+    float2 resv[16];
+
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        if (c + 2 < NCHUNK) load_chunk(c + 2);
+        if (c + 1 < NCHUNK) {
+            if ((c & 1) == 0) load_a(c + 1, a_nxt); else load_a(c + 1, a_cur);
+            if (SGW) dw_stage_s(c + 1, rt_[(c + 1) & 1], bb_[(c + 1) & 1]); else dw_stage(rt_[(c + 1) & 1], wd_[(c + 1) & 1], bb_[(c + 1) & 1]);
+        } else {
+            // last chunk: the residual rows fly during its MFMAs
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                resv[q] = make_float2(0.f, 0.f);
+                if (pok && !(dbg & 8)) resv[q] = *reinterpret_cast<const float2*>(res + obase + (size_t)((q & 3) + 8 * (q >> 2)) * HW);
+            }
+        }
+        if ((c & 1) == 0) mm_stage(bb_[c & 1], a_cur); else mm_stage(bb_[c & 1], a_nxt);
+        if (c + 2 < NCHUNK) store_chunk(rt_[c & 1], wd_[c & 1]);
+        stamp();
+        if (c + 1 < NCHUNK) __syncthreads();
+    }
+
+    // ---- epilogue: folded BN, + residual, PReLU (the order of conv1x1's epilogue)
+    float4 sc4[4], sh4[4], al4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        sc4[rg] = *reinterpret_cast<const float4*>(escale + ch0 + 8 * rg);
+        sh4[rg] = *reinterpret_cast<const float4*>(eshift + ch0 + 8 * rg);
+        al4[rg] = *reinterpret_cast<const float4*>(ealpha + ch0 + 8 * rg);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const float scv[4] = {sc4[rg].x, sc4[rg].y, sc4[rg].z, sc4[rg].w}, shv[4] = {sh4[rg].x, sh4[rg].y, sh4[rg].z, sh4[rg].w};
+        const float alv[4] = {al4[rg].x, al4[rg].y, al4[rg].z, al4[rg].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = rg * 4 + q;
+            float v0 = fmaf(acc0[rr], scv[q], shv[q]) + resv[rr].x;
+            float v1 = fmaf(acc1[rr], scv[q], shv[q]) + resv[rr].y;
+            v0 = v0 > 0.f ? v0 : alv[q] * v0;
+            v1 = v1 > 0.f ? v1 : alv[q] * v1;
+            if (pok && !((dbg & 8) && v0 == 12345.f)) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
+        }
+    }
+#ifdef MSPL_DEBUG_STAMPS
+    if (stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) stamps[((size_t)blockIdx.x * 8 + wave) * 12 + i] = st[i];
+        }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------ host side
+struct XePlan {
+    int kind;        // 0: none, 1: n = 128, W = 30, dil {1,1,2,3}; 2: n = 64, W = 60, dil {1,2,3,4}
+    int TH, KC, GPW;
+};
+
+static XePlan xe_plan(int n, int H, int W, const int32_t* dil) {
+    XePlan p = {0, 0, 0, 0};
+    if (H < 1) return p;
+    if (n == 128 && W == 30 && dil[0] == 1 && dil[1] == 1 && dil[2] == 2 && dil[3] == 3) { p.kind = 1; p.TH = 2; p.KC = 16; p.GPW = 2; }
+    else if (n == 64 && W == 60 && dil[0] == 1 && dil[1] == 2 && dil[2] == 3 && dil[3] == 4) { p.kind = 2; p.TH = 1; p.KC = 8; p.GPW = 4; }
+    return p;
+}
+
+}  // namespace mspl
+
+using namespace mspl;
+
+extern "C" int mspl_eesp_dw_exp_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t dil[4], uint32_t flags) {
+    static const int enabled = getenv("MSPL_EESP_EXP") ? atoi(getenv("MSPL_EESP_EXP")) : 1;
+    (void)flags;
+    if (!enabled || !dil || N < 1) return 0;
+    return xe_plan(n, H, W, dil).kind != 0 ? 1 : 0;
+}
+
+extern "C" int64_t mspl_eesp_dw_exp_pack_floats(int32_t n) { return (int64_t)n * XE_REC + 4ll * n * n; }
+
+extern "C" int mspl_eesp_dw_exp_pack(const float* w4, const float* bscale, const float* bshift, const float* balpha,
+                                     const float* wexp, int32_t n, int32_t H, int32_t W, const int32_t dil[4], float* packed,
+                                     void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MSPL_REQUIRE(w4 && bscale && bshift && balpha && wexp && packed && dil, MSPL_ERR_NULL_POINTER, "eesp_dw_exp_pack: null pointer");
+    const XePlan p = xe_plan(n, H, W, dil);
+    MSPL_REQUIRE(p.kind != 0, MSPL_ERR_UNSUPPORTED, "eesp_dw_exp_pack: n=%d W=%d not covered", n, W);
+    const int total = 4 * n * n;
+    hipLaunchKernelGGL(eesp_exp_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, w4, bscale, bshift, balpha,
+                       wexp, n, p.KC, packed, packed + (size_t)n * XE_REC);
+    MSPL_CHECK_LAUNCH("eesp_dw_exp_pack");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H,
+                                    int32_t W, const mspl_epilogue_t* ep, float* out, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MSPL_REQUIRE(r && packed && dil && ep && out, MSPL_ERR_NULL_POINTER, "eesp_dw_exp: null pointer");
+    MSPL_REQUIRE(N >= 1 && H >= 1, MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: N=%d H=%d", N, H);
+    if (int rc = check_epi(ep, 4 * n, "eesp_dw_exp")) return rc;
+    MSPL_REQUIRE(ep->scale && ep->shift && ep->alpha && ep->residual, MSPL_ERR_NULL_POINTER,
+                 "eesp_dw_exp: the stride-1 block needs scale, shift, alpha and residual");
+    MSPL_REQUIRE(!ep->pre_add && !ep->reinf_r && !ep->gate && !ep->raw_out && (ep->out_ctot == 0 || (ep->out_ctot == 4 * n && ep->out_coff == 0)),
+                 MSPL_ERR_UNSUPPORTED, "eesp_dw_exp: only scale/shift/alpha/residual on an un-sliced destination");
+    const XePlan p = xe_plan(n, H, W, dil);
+    MSPL_REQUIRE(p.kind != 0, MSPL_ERR_UNSUPPORTED, "eesp_dw_exp: n=%d H=%d W=%d dil=%d,%d,%d,%d not covered", n, H, W, dil[0], dil[1], dil[2], dil[3]);
+    MSPL_REQUIRE((((uintptr_t)r | (uintptr_t)out | (uintptr_t)ep->residual | (uintptr_t)packed | (uintptr_t)ep->scale | (uintptr_t)ep->shift |
+                   (uintptr_t)ep->alpha) & 15) == 0, MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: operands must be 16-byte aligned");
+    MSPL_REQUIRE((int64_t)N * 4 * n * H * W < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: tensor too large");
+    const int bands = ceil_div(H, p.TH);
+    const int64_t nwg = (int64_t)N * bands * (4 / p.GPW);
+    MSPL_REQUIRE(nwg < (1ll << 30), MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: grid too large");
+    const float* dwp = packed;
+    const float* ap = packed + (size_t)n * XE_REC;
+    const dim3 grid((unsigned)nwg), blk(512);
+    static const int pad_kb = getenv("MSPL_XE_PAD") ? atoi(getenv("MSPL_XE_PAD")) : 0;   // extra (unused) LDS: caps the workgroups per CU
+    static const int dbg = getenv("MSPL_XE_DBG") ? atoi(getenv("MSPL_XE_DBG")) : 0;
+    static unsigned long long* stamp_buf = nullptr;
+    static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_XE_STAMP");
+    if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 8 * 12 * sizeof(unsigned long long));
+    if (nwg > 8192) stamp_buf = nullptr;
+    static const int var = getenv("MSPL_XE_VAR") ? atoi(getenv("MSPL_XE_VAR")) : 1;
+#define XE_LAUNCH(V) do { \
+    if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, V>), grid, blk, (size_t)pad_kb * 1024, stream, r, dwp, ap, \
+                                        ep->scale, ep->shift, ep->alpha, ep->residual, out, H, bands, (int)nwg, dbg, stamp_buf); \
+    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, V>), grid, blk, (size_t)pad_kb * 1024, stream, r, dwp, ap, \
+                            ep->scale, ep->shift, ep->alpha, ep->residual, out, H, bands, (int)nwg, dbg, stamp_buf); } while (0)
+    switch (var & 3) { case 0: XE_LAUNCH(0); break; case 1: XE_LAUNCH(1); break; case 2: XE_LAUNCH(2); break; default: XE_LAUNCH(3); break; }
+#undef XE_LAUNCH
+    MSPL_CHECK_LAUNCH("eesp_dw_exp");
+    if (stamp_buf) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
+        (void)hipDeviceSynchronize();
+        static unsigned long long host[8192 * 8 * 12];
+        (void)hipMemcpy(host, stamp_buf, (size_t)nwg * 8 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int64_t i = 0; i < nwg * 8; ++i) { if (host[i * 12] < t0) t0 = host[i * 12]; if (host[i * 12 + 11] > t1) t1 = host[i * 12 + 11]; }
+        double avg[12] = {0}, mx[12] = {0};
+        for (int64_t i = 0; i < nwg * 8; ++i)
+            for (int k = 0; k < 12; ++k) { const double v = (double)(host[i * 12 + k] - t0) / 100.0; avg[k] += v / (nwg * 8); if (v > mx[k]) mx[k] = v; }
+        fprintf(stderr, "[xe stamp] n=%d H=%d nwg=%lld span=%.2f us; avg (max) us since first start (start, 2 prologue barriers, 8 steps' work done, end): ",
+                n, H, (long long)nwg, (t1 - t0) / 100.0);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "%.2f(%.2f) ", avg[k], mx[k]);
+        fprintf(stderr, "\n");
+    }
+    return MSPL_OK;
+}

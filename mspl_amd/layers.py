@@ -196,6 +196,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
+_FUSED_DW_EXP = os.environ.get('MSPL_EESP_EXP', '1') != '0'   # inference: K2 + K3 of a stride-1 EESP block as one launch
 _FUSED_EESP_TRAIN = os.environ.get('MSPL_FUSED_EESP_TRAIN', '1') != '0'  # EESP block as one autograd node (frozen BatchNorm)
 _FUSED_PYR_TRAIN = os.environ.get('MSPL_FUSED_PYR_TRAIN', '1') != '0'    # pyramid body as one autograd node (frozen BatchNorm)
 
@@ -395,6 +396,18 @@ class EESP(nn.Module):
         ws = [m.conv.weight for m in self.spp_dw]
         return cached(self, 'w4', ws, lambda: torch.stack([w.reshape(-1, 3, 3) for w in ws]).contiguous())
 
+    def _dw_exp_packed(self, H, W):
+        """Parameter block of the fused K2 + K3 launch (depthwise weights + br_after_cat's fold per reduced channel, expansion
+        weights in matrix-operand order): rebuilt when any of its sources changes."""
+        br, exp = self.br_after_cat, self.conv_1x1_exp
+        deps = [m.conv.weight for m in self.spp_dw] + [br.bn.weight, br.bn.bias, br.bn.running_mean, br.bn.running_var,
+                                                      br.act.weight, exp.conv.weight]
+
+        def build():
+            bs, bb = bn_fold(br.bn)
+            return ops.eesp_dw_exp_pack(self._dw_weights(), bs, bb, br.act.weight, exp.conv.weight, H, W, self.dilations)
+        return cached(self, 'dwexp', deps, build)
+
     def reduce_transform(self, input):
         """K1 + K2: returns the BN+PReLU'd concatenation that feeds conv_1x1_exp."""
         scale, shift = bn_fold(self.br_after_cat.bn)
@@ -434,6 +447,14 @@ class EESP(nn.Module):
     def forward(self, input):
         if _training_path():
             return self._forward_train(input)
+        exp = self.conv_1x1_exp
+        if (self.stride == 1 and exp.conv.out_channels == input.shape[1] and _FUSED_DW_EXP
+                and ops.eesp_dw_exp_fits((input.shape[0], self.proj_1x1.conv.out_channels) + tuple(input.shape[2:]), self.dilations)):
+            # K2 + K3 in one launch: the 4n-channel concatenation stays on the CU (csrc/eesp_exp.hip)
+            o1 = self.proj_1x1(input)
+            scale, shift = bn_fold(exp.bn)
+            return ops.eesp_dw_exp(o1, self._dw_exp_packed(input.shape[2], input.shape[3]), self.dilations,
+                                   Epi(scale, shift, self.module_act.weight, residual=input))
         cat = self.reduce_transform(input)
         scale, shift = bn_fold(self.conv_1x1_exp.bn)
         if self.stride == 2 and self.downAvg:

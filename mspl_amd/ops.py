@@ -167,6 +167,40 @@ def eesp_proj_dw_hff(x, wproj, pscale, pshift, palpha, w4, dilations, groups, ep
     return dst
 
 
+def eesp_dw_exp_fits(shape, dilations):
+    """True when K2 + K3 of a stride-1 EESP block run as one launch for a reduced tensor of `shape` (N,n,H,W)."""
+    N, n, H, W = [int(v) for v in shape]
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
+    return bool(lib.mspl_eesp_dw_exp_fits(N, n, H, W, d, current_launch_flags()))
+
+
+def eesp_dw_exp_pack(w4, bscale, bshift, balpha, wexp, H, W, dilations):
+    """The packed parameter block of mspl_eesp_dw_exp_fwd (depends on the weights only: cache it per weight version)."""
+    w4 = _f32(w4, 'w4')
+    n = w4.shape[1]
+    if tuple(w4.shape) != (4, n, 3, 3):
+        raise RuntimeError('mspl_amd: eesp_dw_exp weight %s, expected (4,%d,3,3)' % (tuple(w4.shape), n))
+    bs, bb, ba = _vec(bscale, 4 * n, 'bscale'), _vec(bshift, 4 * n, 'bshift'), _vec(balpha, 4 * n, 'balpha')
+    wexp = _vec(wexp, 4 * n * n, 'expansion weight')
+    packed = torch.empty(int(lib.mspl_eesp_dw_exp_pack_floats(n)), device=w4.device, dtype=torch.float32)
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
+    check(lib.mspl_eesp_dw_exp_pack(_p(w4), _p(bs), _p(bb), _p(ba), _p(wexp), n, int(H), int(W), d, _p(packed), _stream()))
+    return packed
+
+
+def eesp_dw_exp(r, packed, dilations, ep):
+    """K2 + K3 of a stride-1 EESP block: r (N,n,H,W) -> (N,4n,H,W); ep carries conv_1x1_exp's folded BN, module_act's slope
+    and the residual (the block's input)."""
+    r = _f32(r, 'r')
+    N, n, H, W = r.shape
+    packed = _vec(packed, int(lib.mspl_eesp_dw_exp_pack_floats(n)), 'packed')
+    dst = torch.empty((N, 4 * n, H, W), device=r.device, dtype=torch.float32)
+    s, keep = _build(ep, dst, 0, N, 4 * n, H * W)
+    d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
+    check(lib.mspl_eesp_dw_exp_fwd(_p(r), _p(packed), d, N, n, H, W, ctypes.byref(s), _p(dst), _stream()))
+    return dst
+
+
 def conv1x1(x, w, groups=1, ep=None, out=None):
     """K1/K3.  x (N,Cin,H,W), w (Cout,Cin/groups[,1,1])."""
     x, w = _f32(x, 'x'), _f32(w, 'w')

@@ -77,6 +77,40 @@ def test_eesp_dw_hff_stride2_streaming_form(dil, shape, monkeypatch):
     assert torch.equal(dst[:, 2:2 + 4 * n], got) and torch.all(dst[:, :2] == -5.0) and torch.all(dst[:, 2 + 4 * n:] == -5.0)
 
 
+@pytest.mark.parametrize('cfg', [(2, 128, 18, 30, [1, 1, 2, 3]), (1, 128, 16, 30, [1, 1, 2, 3]), (3, 128, 5, 30, [1, 1, 2, 3]), (17, 128, 18, 30, [1, 1, 2, 3]),
+                                 (2, 64, 36, 60, [1, 2, 3, 4]), (1, 64, 32, 60, [1, 2, 3, 4]), (3, 64, 3, 60, [1, 2, 3, 4]), (1, 64, 1, 60, [1, 2, 3, 4])])
+def test_eesp_dw_exp(cfg):
+    """K2 + K3 of a stride-1 EESP block in one launch (nn_layers/eesp.py:68-93) against torch fp32, and bit-identical to the
+    two-launch form (same operation order in the branch arithmetic and in the matrix-core sums)."""
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, n, H, W, dil = cfg
+    assert ops.eesp_dw_exp_fits((N, n, H, W), dil)
+    r = rnd(N, n, H, W, seed=1)
+    x_in = rnd(N, 4 * n, H, W, seed=6)
+    w = rnd(4, n, 3, 3, seed=2, scale=0.3)
+    bs, bb, ba = rnd(4 * n, seed=3).abs() + 0.5, rnd(4 * n, seed=4) * 0.1, rnd(4 * n, seed=5).abs() * 0.3
+    wexp = rnd(4 * n, n, 1, 1, seed=7, scale=0.1)
+    es, eb, ea = rnd(4 * n, seed=8).abs() + 0.5, rnd(4 * n, seed=9) * 0.1, rnd(4 * n, seed=10).abs() * 0.3
+    outs = []
+    for k in range(4):
+        o = F.conv2d(r, w[k].unsqueeze(1), None, 1, dil[k], dil[k], n)
+        outs.append(o if k == 0 else o + outs[-1])
+    cat = F.prelu(torch.cat(outs, 1) * bs.view(1, -1, 1, 1) + bb.view(1, -1, 1, 1), ba)
+    ref = F.conv2d(cat, wexp, None, 1, 0, 1, 4) * es.view(1, -1, 1, 1) + eb.view(1, -1, 1, 1) + x_in
+    ref = F.prelu(ref, ea)
+    d = lambda t: t.to(DEV)
+    packed = ops.eesp_dw_exp_pack(d(w), d(bs), d(bb), d(ba), d(wexp), H, W, dil)
+    got = ops.eesp_dw_exp(d(r), packed, dil, Epi(d(es), d(eb), d(ea), residual=d(x_in)))
+    close(got, ref)
+    cat2 = ops.eesp_dw_hff(d(r), d(w), dil, 1, Epi(d(bs), d(bb), d(ba)))
+    two = ops.conv1x1(cat2, d(wexp), 4, Epi(d(es), d(eb), d(ea), residual=d(x_in)))
+    assert torch.equal(got, two)
+    # not covered: another width, another dilation set
+    assert not ops.eesp_dw_exp_fits((N, n, H, W + 2), dil)
+    assert not ops.eesp_dw_exp_fits((N, n, H, W), [1, 1, 1, 2])
+
+
 @pytest.mark.parametrize('cfg', [(2, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 128, 4, 16, 30, [1, 1, 2, 3]), (2, 256, 64, 4, 18, 30, [1, 2, 3, 4]),
                                  (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4]),
                                  (32, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 64, 4, 20, 36, [1, 1, 2, 3])])

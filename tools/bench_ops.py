@@ -181,3 +181,54 @@ def bench_k2x():
 
 if len(sys.argv) > 1 and sys.argv[1] == 'k2x':
     bench_k2x()
+
+
+def bench_exp():
+    """K2 + K3 of the stride-1 EESP blocks: the fused launch (csrc/eesp_exp.hip) against the two launches it replaces."""
+    N = int(os.environ.get('K2_N', '16'))
+    for name, n, h, w, dil in [('L3 s1 n=64 36x60', 64, 36, 60, [1, 2, 3, 4]), ('L4 s1 n=128 18x30', 128, 18, 30, [1, 1, 2, 3])]:
+        r = torch.randn(N, n, h, w, device=DEV)
+        xin = torch.randn(N, 4 * n, h, w, device=DEV)
+        w4 = torch.randn(4, n, 3, 3, device=DEV) * 0.2
+        bs, bb, ba = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        wexp = torch.randn(4 * n, n, 1, 1, device=DEV) * 0.1
+        es, eb, ea = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        cat = torch.empty(N, 4 * n, h, w, device=DEV)
+        out = torch.empty(N, 4 * n, h, w, device=DEV)
+        epb, epe = Epi(bs, bb, ba), Epi(es, eb, ea, residual=xin)
+        t_k2 = timeit(lambda: ops.eesp_dw_hff(r, w4, dil, 1, epb, out=(cat, 0)))
+        t_k3 = timeit(lambda: ops.conv1x1(cat, wexp, 4, epe, out=(out, 0)))
+        t_two = timeit(lambda: (ops.eesp_dw_hff(r, w4, dil, 1, epb, out=(cat, 0)), ops.conv1x1(cat, wexp, 4, epe, out=(out, 0))))
+        packed = ops.eesp_dw_exp_pack(w4, bs, bb, ba, wexp, h, w, dil)
+        t_f = timeit(lambda: ops.eesp_dw_exp(r, packed, dil, epe))
+        by = 4 * N * h * w * 9 * n
+        fl = 2 * N * h * w * 4 * n * n
+        print('%-20s N=%d  K2 %6.1f + K3 %6.1f (back to back %6.1f) us | fused %6.1f us  %6.0f GB/s (%.2f of 8 TB/s)  %5.1f TFLOP/s (%.2f of 157)'
+              % (name, N, t_k2, t_k3, t_two, t_f, by / t_f / 1e3, by / t_f / 8e6, fl / t_f / 1e6, fl / t_f / 157.3e6))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'exp':
+    bench_exp()
+
+
+def bench_expx():
+    """Eager launches of the fused K2+K3 kernel (for a STAMPS=1 build with MSPL_XE_STAMP=1: the launcher prints the step timeline)."""
+    N = int(os.environ.get('K2_N', '16'))
+    for name, n, h, w, dil in [('L3 s1 n=64 36x60', 64, 36, 60, [1, 2, 3, 4]), ('L4 s1 n=128 18x30', 128, 18, 30, [1, 1, 2, 3])]:
+        r = torch.randn(N, n, h, w, device=DEV)
+        xin = torch.randn(N, 4 * n, h, w, device=DEV)
+        w4 = torch.randn(4, n, 3, 3, device=DEV) * 0.2
+        bs, bb, ba = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        wexp = torch.randn(4 * n, n, 1, 1, device=DEV) * 0.1
+        es, eb, ea = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        packed = ops.eesp_dw_exp_pack(w4, bs, bb, ba, wexp, h, w, dil)
+        epe = Epi(es, eb, ea, residual=xin)
+        sys.stderr.write('--- %s\n' % name)
+        sys.stderr.flush()
+        for _ in range(4):
+            ops.eesp_dw_exp(r, packed, dil, epe)
+            torch.cuda.synchronize()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'expx':
+    bench_expx()
