@@ -84,12 +84,12 @@ __global__ void eesp_exp_pack_kernel(const float* __restrict__ w4, const float* 
 // waves per workgroup (one of each per SIMD) does NOT overlap the two kinds of work -- the depthwise waves' step got 1.2 us
 // longer exactly while the matrix waves' 1.1 us of v_mfma_f32_32x32x2_f32 ran: the fp32 MFMA runs at the vector rate and holds
 // the SIMD's vector issue.  So every wave does both, and a step costs (vector work) + (matrix work) per SIMD.
-template <int NCH, int W, int TH, int KC, int GPW, class DS, int VAR>
+template <int NCH, int W, int TH, int KC, int GPW, class DS>
 __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __restrict__ r, const float* __restrict__ dwp,
                                                              const float* __restrict__ ap, const float* __restrict__ escale,
                                                              const float* __restrict__ eshift, const float* __restrict__ ealpha,
                                                              const float* __restrict__ res, float* __restrict__ out,
-                                                             int H, int bands, int nwg, int dbg, unsigned long long* __restrict__ stamps) {
+                                                             int H, int bands, int nwg, unsigned long long* __restrict__ stamps) {
     constexpr int MAXD = DS::maxd();
     constexpr int ROWS = TH + 2 * MAXD;
     constexpr int P = 4;                       // zero columns on either side of a staged row (>= MAXD, even: 8-byte aligned rows)
@@ -103,14 +103,12 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     constexpr int IPT = (ITEMS + 511) / 512;
     constexpr int CPW = KC / 8;                // channels per wave and chunk in the depthwise stage
     constexpr int A4 = KC / 8;                 // float4 of A per lane and chunk
-    constexpr int WREC4 = KC * XE_REC / 4;     // float4 of a chunk's depthwise records
     static_assert(GPW * RTPG == 8, "eight waves: (group, row tile)");
     static_assert(PXV <= 64 && (W % 2) == 0 && MAXD <= P, "band geometry");
-    static_assert(KC % 8 == 0 && NCH % KC == 0 && NCHUNK >= 2 && WREC4 <= 512, "chunking");
+    static_assert(KC % 8 == 0 && NCH % KC == 0 && NCHUNK >= 2, "chunking");
 
     __shared__ __attribute__((aligned(16))) float rt_[2][KC * ROWS * RS];
     __shared__ __attribute__((aligned(16))) float bb_[2][GPW * KC * 64];
-    __shared__ __attribute__((aligned(16))) float wd_[2][KC * XE_REC];   // the chunk's depthwise weights + BN / PReLU constants
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,79 +135,47 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     const int gl = wave / RTPG, rtile = wave % RTPG;     // matrix stage: this wave's group (local) and row tile
     const int g = g_first + gl;
 
-    // ---- staging (L): chunk c of the reduced tensor, rows y0 - MAXD .. y0 + TH - 1 + MAXD of KC channels, and the chunk's
-    // depthwise records.  An item's place in the chunk is the same for every chunk: computed once.
+    // ---- staging (L): chunk c of the reduced tensor, rows y0 - MAXD .. y0 + TH - 1 + MAXD of KC channels
     const float* rimg = r + (size_t)img * NCH * HW;
     const int glin0 = (y0 - MAXD) * HW2;                 // float2 index of the first staged row inside a plane (may be negative)
-    constexpr bool PRE = (VAR & 2) != 0;
-    constexpr bool SGW = (VAR & 1) != 0;
-    int soff[PRE ? IPT : 1], doff[PRE ? IPT : 1];        // source offset (floats, inside the chunk) / LDS offset; -1: zero, nothing
-    if (PRE) {
+    float2 sv[IPT];
+    auto load_chunk = [&](int c) {
+        const float* rc = rimg + (size_t)c * KC * HW;
 #pragma unroll
         for (int q = 0; q < IPT; ++q) {
             const int i = tid + 512 * q;
             const int ic = i < ITEMS ? i : 0;
             const int j = ic / (ROWS * HW2);
             const int rem = ic - j * (ROWS * HW2);
-            const int row = rem / HW2, c2 = rem - row * HW2;
             const int gl2 = glin0 + rem;
             const bool ok = gl2 >= 0 && gl2 < H * HW2;
-            soff[q] = ok ? j * HW + 2 * gl2 : -1;
-            doff[q] = i < ITEMS ? (j * ROWS + row) * RS + P + 2 * c2 : -1;
+            const int gc = ok ? gl2 : 0;
+            const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + 2 * gc);   // unconditional load from a clamped address
+            sv[q] = ok ? v : make_float2(0.f, 0.f);
         }
-    }
-    float2 sv[IPT];
-    float4 wrec;
-    auto load_chunk = [&](int c) {
-        if (dbg & 4) return;
-        const float* rc = rimg + (size_t)c * KC * HW;
-#pragma unroll
-        for (int q = 0; q < IPT; ++q) {
-            if (PRE) {
-                const float2 v = *reinterpret_cast<const float2*>(rc + (soff[q] < 0 ? 0 : soff[q]));
-                sv[q] = soff[q] < 0 ? make_float2(0.f, 0.f) : v;
-            } else {
-                const int i = tid + 512 * q;
-                const int ic = i < ITEMS ? i : 0;
-                const int j = ic / (ROWS * HW2);
-                const int rem = ic - j * (ROWS * HW2);
-                const int gl2 = glin0 + rem;
-                const bool ok = gl2 >= 0 && gl2 < H * HW2;
-                const int gc = ok ? gl2 : 0;
-                const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + 2 * gc);
-                sv[q] = ok ? v : make_float2(0.f, 0.f);
-            }
-        }
-        if (!SGW) wrec = *reinterpret_cast<const float4*>(dwp + (size_t)c * KC * XE_REC + 4 * (tid < WREC4 ? tid : 0));
     };
-    auto store_chunk = [&](float* dst, float* wdst) {
-        if (dbg & 4) return;
+    auto store_chunk = [&](float* dst) {
 #pragma unroll
         for (int q = 0; q < IPT; ++q) {
-            if (PRE) {
-                if (doff[q] >= 0) *reinterpret_cast<float2*>(dst + doff[q]) = sv[q];
-            } else {
-                const int i = tid + 512 * q;
-                if (i < ITEMS) {
-                    const int j = i / (ROWS * HW2);
-                    const int rem = i - j * (ROWS * HW2);
-                    const int row = rem / HW2, c2 = rem - row * HW2;
-                    *reinterpret_cast<float2*>(dst + (j * ROWS + row) * RS + P + 2 * c2) = sv[q];
-                }
+            const int i = tid + 512 * q;
+            if (i < ITEMS) {
+                const int j = i / (ROWS * HW2);
+                const int rem = i - j * (ROWS * HW2);
+                const int row = rem / HW2, c2 = rem - row * HW2;
+                *reinterpret_cast<float2*>(dst + (j * ROWS + row) * RS + P + 2 * c2) = sv[q];
             }
         }
-        if (!SGW && tid < WREC4) *reinterpret_cast<float4*>(wdst + 4 * tid) = wrec;
     };
 
-    // ---- depthwise stage (D): lane = pixel of the band; a wave takes CPW channels of the chunk, one at a time, two branches at a
-    // time: their 24 constants (broadcast 16-byte LDS reads) and taps are requested together, then evaluated in eesp_dw.hip's order
+    // ---- depthwise stage (D): lane = pixel of the band; a wave takes CPW channels of the chunk, one at a time.  The channel's 48
+    // constants come through scalar loads (one 192-byte record; measured against broadcast LDS reads of a staged copy: 36 vs 42 us
+    // per level-4 launch), the taps are ds_read_b32 with immediate offsets into the zero-haloed rows.
     const int pxc = lane < PXV ? lane : PXV - 1;
     const int ty = (TH > 1) ? pxc / W : 0;
     const int tx = pxc - ty * W;
     const int tapbase = (ty + MAXD) * RS + P + tx;
     const int nbr = g_first + GPW;                                     // uniform: a workgroup needs branches 0 .. its last group
-    auto dw_stage_s = [&](int c, const float* src, float* dst) {       // constants through scalar loads (one 192-byte record per channel)
-        if (dbg & 1) return;
+    auto dw_stage = [&](int c, const float* src, float* dst) {
 #pragma unroll
         for (int u = 0; u < CPW; ++u) {
             const int j = wave + 8 * u;
@@ -231,65 +197,12 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
                     a = fmaf(wv[k * 12 + ky * 3 + 1], rowp[0], a);
                     a = fmaf(wv[k * 12 + ky * 3 + 2], rowp[d], a);
                 }
-                a += prev;
+                a += prev;                                              // hierarchical feature fusion (nn_layers/eesp.py:72-76)
                 prev = a;
                 if (k >= g_first) {
                     float q = fmaf(a, wv[k * 12 + 9], wv[k * 12 + 10]);
                     q = q > 0.f ? q : wv[k * 12 + 11] * q;
                     dst[((k - g_first) * KC + j) * 64 + lane] = q;
-                }
-            }
-        }
-    };
-    auto dw_stage = [&](const float* src, const float* wsrc, float* dst) {
-        if (dbg & 1) return;
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-            const int j = wave + 8 * u;
-            const float4* wp4 = reinterpret_cast<const float4*>(wsrc + j * XE_REC);
-            const float* tp = src + j * (ROWS * RS) + tapbase;
-            float prev = 0.f, centre = 0.f;
-#pragma unroll
-            for (int kp = 0; kp < 4; kp += 2) {
-                if (kp < nbr) {
-                    float wv[24];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const float4 t4 = wp4[kp * 3 + i];
-                        wv[4 * i] = t4.x; wv[4 * i + 1] = t4.y; wv[4 * i + 2] = t4.z; wv[4 * i + 3] = t4.w;
-                    }
-                    float tap[2][9];
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const int d = DS::d(kp + kk);
-                        if (kk > 0 && DS::d(kp) == d) {
-#pragma unroll
-                            for (int i = 0; i < 9; ++i) tap[1][i] = tap[0][i];
-                        } else {
-#pragma unroll
-                            for (int ky = 0; ky < 3; ++ky) {
-                                const float* rowp = tp + (ky - 1) * d * RS;
-                                tap[kk][ky * 3 + 0] = rowp[-d];
-                                tap[kk][ky * 3 + 1] = (ky == 1 && (kp + kk) > 0) ? centre : rowp[0];
-                                tap[kk][ky * 3 + 2] = rowp[d];
-                            }
-                            if (kp + kk == 0) centre = tap[0][4];
-                        }
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const int k = kp + kk;
-                        float a = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) a = fmaf(wv[kk * 12 + i], tap[kk][i], a);
-                        a += prev;                                      // hierarchical feature fusion (nn_layers/eesp.py:72-76)
-                        prev = a;
-                        if (k >= g_first) {
-                            float q = fmaf(a, wv[kk * 12 + 9], wv[kk * 12 + 10]);
-                            q = q > 0.f ? q : wv[kk * 12 + 11] * q;
-                            dst[((k - g_first) * KC + j) * 64 + lane] = q;
-                        }
-                    }
                 }
             }
         }
@@ -306,7 +219,6 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
         for (int i = 0; i < A4; ++i) dst[i] = apw[(size_t)c * 64 * A4 + i];
     };
     auto mm_stage = [&](const float* src, const float4 (&av)[A4]) {
-        if (dbg & 2) return;
         const float* bp = src + (gl * KC + half) * 64 + 2 * li;
 #pragma unroll
         for (int i = 0; i < KC / 2; ++i) {
@@ -326,12 +238,12 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
         const int rr = i / (2 * P);                              // (buffer, channel, row) flattened
         (&rt_[0][0])[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
     }
-    store_chunk(rt_[0], wd_[0]);
+    store_chunk(rt_[0]);
     load_chunk(1);
     __syncthreads();
     stamp();
-    if (SGW) dw_stage_s(0, rt_[0], bb_[0]); else dw_stage(rt_[0], wd_[0], bb_[0]);
-    store_chunk(rt_[1], wd_[1]);
+    dw_stage(0, rt_[0], bb_[0]);
+    store_chunk(rt_[1]);
     __syncthreads();
     stamp();
 
@@ -347,17 +259,17 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
         if (c + 2 < NCHUNK) load_chunk(c + 2);
         if (c + 1 < NCHUNK) {
             if ((c & 1) == 0) load_a(c + 1, a_nxt); else load_a(c + 1, a_cur);
-            if (SGW) dw_stage_s(c + 1, rt_[(c + 1) & 1], bb_[(c + 1) & 1]); else dw_stage(rt_[(c + 1) & 1], wd_[(c + 1) & 1], bb_[(c + 1) & 1]);
+            dw_stage(c + 1, rt_[(c + 1) & 1], bb_[(c + 1) & 1]);
         } else {
             // last chunk: the residual rows fly during its MFMAs
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 resv[q] = make_float2(0.f, 0.f);
-                if (pok && !(dbg & 8)) resv[q] = *reinterpret_cast<const float2*>(res + obase + (size_t)((q & 3) + 8 * (q >> 2)) * HW);
+                if (pok) resv[q] = *reinterpret_cast<const float2*>(res + obase + (size_t)((q & 3) + 8 * (q >> 2)) * HW);
             }
         }
         if ((c & 1) == 0) mm_stage(bb_[c & 1], a_cur); else mm_stage(bb_[c & 1], a_nxt);
-        if (c + 2 < NCHUNK) store_chunk(rt_[c & 1], wd_[c & 1]);
+        if (c + 2 < NCHUNK) store_chunk(rt_[c & 1]);
         stamp();
         if (c + 1 < NCHUNK) __syncthreads();
     }
@@ -381,7 +293,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
             float v1 = fmaf(acc1[rr], scv[q], shv[q]) + resv[rr].y;
             v0 = v0 > 0.f ? v0 : alv[q] * v0;
             v1 = v1 > 0.f ? v1 : alv[q] * v1;
-            if (pok && !((dbg & 8) && v0 == 12345.f)) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
+            if (pok) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
         }
     }
 #ifdef MSPL_DEBUG_STAMPS
@@ -458,25 +370,21 @@ extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const i
     const float* dwp = packed;
     const float* ap = packed + (size_t)n * XE_REC;
     const dim3 grid((unsigned)nwg), blk(512);
-    static const int pad_kb = getenv("MSPL_XE_PAD") ? atoi(getenv("MSPL_XE_PAD")) : 0;   // extra (unused) LDS: caps the workgroups per CU
-    static const int dbg = getenv("MSPL_XE_DBG") ? atoi(getenv("MSPL_XE_DBG")) : 0;
     static unsigned long long* stamp_buf = nullptr;
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_XE_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 8 * 12 * sizeof(unsigned long long));
-    if (nwg > 8192) stamp_buf = nullptr;
-    static const int var = getenv("MSPL_XE_VAR") ? atoi(getenv("MSPL_XE_VAR")) : 1;
-#define XE_LAUNCH(V) do { \
-    if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, V>), grid, blk, (size_t)pad_kb * 1024, stream, r, dwp, ap, \
-                                        ep->scale, ep->shift, ep->alpha, ep->residual, out, H, bands, (int)nwg, dbg, stamp_buf); \
-    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, V>), grid, blk, (size_t)pad_kb * 1024, stream, r, dwp, ap, \
-                            ep->scale, ep->shift, ep->alpha, ep->residual, out, H, bands, (int)nwg, dbg, stamp_buf); } while (0)
-    switch (var & 3) { case 0: XE_LAUNCH(0); break; case 1: XE_LAUNCH(1); break; case 2: XE_LAUNCH(2); break; default: XE_LAUNCH(3); break; }
-#undef XE_LAUNCH
+    unsigned long long* stamps = nwg <= 8192 ? stamp_buf : nullptr;
+    if (p.kind == 1)
+        hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>>), grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift,
+                           ep->alpha, ep->residual, out, H, bands, (int)nwg, stamps);
+    else
+        hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>>), grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift,
+                           ep->alpha, ep->residual, out, H, bands, (int)nwg, stamps);
     MSPL_CHECK_LAUNCH("eesp_dw_exp");
-    if (stamp_buf) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
+    if (stamps) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
         (void)hipDeviceSynchronize();
         static unsigned long long host[8192 * 8 * 12];
-        (void)hipMemcpy(host, stamp_buf, (size_t)nwg * 8 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(host, stamps, (size_t)nwg * 8 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int64_t i = 0; i < nwg * 8; ++i) { if (host[i * 12] < t0) t0 = host[i * 12]; if (host[i * 12 + 11] > t1) t1 = host[i * 12 + 11]; }
         double avg[12] = {0}, mx[12] = {0};
