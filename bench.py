@@ -353,8 +353,10 @@ def eval_step_rate(dev, iters=20):
     for name, ep, n in (('one_in_flight', evaluation.EvalPass(m, 5, class_weights=torch.ones(5), ignore_idx=4, aux_weight=0.5, device=dev,
                                                              use_graph=True), iters),
                         ('lanes_3', evaluation.PipelinedEvalPass(m, 5, depth=3, class_weights=torch.ones(5), ignore_idx=4, aux_weight=0.5,
-                                                                 device=dev), 3 * iters)):
-        for _ in range(6):
+                                                                 device=dev), 3 * iters),
+                        ('lanes_3x2', evaluation.PipelinedEvalPass(m, 5, depth=3, group=2, class_weights=torch.ones(5), ignore_idx=4,
+                                                                   aux_weight=0.5, device=dev), 6 * iters)):
+        for _ in range(12):
             ep(x, y)
         ep.reset()
         torch.cuda.synchronize()
@@ -366,11 +368,13 @@ def eval_step_rate(dev, iters=20):
         dt = (time.perf_counter() - t0) / n
         res[name] = {'value': round(BATCH / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'batches': n, 'loss_finite': bool(np_isfinite(loss)),
                      'pixels_counted': int(ep.sums()[2 * ep.K:3 * ep.K].sum().item())}
-    best = res['lanes_3']
+    best = res['lanes_3x2']
     return {'value': best['value'], 'unit': 'images/s', 'ms_per_batch': best['ms_per_batch'], 'batches': best['batches'],
             'workload': 'val_seg_ue step, ESPDNet-UE s=2.0 C=5, bs=16 x 3 x 256 x 480 fp32: forward + out+0.5*aux + weighted CE + MIOU '
-                        'areas, one hipGraph replay per batch, 3 batches in flight (what val_seg_ue runs)',
-            'loss_finite': best['loss_finite'], 'pixels_counted': best['pixels_counted'], 'one_in_flight': res['one_in_flight']}
+                        'areas, hipGraph replays, 3 launches in flight x 2 consecutive batches per launch (what val_seg_ue runs; per-batch '
+                        'loss means and meter updates as in the reference loop)',
+            'loss_finite': best['loss_finite'], 'pixels_counted': best['pixels_counted'], 'one_in_flight': res['one_in_flight'],
+            'one_batch_per_launch': res['lanes_3']}
 
 
 def np_isfinite(v):

@@ -94,6 +94,7 @@ class EvalPass(EvalSums, _GraphedPassMixin):
         self.acc = torch.zeros(3, dtype=torch.float64, device=self.device)             # sum loss_b * n_b, sum n_b, last loss_b
         self.batches = 0
         self._graphs = {}
+        self._splits = None          # batch sizes of the reference's batches inside one launch (PipelinedEvalPass(group > 1)); None: one
 
     def reset(self):
         self.areas.zero_()
@@ -112,9 +113,15 @@ class EvalPass(EvalSums, _GraphedPassMixin):
     def _graph_outputs(run_result):
         return run_result
 
-    @staticmethod
-    def _shape_key(inputs):
-        return tuple(tuple(t.shape) for t in inputs)
+    def _shape_key(self, inputs):
+        return tuple(tuple(t.shape) for t in inputs) + (self._splits,)
+
+    def static_inputs(self, inputs_like, splits):
+        """The input buffers of the graph captured for a launch of `splits` batches shaped like `inputs_like` (one batch), or None."""
+        n = sum(splits)
+        key = tuple((n,) + tuple(t.shape[1:]) for t in inputs_like) + (tuple(splits),)
+        g = self._graphs.get(key)
+        return None if g is None else g.static_in
 
     @staticmethod
     def _clone_input(inputs):
@@ -134,19 +141,30 @@ class EvalPass(EvalSums, _GraphedPassMixin):
         else:
             main, aux = _lowres(self.model, images)
         aw = self.aux_weight if aux is not None else 0.0
-        eval_epilogue(main, aux if aw != 0.0 else None, labels, self.cw, images.shape[2:], aw, self.ignore_idx, self.K,
-                      self.loss_sums, self.areas)
-        check(lib.mspl_eval_batch_finalize(_p(self.loss_sums), _p(self.acc), int(images.shape[0]), _stream()))
+        # one forward over the whole launch; loss sums and the meter update per BATCH of the reference's loop (the loss is a mean over a
+        # batch's valid pixels, train_eval_seg.py:288-297), areas add up over everything
+        off = 0
+        for nb in (self._splits or (int(images.shape[0]),)):
+            sl = slice(off, off + nb)
+            eval_epilogue(main[sl], aux[sl] if aw != 0.0 else None, labels[sl], self.cw, images.shape[2:], aw, self.ignore_idx, self.K,
+                          self.loss_sums, self.areas)
+            check(lib.mspl_eval_batch_finalize(_p(self.loss_sums), _p(self.acc), int(nb), _stream()))
+            off += nb
         return self.acc
 
-    def __call__(self, images, labels, depth=None):
+    def __call__(self, images, labels, depth=None, splits=None):
+        """splits: sizes of the consecutive batches of the reference's loop that `images` holds (default: one batch)."""
         with torch.no_grad():
             images = images.to(self.device)
             labels = labels.to(self.device, torch.int64).contiguous()
             if tuple(labels.shape) != (images.shape[0],) + tuple(images.shape[2:]):
                 raise RuntimeError('mspl_amd: eval labels %s do not match images %s' % (tuple(labels.shape), tuple(images.shape)))
+            splits = (int(images.shape[0]),) if splits is None else tuple(int(v) for v in splits)
+            if sum(splits) != images.shape[0] or min(splits) < 1:
+                raise RuntimeError('mspl_amd: eval splits %s do not add up to %d images' % (splits, images.shape[0]))
+            self._splits = splits
             inputs = (images, labels) if depth is None else (images, depth.to(self.device), labels)
-            self.batches += 1
+            self.batches += len(splits)
             if self.use_graph:
                 return self._replay(inputs)
             return self._run(inputs)
@@ -162,48 +180,101 @@ class PipelinedEvalPass(EvalSums):
     """`depth` EvalPass lanes taken in turn, each on a stream of its own with its own hipGraph, static inputs and accumulators: the
     evaluation step of consecutive batches overlaps on the GPU the way the label pass's lanes do (one graph replay alone leaves the
     chip half idle: its kernels are small and run one after the other).  The lanes never share an accumulator, so nothing races;
-    `sums()` adds them up (integer areas: exact; the loss sums are float64 sums of per-batch means either way)."""
+    `sums()` adds them up (integer areas: exact; the loss sums are float64 sums of per-batch means either way).
 
-    def __init__(self, model, num_classes, depth=3, **kw):
+    group: consecutive batches that ONE launch of a lane evaluates (the label pass's batches-per-launch): the batches are copied into
+    the lane's input buffer as they arrive (the caller may reuse its tensors at once) and the lane is launched when `group` of them are
+    staged, or earlier on a batch of another shape / `flush()` / `sums()`.  Per-batch semantics are kept: the loss is a mean per batch
+    and the meters are updated batch by batch (EvalPass._run), so the results do not depend on `group`."""
+
+    def __init__(self, model, num_classes, depth=3, group=1, **kw):
         from .uest import _concurrent_streams
         kw.setdefault('use_graph', True)
         self.lanes = [EvalPass(model, num_classes, **kw) for _ in range(max(1, int(depth)))]
         self.device = self.lanes[0].device
         self.K = self.lanes[0].K
+        self.group = max(1, int(group))
         self.streams = _concurrent_streams(len(self.lanes), self.device) if len(self.lanes) > 1 else [None]
         self._next = 0
+        self._staged = []            # batches waiting in the current lane: (images, depth, labels, in_static_slot)
 
     @property
     def batches(self):
-        return sum(l.batches for l in self.lanes)
+        return sum(l.batches for l in self.lanes) + len(self._staged)
 
     def reset(self):
         self._join()
         for l in self.lanes:
             l.reset()
 
+    def flush(self):
+        """Launch what is staged in the current lane (fewer than `group` batches)."""
+        if self._staged:
+            self._launch()
+
     def _join(self):
+        self.flush()
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
             if st is not None:
                 cur.wait_stream(st)
 
+    def _on_lane(self):
+        st = self.streams[self._next]
+        return torch.cuda.stream(st) if st is not None else torch.no_grad()
+
     def __call__(self, images, labels, depth=None):
-        i = self._next
-        self._next = (i + 1) % len(self.lanes)
-        lane, st = self.lanes[i], self.streams[i]
-        if st is None:
-            return lane(images, labels, depth)
+        lane, st = self.lanes[self._next], self.streams[self._next]
         images = images.to(self.device)
         labels = labels.to(self.device)
         depth = None if depth is None else depth.to(self.device)
-        st.wait_stream(torch.cuda.current_stream(self.device))          # the caller's batch is complete before the lane copies it
-        with torch.cuda.stream(st), ops.launch_flags(throughput=True):      # launch shapes for kernels that share the GPU (see uest.py)
-            out = lane(images, labels, depth)
+        if self._staged and (self._staged[0][0].shape != images.shape or (self._staged[0][1] is None) != (depth is None)):
+            self._launch()                                              # a batch of another shape: evaluate what is staged first
+            lane, st = self.lanes[self._next], self.streams[self._next]
+        k = len(self._staged)
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream(self.device))      # the caller's batch is complete before the lane copies it
+        with self._on_lane(), torch.no_grad():
+            # the lane takes its copy now: straight into slot k of the graph's input buffer once that graph exists
+            like = (images, labels) if depth is None else (images, depth, labels)
+            n = images.shape[0]
+            static = lane.static_inputs(like, (n,) * self.group) if self.group > 1 and lane.use_graph else None
+            if static is not None and all(b[3] for b in self._staged):
+                sl = slice(k * n, (k + 1) * n)
+                static[0][sl].copy_(images)
+                static[-1][sl].copy_(labels)
+                if depth is not None:
+                    static[1][sl].copy_(depth)
+                self._staged.append((static[0][sl], None if depth is None else static[1][sl], static[-1][sl], True))
+            elif self.group == 1:
+                self._staged.append((images, depth, labels, False))      # launched below, before this call returns
+            else:
+                self._staged.append((images.clone(), None if depth is None else depth.clone(), labels.to(torch.int64).clone(), False))
         for t in (images, labels, depth):
-            if t is not None:
+            if t is not None and st is not None:
                 t.record_stream(st)
-        return out
+        if len(self._staged) == self.group:
+            self._launch()
+        return lane.acc
+
+    def _launch(self):
+        lane, st = self.lanes[self._next], self.streams[self._next]
+        staged, self._staged = self._staged, []
+        self._next = (self._next + 1) % len(self.lanes)
+        splits = tuple(int(b[0].shape[0]) for b in staged)
+        with self._on_lane(), ops.launch_flags(throughput=True):          # launch shapes for kernels that share the GPU (see uest.py)
+            if len(staged) == 1:
+                images, depth, labels = staged[0][:3]
+            elif all(b[3] for b in staged) and len(staged) == self.group:
+                like = staged[0][:3] if staged[0][1] is not None else (staged[0][0], staged[0][2])
+                static = lane.static_inputs(like, splits)                 # the slots the batches were copied into: no further copy
+                images, labels = static[0], static[-1]
+                depth = static[1] if staged[0][1] is not None else None
+            else:
+                images = torch.cat([b[0] for b in staged])
+                labels = torch.cat([b[2] for b in staged])
+                depth = torch.cat([b[1] for b in staged]) if staged[0][1] is not None else None
+            lane(images, labels, depth, splits=splits)
 
     def sums(self):
         self._join()
@@ -214,13 +285,14 @@ class PipelinedEvalPass(EvalSums):
 
 
 def val_seg_ue(model, dataset_loader, criterion=None, num_classes=21, device='cuda', use_depth=False, add_criterion=None,
-               greenhouse_use_trav=False, use_graph=True, pre_sharded=False, _eval_pass=None, lanes=3):
+               greenhouse_use_trav=False, use_graph=True, pre_sharded=False, _eval_pass=None, lanes=3, group=2):
     """Drop-in for utilities/train_eval_seg.py:249-324: returns (iou, average loss) ((iou, 0) without a criterion).
 
     criterion: a SegmentationLoss-like object -- its `class_wts` / `class_weights` and `ignore_idx` are read (loss_type 'ce'); None
     evaluates the MIOU only.  add_criterion (the NID term of the supervised loop) has no fused form and is refused.
     One process per GPU: rank r takes batches b == r (mod world) unless the loader is pre_sharded; every rank returns the same result.
-    lanes: evaluation steps in flight on the GPU (PipelinedEvalPass; 1 = one graph replay after the other)."""
+    lanes: evaluation steps in flight on the GPU (PipelinedEvalPass; 1 = one graph replay after the other); group: consecutive
+    batches per launch of a lane."""
     if add_criterion is not None:
         raise NotImplementedError('mspl_amd: val_seg_ue(add_criterion=...) is not on the path (the shipped scripts pass None)')
     cw = ign = None
@@ -235,7 +307,7 @@ def val_seg_ue(model, dataset_loader, criterion=None, num_classes=21, device='cu
     if _eval_pass is not None:
         ep = _eval_pass
     elif use_graph and lanes > 1:
-        ep = PipelinedEvalPass(model, num_classes, depth=lanes, class_weights=cw, ignore_idx=255 if ign is None else ign, aux_weight=0.5,
+        ep = PipelinedEvalPass(model, num_classes, depth=lanes, group=group, class_weights=cw, ignore_idx=255 if ign is None else ign, aux_weight=0.5,
                                device=device)
     else:
         ep = EvalPass(model, num_classes, class_weights=cw, ignore_idx=255 if ign is None else ign, aux_weight=0.5, device=device,

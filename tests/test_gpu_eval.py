@@ -113,18 +113,19 @@ def test_eval_pass_graph_equals_eager_and_reset():
     assert torch.equal(b.areas, c.areas)
 
 
-def test_pipelined_eval_pass_equals_one_lane():
+@pytest.mark.parametrize('depth,group', [(3, 1), (3, 2), (2, 3)])
+def test_pipelined_eval_pass_equals_one_lane(depth, group):
     """Three evaluation steps in flight (PipelinedEvalPass, what val_seg_ue runs) give the sums of one lane: areas exactly, the loss sums
     to float64 rounding; batches of two shapes (a short last batch), reset, and the tensors handed in may be reused at once."""
     from mspl_amd import evaluation as ev
     C = 5
     m, _ = _model(C, 'greenhouse', 72)
     g = torch.Generator().manual_seed(10)
-    shapes = [(4, 64, 96)] * 7 + [(2, 64, 96)]
+    shapes = [(4, 64, 96)] * 7 + [(2, 64, 96)]       # (with group > 1: a partly filled lane and a ragged batch at the end)
     xs = [torch.randn(n, 3, h, w, generator=g) for n, h, w in shapes]
     ys = [torch.randint(0, C, (n, h, w), generator=g) for n, h, w in shapes]
     one = ev.EvalPass(m, C, class_weights=torch.rand(C, generator=g) + 0.5, ignore_idx=4, device=DEV, use_graph=True)
-    three = ev.PipelinedEvalPass(m, C, depth=3, class_weights=one.cw, ignore_idx=4, device=DEV)
+    three = ev.PipelinedEvalPass(m, C, depth=depth, group=group, class_weights=one.cw, ignore_idx=4, device=DEV)
     buf_x, buf_y = torch.empty(4, 3, 64, 96, device=DEV), torch.empty(4, 64, 96, dtype=torch.int64, device=DEV)
     for rep in range(2):
         for x, y in zip(xs, ys):
