@@ -11,8 +11,9 @@ One step = one batch through the whole path; inputs are resident in HBM before t
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel = eesp_dw_hff (K2): algorithmic bytes per launch / mean launch time,
-               measured with HIP events on the launch stream inside this process.
+  roofline     dominant kernel = eesp_dw_exp (K2 + K3 of the stride-1 EESP blocks in one launch): matrix FLOPs per launch /
+               mean launch time against the fp32 MFMA peak (+ its bytes against the HBM roof), measured with HIP events on the
+               launch stream inside this process; roofline_k2 = the standalone K2 launches that remain (HBM).
   cpu_baseline the CPU oracle (oracle/, a port of the reference's torch path) timed on the host cores on a
                bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -258,6 +259,8 @@ def three_source_rate(dev, iters=20):
     return out
 
 
+SUPERVISED_BYTES_PER_IMAGE = 947.7e6     # tools/train_bytes.py 13 288 480: the same accounting for C=13 at 288x480
+EVAL_BYTES_PER_IMAGE = 306.7e6           # forward of the C=5 model at 256x480 (305.7 MB, tools/train_bytes.py) + the int64 labels (8 B / pixel)
 TRAIN_BYTES_PER_IMAGE = 820.5e6          # DESIGN.md section 7 / tools/train_bytes.py: forward (305.7 MB, = SURVEY 8(d)'s 306.9) + data-gradient + weight-gradient
                                          # passes per image in SURVEY 8(d)'s accounting (weighted layers 3x their forward bytes, weightless ones 2x), C=5, 256x480
 
@@ -369,7 +372,12 @@ def eval_step_rate(dev, iters=20):
         res[name] = {'value': round(BATCH / dt, 1), 'ms_per_batch': round(dt * 1e3, 3), 'batches': n, 'loss_finite': bool(np_isfinite(loss)),
                      'pixels_counted': int(ep.sums()[2 * ep.K:3 * ep.K].sum().item())}
     best = res['lanes_3x2']
+    for r_ in res.values():
+        gbs = EVAL_BYTES_PER_IMAGE * r_['value'] / 1e9
+        r_['roofline'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
     return {'value': best['value'], 'unit': 'images/s', 'ms_per_batch': best['ms_per_batch'], 'batches': best['batches'],
+            'roofline': dict(best['roofline'], algorithmic_bytes_per_image=EVAL_BYTES_PER_IMAGE,
+                             accounting='SURVEY 8(d): the forward\'s convolutions as in + out (305.7 MB, tools/train_bytes.py 5 256 480) + the labels'),
             'workload': 'val_seg_ue step, ESPDNet-UE s=2.0 C=5, bs=16 x 3 x 256 x 480 fp32: forward + out+0.5*aux + weighted CE + MIOU '
                         'areas, hipGraph replays, 3 launches in flight x 2 consecutive batches per launch (what val_seg_ue runs; per-batch '
                         'loss means and meter updates as in the reference loop)',
@@ -406,7 +414,13 @@ def supervised_step_rate(dev, iters=6):
         loss, _ = step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    achieved = SUPERVISED_BYTES_PER_IMAGE * BATCH / dt / 1e9
     return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
+            'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_image': SUPERVISED_BYTES_PER_IMAGE, 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'accounting': 'tools/train_bytes.py 13 288 480 (the train step\'s accounting: forward + data gradient + weight '
+                                       'gradient of every weighted layer, BatchNorm / PReLU = 0 -- the batch-statistics pass over every '
+                                       'convolution result, which this mode needs on top, is NOT counted)'},
             'workload': 'train_seg_ue iteration, ESPDNet-UE s=2.0 C=13 in train() (batch-statistics BN), bs=16 x 3 x 288 x 480 fp32, '
                         'CrossEntropy + flooding + SGD(2 lr groups), hipGraph replay + SGD kernels',
             'loss_finite': bool(torch.isfinite(loss))}
@@ -612,31 +626,58 @@ def main():
         del solo
     x = xs[0]
 
-    # ---- roofline of the dominant kernel (K2): HIP events on the launch stream.  The 13 K2 launches of one
-    # forward are recorded (same tensors, same shapes), then each is re-issued REPS times back to back between one
-    # event pair while the stream is parked behind a spin kernel, so the interval is device execution (kernel +
-    # launch boundary), not the host's launch cadence.  avg launch = sum over the 13 shapes of (interval / REPS) / 13.
-    calls = []
-    real = ops.eesp_dw_hff
+    # ---- roofline of the dominant kernels: the EESP depthwise family.  Round 4: the ten stride-1 blocks run K2 + K3 as ONE launch
+    # (ops.eesp_dw_exp, csrc/eesp_exp.hip: the dominant kernel of a pass, ~24 % of its kernel time), the three strided blocks keep
+    # the standalone K2 launch (ops.eesp_dw_hff).  Both kinds are recorded in one eager pass (same tensors, same shapes), re-issued
+    # REPS times back to back between one event pair (stream parked behind a spin kernel) for the isolated figure, and timed IN the
+    # pass with an event pair around every launch.
+    MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32; = the fp32 vector peak)
+    calls = []              # (kind, fn, args, kwargs)
+    real_k2, real_exp = ops.eesp_dw_hff, ops.eesp_dw_exp
 
     def record_k2(*a_, **kw):
-        r = real(*a_, **kw)
-        calls.append((a_, dict(kw, out=(r, 0))))
+        r = real_k2(*a_, **kw)
+        calls.append(('k2', real_k2, a_, dict(kw, out=(r, 0))))
+        return r
+
+    def record_exp(*a_, **kw):
+        r = real_exp(*a_, **kw)
+        calls.append(('exp', real_exp, a_, kw))
         return r
     eager = uest.SelfLabelPass(model, classes=CLASSES, device=dev, use_graph=False)
     from mspl_amd import layers as L
-    L.ops.eesp_dw_hff = record_k2
+    L.ops.eesp_dw_hff, L.ops.eesp_dw_exp = record_k2, record_exp
     try:
-        with ops.launch_flags(throughput=True):        # the lanes' launch shapes: K1 and K2 as two launches (without it the stride-1 blocks use the fused K1+K2 launch)
+        with ops.launch_flags(throughput=True):        # the lanes' launch shapes
             eager(x)
         torch.cuda.synchronize()
     finally:
-        L.ops.eesp_dw_hff = real
+        L.ops.eesp_dw_hff, L.ops.eesp_dw_exp = real_k2, real_exp
+
+    def call_bytes(c, mult=1):
+        """Algorithmic bytes of one launch.  K2: 4*n*(H*W + 4*Ho*Wo) per image.  Fused K2 + K3: what the launch has to
+        move -- read the reduced tensor (n) and the residual (4n), write the result (4n): 4*9n*H*W per image (the two launches it
+        replaces: 4*17n*H*W with the residual, 4*13n*H*W by SURVEY 8d's convention of counting a convolution as in + out)."""
+        kind, _, a_, kw = c
+        n_, ch_, hi_, wi_ = a_[0].shape
+        if kind == 'exp':
+            return mult * 4 * n_ * 9 * ch_ * hi_ * wi_
+        st_ = a_[3] if len(a_) > 3 else kw.get('stride', 1)
+        ho_, wo_ = (hi_ - 1) // st_ + 1, (wi_ - 1) // st_ + 1
+        return mult * 4 * n_ * ch_ * (hi_ * wi_ + 4 * ho_ * wo_)
+
+    def call_flops(c, mult=1):
+        kind, _, a_, _ = c
+        if kind != 'exp':
+            return 0
+        n_, ch_, hi_, wi_ = a_[0].shape
+        return mult * 2 * n_ * hi_ * wi_ * 4 * ch_ * ch_          # the grouped expansion: 4n outputs x n inputs per pixel
+
     REPS = 20
-    k2_ms = []
-    for a_, kw in calls:
+    iso_ms = []
+    for _, fn, a_, kw in calls:
         for _ in range(2):
-            real(*a_, **kw)
+            fn(*a_, **kw)
         torch.cuda.synchronize()
         best = None
         for _ in range(3):
@@ -644,72 +685,57 @@ def main():
             torch.cuda._sleep(2_000_000)
             e0.record()
             for _ in range(REPS):
-                real(*a_, **kw)
+                fn(*a_, **kw)
             e1.record()
             torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / REPS
             best = t if best is None or t < best else best
-        k2_ms.append(best)
-    def k2_bytes_of(cs):
-        tot = 0
-        for a_, kw in cs:
-            n_, ch_, hi_, wi_ = a_[0].shape
-            st_ = a_[3] if len(a_) > 3 else kw.get('stride', 1)
-            ho_, wo_ = (hi_ - 1) // st_ + 1, (wi_ - 1) // st_ + 1
-            tot += 4 * n_ * ch_ * (hi_ * wi_ + 4 * ho_ * wo_)
-        return tot
-    # algorithmic bytes of the launches that were actually recorded (4*n*(H*W + 4*Ho*Wo) per image and block); the walk over
-    # the model's EESP blocks is the cross-check (a mismatch is reported in the line, it does not cost the line)
-    k2_bytes, k2_launches = 0, len(calls)
-    for a_, kw in calls:
-        n_, ch_, hi_, wi_ = a_[0].shape
-        st_ = a_[3] if len(a_) > 3 else kw.get('stride', 1)
-        ho_, wo_ = (hi_ - 1) // st_ + 1, (wi_ - 1) // st_ + 1
-        k2_bytes += 4 * n_ * ch_ * (hi_ * wi_ + 4 * ho_ * wo_)
+        iso_ms.append(best)
+    k2_launches = len(calls)
+    n_exp = sum(1 for c in calls if c[0] == 'exp')
     model_bytes, model_launches = k2_algorithmic_bytes(model, BATCH, H, W)
-    k2_note = ('ten of the 13 launches are the stride-1 blocks of levels 3 / 4: 44 and 22 MB per launch.  A kernel that only moves those bytes '
-               '(tools/ubench/floor.hip, profiles/r02_k2_movement_floor.txt) takes 6.1 / 4.0 us with write-through stores = 0.91 / 0.69 of '
-               '8 TB/s (10.0 / 6.1 us = 0.55 / 0.45 with plain stores) on warm caches with nothing else to do, and an empty launch 2.2 us: 0.70 '
-               'for the 13-launch average is not reachable at batch 16; a register-streaming form of the stride-1 launches was built and '
-               'measured slower (DESIGN 4c); the stride-2 launches run at 0.47 in the pass (0.64 alone) in their streaming form')
-    if not (model_launches == k2_launches and model_bytes == k2_bytes):
-        k2_note += '; recorded %d K2 launches / %d bytes, the model walk gives %d / %d' % (k2_launches, k2_bytes, model_launches, model_bytes)
+    family_note = ('%d of the %d launches are the fused K2 + K3 launches of the stride-1 blocks (levels 3 / 4), bounded by the SIMD issue '
+                   'the fp32 MFMAs and the depthwise vector work share (measured: the two do not overlap on a SIMD), not by HBM; the other %d '
+                   'are the strided blocks\' standalone K2 launches (streaming / direct form), HBM-side' % (n_exp, k2_launches, k2_launches - n_exp))
+    if model_launches != k2_launches:
+        family_note += '; recorded %d launches, the model walk gives %d' % (k2_launches, model_launches)
 
     # ---- the same launches timed IN the pass: one eager label pass, the stream parked behind a spin kernel (so the host's launch
-    # cadence is out of the picture), a HIP event pair around every K2 launch.  An event pair adds its own time to what it brackets;
+    # cadence is out of the picture), a HIP event pair around every launch.  An event pair adds its own time to what it brackets;
     # that overhead is calibrated PER SHAPE on the isolated kernel: (event pair around ONE warm launch) - (back-to-back time per
-    # launch of the same kernel, measured above), and subtracted.  This is the number rocprofv3's in-pass average must agree with
-    # (profiles/r03_kernel_stats_inflight1.csv): inputs come from the producer kernel through L2 / Infinity Cache / HBM as in the
-    # real pass, not from 20 warm re-issues.
+    # launch of the same kernel, measured above), and subtracted.  This is the number rocprofv3's in-pass average must agree with:
+    # inputs come from the producer kernel through L2 / Infinity Cache / HBM as in the real pass, not from 20 warm re-issues.
     def pair_overhead():
         ovh = []
-        for (a_, kw), b2b in zip(calls, k2_ms):
+        for (_, fn, a_, kw), b2b in zip(calls, iso_ms):
             ts = []
             for _ in range(5):
-                real(*a_, **kw)
+                fn(*a_, **kw)
                 torch.cuda._sleep(2_000_000)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                real(*a_, **kw)
+                fn(*a_, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             ovh.append(max(0.0, sorted(ts)[len(ts) // 2] - b2b))
         return ovh
 
-    def k2_in_pass(mult, ovh, passes=7):
+    def family_in_pass(mult, ovh, passes=7):
         xin = x if mult == 1 else torch.cat([x] * mult, 0)
         per_pass = []
         rec = []
 
-        def timed_k2(*a_, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = real(*a_, **kw)
-            e1.record()
-            rec.append((e0, e1))
-            return r
-        L.ops.eesp_dw_hff = timed_k2
+        def timed(fn):
+            def run(*a_, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = fn(*a_, **kw)
+                e1.record()
+                rec.append((e0, e1))
+                return r
+            return run
+        L.ops.eesp_dw_hff, L.ops.eesp_dw_exp = timed(real_k2), timed(real_exp)
         try:
             with L.side_streams(False), ops.launch_flags(throughput=True):
                 eager(xin)                                  # allocator / caches warm for this batch size
@@ -721,35 +747,49 @@ def main():
                     torch.cuda.synchronize()
                     per_pass.append([e0.elapsed_time(e1) for e0, e1 in rec])
         finally:
-            L.ops.eesp_dw_hff = real
+            L.ops.eesp_dw_hff, L.ops.eesp_dw_exp = real_k2, real_exp
         n = len(per_pass[0])
         return [sorted(pp[i] for pp in per_pass)[len(per_pass) // 2] - ovh[i] for i in range(n)]
+
+    def summarise(ms, mult=1):
+        """Per kind: launches, average launch time, bytes / flops over the summed time."""
+        res = {}
+        for kind in ('exp', 'k2', 'all'):
+            idx = [i for i, c in enumerate(calls) if kind == 'all' or c[0] == kind]
+            if not idx:
+                continue
+            t_s = sum(ms[i] for i in idx) * 1e-3
+            by = sum(call_bytes(calls[i], mult) for i in idx)
+            fl = sum(call_flops(calls[i], mult) for i in idx)
+            res[kind] = {'launches': len(idx), 'avg_launch_us': round(t_s / len(idx) * 1e6, 3), 'gbs': round(by / t_s / 1e9, 1),
+                         'tflops': round(fl / t_s / 1e12, 2), 'bytes_per_launch': int(by / len(idx)),
+                         'per_launch_us': [round(ms[i] * 1e3, 2) for i in idx]}
+        return res
+    iso = summarise(iso_ms)
     in_pass = {}
+    ovh = None
     if rank == 0:
         try:
             ovh = pair_overhead()
         except Exception as e_:      # noqa: BLE001
-            ovh = None
             in_pass[1] = {'error': repr(e_)[:200]}
         for mult in ((1, group) if group > 1 else (1,)) if ovh is not None else ():
             try:
-                med = k2_in_pass(mult, ovh)
-                avg_s = sum(med) / len(med) * 1e-3
-                in_pass[mult] = {'avg_launch_us': round(avg_s * 1e6, 3), 'event_pair_overhead_us': round(sum(ovh) / len(ovh) * 1e3, 3),
-                                 'achieved': round(mult * k2_bytes_of(calls) / len(med) / avg_s / 1e9, 1),
-                                 'per_launch_us': [round(v * 1e3, 2) for v in med]}
+                in_pass[mult] = summarise(family_in_pass(mult, ovh), mult)
+                in_pass[mult]['event_pair_overhead_us'] = round(sum(ovh) / len(ovh) * 1e3, 3)
             except Exception as e_:      # noqa: BLE001
                 in_pass[mult] = {'error': repr(e_)[:200]}
 
-    # The same 13 K2 launches at 4x the batch ("report K2 at bs=16 and bs=64"): at bs=16 seven of the
-    # thirteen launches move 22 MB each and are bounded by launch ramp + two memory round trips, not by bandwidth.
+    # The standalone K2 launches at 4x the batch (SURVEY.md 8d: "report K2 at bs=16 and bs=64").
     k2_ms64 = []
     if rank == 0 and not args.no_bs64:
-        for a_, kw in calls:
+        for kind, fn, a_, kw in calls:
+            if kind != 'k2':
+                continue
             xin64 = torch.cat([a_[0]] * 4, 0)
             kw64 = {k: v for k, v in kw.items() if k != 'out'}
             for _ in range(2):
-                real(xin64, *a_[1:], **kw64)
+                fn(xin64, *a_[1:], **kw64)
             torch.cuda.synchronize()
             best = None
             for _ in range(3):
@@ -757,48 +797,60 @@ def main():
                 torch.cuda._sleep(2_000_000)
                 e0.record()
                 for _ in range(REPS):
-                    real(xin64, *a_[1:], **kw64)
+                    fn(xin64, *a_[1:], **kw64)
                 e1.record()
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / REPS
                 best = t if best is None or t < best else best
             k2_ms64.append(best)
             del xin64
-    avg64_s = (sum(k2_ms64) / len(k2_ms64)) * 1e-3 if k2_ms64 else None
-    # HBM bytes per K2 launch from the PMC counters (FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as
-    # the MI355X guide prescribes; tools/k2_traffic.py writes the summary).  bench.py cannot run rocprofv3 on itself.
-    k2_traffic, k2_traffic_src = None, None
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as the MI355X
+    # guide prescribes; tools/k2_traffic.py writes the summary).  bench.py cannot run rocprofv3 on itself.
     def newest(names):
         for n in names:
             if os.path.exists(os.path.join(ROOT, 'profiles', n)):
                 return n
         return None
-    tname = newest(['r03_k2_hbm_traffic.json', 'r02_k2_hbm_traffic.json', 'r01_k2_hbm_traffic.json'])
+    fam_traffic = {}
+    tname = newest(['r04_k2_hbm_traffic.json'])
     if tname:
-        k2_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', tname)))['avg_traffic_bytes_per_launch'])
-        k2_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % tname
+        tj = json.load(open(os.path.join(ROOT, 'profiles', tname)))
+        fam_traffic = {'exp': tj.get('fused_avg_traffic_bytes_per_launch'), 'k2': tj.get('standalone_avg_traffic_bytes_per_launch'),
+                       'source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % tname}
     # measured HBM bytes of one whole pass (every kernel; tools/pass_traffic.py, same PMC recipe)
     path_traffic, path_traffic_src = None, None
-    pname = newest(['r03_pass_hbm_traffic.json', 'r02_pass_hbm_traffic.json', 'r01_m_pass_hbm_traffic.json'])
+    pname = newest(['r04_pass_hbm_traffic.json', 'r03_pass_hbm_traffic.json', 'r02_pass_hbm_traffic.json'])
     if pname:
         path_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', pname)))['total_MB_per_image'] * 1e6)
         path_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)' % pname
     # the same kernels' average duration in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --profile-pass
     # --in-flight 1` (label passes only): the figure the live in-pass measurement has to agree with
-    k2_rocprof_us, k2_rocprof_src = None, None
-    cname = newest(['r03_kernel_stats_inflight1.csv', 'r02_b_kernel_stats_inflight1.csv'])
+    rocprof_us, rocprof_src = {}, None
+    cname = newest(['r04_kernel_stats_inflight1.csv'])
     if cname:
         import csv
-        tot_ns, tot_calls = 0.0, 0
+        acc_ = {'exp': [0.0, 0], 'k2': [0.0, 0]}
         for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', cname))):
-            if any(k in row['Name'] for k in ('eesp_dw_hff_kernel', 'eesp_dw_direct_kernel', 'eesp_dw_stream2_kernel')):
-                tot_ns += float(row['TotalDurationNs'])
-                tot_calls += int(row['Calls'])
-        if tot_calls:
-            k2_rocprof_us = round(tot_ns / tot_calls / 1e3, 3)
-            k2_rocprof_src = 'profiles/%s (%d K2 launches)' % (cname, tot_calls)
-    avg_launch_s = (sum(k2_ms) / len(k2_ms)) * 1e-3
-    achieved = (k2_bytes / k2_launches) / avg_launch_s / 1e9
+            kind = 'exp' if 'eesp_dw_exp_kernel' in row['Name'] else ('k2' if any(k in row['Name'] for k in ('eesp_dw_hff_kernel', 'eesp_dw_direct_kernel', 'eesp_dw_stream2_kernel')) else None)
+            if kind:
+                acc_[kind][0] += float(row['TotalDurationNs'])
+                acc_[kind][1] += int(row['Calls'])
+        rocprof_us = {k: round(v[0] / v[1] / 1e3, 3) for k, v in acc_.items() if v[1]}
+        rocprof_src = 'profiles/%s' % cname
+
+    def roof_exp(sm):
+        return None if not sm or 'exp' not in sm else {
+            'bound': 'mfma', 'achieved': sm['exp']['tflops'], 'peak': MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+            'frac': round(sm['exp']['tflops'] / MFMA_PEAK_TF, 4), 'avg_launch_us': sm['exp']['avg_launch_us'],
+            'launches': sm['exp']['launches'], 'algorithmic_bytes_per_launch': sm['exp']['bytes_per_launch'],
+            'hbm_view': {'achieved': sm['exp']['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sm['exp']['gbs'] / HBM_PEAK_GBS, 4)},
+            'per_launch_us': sm['exp']['per_launch_us']}
+
+    def roof_k2(sm):
+        return None if not sm or 'k2' not in sm else {
+            'bound': 'hbm', 'achieved': sm['k2']['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(sm['k2']['gbs'] / HBM_PEAK_GBS, 4),
+            'avg_launch_us': sm['k2']['avg_launch_us'], 'launches': sm['k2']['launches'],
+            'algorithmic_bytes_per_launch': sm['k2']['bytes_per_launch'], 'per_launch_us': sm['k2']['per_launch_us']}
 
     if rank == 0:
         ip1 = in_pass.get(1, {})
@@ -826,34 +878,46 @@ def main():
                        'per_gpu_batch': BATCH, 'batches_in_flight': depth, 'batches_per_launch': group, 'input': [BATCH, 3, H, W],
                        'classes': CLASSES,
                        'sharding': 'image list sharded by rank, no data-path collective'},
-            # `roofline` = the IN-PASS launch time (what rocprofv3 sees inside a label pass); the isolated warm re-issue figure of
-            # rounds 1-2 stays beside it as roofline_isolated
-            'roofline': {'bound': 'hbm', 'kernel': 'eesp_dw_hff (K2: eesp_dw_hff_kernel + eesp_dw_direct_kernel + eesp_dw_stream2_kernel, %d launches/forward)' % k2_launches,
-                         'achieved': ip1.get('achieved', round(achieved, 1)), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ip1.get('achieved', achieved) / HBM_PEAK_GBS, 4), 'traffic': k2_traffic,
-                         'traffic_source': k2_traffic_src,
-                         'algorithmic_bytes_per_launch': int(k2_bytes / k2_launches), 'accounting_note': k2_note,
-                         'avg_launch_us': ip1.get('avg_launch_us', round(avg_launch_s * 1e6, 3)),
-                         'timing': ('HIP event pair around each K2 launch of one eager pass at batch 16 (stream parked behind a spin kernel; the '
-                                    'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 7 passes); '
-                                    'rocprofv3 in the same pass: rocprof_avg_launch_us' if 'achieved' in ip1 else
-                                    'isolated re-issues (in-pass measurement failed: %s)' % ip1.get('error')),
-                         'event_pair_overhead_us': ip1.get('event_pair_overhead_us'), 'per_launch_us': ip1.get('per_launch_us'),
-                         'rocprof_avg_launch_us': k2_rocprof_us, 'rocprof_source': k2_rocprof_src},
-            'roofline_isolated': {'kernel': 'same 13 launches, each re-issued 20x back to back on warm tensors (best of 3)',
-                                  'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                  'frac': round(achieved / HBM_PEAK_GBS, 4), 'avg_launch_us': round(avg_launch_s * 1e6, 3)},
-            'roofline_bs%d' % (BATCH * group): None if (group == 1 or 'achieved' not in in_pass.get(group, {})) else {
-                'kernel': 'eesp_dw_hff (K2) in-pass at the batch the lanes launch (%d consecutive batches of 16 per launch)' % group,
-                'achieved': in_pass[group]['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(in_pass[group]['achieved'] / HBM_PEAK_GBS, 4), 'avg_launch_us': in_pass[group]['avg_launch_us'],
-                'per_launch_us': in_pass[group]['per_launch_us']},
+            # `roofline` = the dominant kernel (the fused K2 + K3 launch) at its IN-PASS launch time; `roofline_k2` = the standalone K2
+            # launches that remain (the strided blocks); `roofline_family` = all thirteen against their bytes, for continuity with
+            # rounds 1-3 (whose `roofline` was the thirteen standalone K2 launches: 0.30 of the HBM roof)
+            'roofline': dict(roof_exp(ip1 if 'exp' in ip1 else iso) or {}, **{
+                'kernel': 'eesp_dw_exp (K2 + K3 of a stride-1 EESP block in one launch: depthwise branches -> LDS -> MFMA B operand; '
+                          '%d launches/forward, the dominant kernel of a pass)' % n_exp,
+                'traffic': fam_traffic.get('exp'), 'traffic_source': fam_traffic.get('source'),
+                'accounting_note': family_note + '.  achieved = the expansion\'s matrix FLOPs (2 * 4n * n per pixel) / launch time; the depthwise '
+                                   'vector work (36 FMAs per reduced channel and pixel) runs on the same SIMD issue and is not counted; '
+                                   'hbm_view = 4 * 9n * H * W bytes per image / launch time',
+                'timing': ('HIP event pair around each launch of one eager pass at batch 16 (stream parked behind a spin kernel; the '
+                           'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 7 passes); '
+                           'rocprofv3 in the same kind of pass: rocprof_avg_launch_us' if 'exp' in ip1 else
+                           'isolated re-issues (in-pass measurement failed: %s)' % ip1.get('error')),
+                'event_pair_overhead_us': ip1.get('event_pair_overhead_us'),
+                'rocprof_avg_launch_us': rocprof_us.get('exp'), 'rocprof_source': rocprof_src}),
+            'roofline_k2': dict(roof_k2(ip1 if 'k2' in ip1 else iso) or {}, **{
+                'kernel': 'eesp_dw_hff (standalone K2: eesp_dw_stream2_kernel + eesp_dw_direct_kernel, the strided blocks)',
+                'traffic': fam_traffic.get('k2'), 'traffic_source': fam_traffic.get('source'),
+                'rocprof_avg_launch_us': rocprof_us.get('k2'), 'rocprof_source': rocprof_src}),
+            'roofline_family': None if 'all' not in ip1 else {
+                'kernel': 'all %d EESP depthwise launches of a forward (fused + standalone) against their algorithmic bytes' % k2_launches,
+                'bound': 'hbm', 'achieved': ip1['all']['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(ip1['all']['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_us': ip1['all']['avg_launch_us'],
+                'algorithmic_bytes_per_launch': ip1['all']['bytes_per_launch'],
+                'note': 'rounds 1-3: 13 standalone K2 launches, 34.4 MB and 14.2 us per launch = 0.30; the concatenation K2 wrote and K3 read '
+                        'back (4 * 8n * H * W bytes per image and block) no longer exists'},
+            'roofline_isolated': {'kernel': 'the same launches, each re-issued 20x back to back on warm tensors (best of 3)',
+                                  'fused': roof_exp(iso), 'k2': roof_k2(iso)},
+            'roofline_bs%d' % (BATCH * group): None if (group == 1 or 'exp' not in in_pass.get(group, {})) else {
+                'kernel': 'in-pass at the batch the lanes launch (%d consecutive batches of 16 per launch)' % group,
+                'fused': roof_exp(in_pass[group]), 'k2': roof_k2(in_pass[group])},
+            'roofline_bs64': None if not k2_ms64 else {
+                'kernel': 'standalone K2, same shapes at batch 64 (isolated)',
+                'achieved': round(4 * sum(call_bytes(c) for c in calls if c[0] == 'k2') / (sum(k2_ms64) * 1e-3) / 1e9, 1),
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(4 * sum(call_bytes(c) for c in calls if c[0] == 'k2') / (sum(k2_ms64) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'avg_launch_us': round(sum(k2_ms64) / len(k2_ms64) * 1e3, 3)},
             # the whole hot path against SURVEY section 8(d)'s algorithmic activation traffic (356.9 MB/image at 288x480,
             # convs as in+out, the EESP branches as one shared read, BN/PReLU/add/cat fused = 0)
-            'roofline_bs64': None if avg64_s is None else {
-                'kernel': 'eesp_dw_hff (K2), same 13 shapes at batch 64', 'achieved': round(4 * k2_bytes / k2_launches / avg64_s / 1e9, 1),
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(4 * k2_bytes / k2_launches / avg64_s / 1e9 / HBM_PEAK_GBS, 4),
-                'avg_launch_us': round(avg64_s * 1e6, 3)},
             'single_in_flight': single,
             'path_roofline': {'algorithmic_bytes_per_image': PATH_BYTES_PER_IMAGE, 'traffic_bytes_per_image': path_traffic,
                               'traffic_source': path_traffic_src,
@@ -861,7 +925,7 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        pk = os.path.join(ROOT, 'profiles', newest(['r03_per_kernel.json', 'r02_per_kernel.json']) or 'none')
+        pk = os.path.join(ROOT, 'profiles', newest(['r04_per_kernel.json', 'r03_per_kernel.json']) or 'none')
         if os.path.exists(pk):
             # per-kernel table of one label pass (us, MB, fraction of the HBM roof), from a rocprofv3 --kernel-trace --stats run of
             # `bench.py --profile-pass --in-flight 1` (no K2 re-issues in it) + the PMC traffic passes; tools/per_kernel.py

@@ -232,3 +232,42 @@ def bench_expx():
 
 if len(sys.argv) > 1 and sys.argv[1] == 'expx':
     bench_expx()
+
+
+def bench_k2_cold():
+    """The large strided K2 launch with WARM caches (re-issued back to back: its input and output fit the 256 MB Infinity Cache) and
+    with COLD ones (a 1 GB buffer is rewritten before every launch): explains the in-pass / isolated gap of that launch."""
+    for N in (16, 32):
+        n, h, w, stride, dil = 24, 144, 240, 2, [1, 2, 3, 4]
+        x = torch.randn(N, n, h, w, device=DEV)
+        w4 = torch.randn(4, n, 3, 3, device=DEV) * 0.2
+        sc, sh, al = torch.rand(4 * n, device=DEV) + 0.5, torch.randn(4 * n, device=DEV), torch.rand(4 * n, device=DEV) * 0.3
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        out = torch.empty(N, 4 * n, ho, wo, device=DEV)
+        ep = Epi(sc, sh, al)
+        big = torch.empty(256 * 1024 * 1024, device=DEV)          # 1 GB
+        res = {}
+        for mode in ('warm', 'cold', 'input-fresh'):
+            ts = []
+            for _ in range(12):
+                if mode == 'cold':
+                    big.fill_(1.0)
+                elif mode == 'input-fresh':
+                    big.fill_(1.0)
+                    x.mul_(1.0)                                   # the producer has just written the input (as in the pass)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(2_000_000)
+                e0.record()
+                ops.eesp_dw_hff(x, w4, dil, stride, ep, out=(out, 0))
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts.sort()
+            res[mode] = ts[len(ts) // 2]
+        by = 4 * N * n * (h * w + 4 * ho * wo)
+        print('L2_0 K2 N=%d (%.0f MB in + out): event-pair time warm %.1f us, cold %.1f us, cold with a freshly written input %.1f us '
+              '(each includes the ~2.7 us of the event pair)' % (N, by / 1e6, res['warm'], res['cold'], res['input-fresh']))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'k2cold':
+    bench_k2_cold()

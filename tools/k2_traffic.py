@@ -12,21 +12,32 @@ import csv, json, sys
 d, out = sys.argv[1], sys.argv[2]
 
 
+FAMILY = ('eesp_dw_hff', 'eesp_dw_direct', 'eesp_dw_stream2', 'eesp_dw_exp')     # round 4: eesp_dw_exp = K2 + K3 of a stride-1 block in one launch
+
+
 def k2_values(counter):
-    rows = csv.DictReader(open('%s/%s_counter_collection.csv' % (d, counter)))
-    return [float(r['Counter_Value']) for r in rows if any(k in r['Kernel_Name'] for k in ('eesp_dw_hff', 'eesp_dw_direct', 'eesp_dw_stream2')) and r['Counter_Name'] == counter]
+    rows = [r for r in csv.DictReader(open('%s/%s_counter_collection.csv' % (d, counter)))
+            if any(k in r['Kernel_Name'] for k in FAMILY) and r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    return [float(r['Counter_Value']) for r in rows], ['eesp_dw_exp' in r['Kernel_Name'] for r in rows]
 
 
-f, w = k2_values('FETCH_SIZE'), k2_values('WRITE_SIZE')
-per_fwd = 13                                      # K2 launches per forward (ESPDNet-UE s=2.0)
-f13, w13 = f[:per_fwd], w[:per_fwd]               # the first forward's 13 launches (every forward repeats them)
+(f, fused), (w, _) = k2_values('FETCH_SIZE'), k2_values('WRITE_SIZE')
+per_fwd = 13                                      # EESP depthwise launches per forward (ESPDNet-UE s=2.0)
+f13, w13, fused = f[:per_fwd], w[:per_fwd], fused[:per_fwd]   # the first forward's 13 launches (every forward repeats them)
 read_b = [2.0 * 1024.0 * v for v in f13]
 write_b = [1024.0 * v for v in w13]
 res = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --no-graph, batch 16 x 3 x 288 x 480',
        'corrections': 'KiB -> bytes; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE exact',
        'launches_per_forward': per_fwd,
        'read_bytes_per_launch': read_b, 'write_bytes_per_launch': write_b,
+       'fused_launch': fused,
        'avg_traffic_bytes_per_launch': (sum(read_b) + sum(write_b)) / per_fwd}
+nf = sum(fused)
+if nf:
+    res['fused_avg_traffic_bytes_per_launch'] = sum(r + w_ for r, w_, f_ in zip(read_b, write_b, fused) if f_) / nf
+if nf < per_fwd:
+    res['standalone_avg_traffic_bytes_per_launch'] = sum(r + w_ for r, w_, f_ in zip(read_b, write_b, fused) if not f_) / (per_fwd - nf)
 json.dump(res, open(out, 'w'), indent=1)
 print('avg HBM traffic per K2 launch: %.2f MB (read %.2f + write %.2f)' % (res['avg_traffic_bytes_per_launch'] / 1e6,
                                                                           sum(read_b) / per_fwd / 1e6, sum(write_b) / per_fwd / 1e6))

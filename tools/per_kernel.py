@@ -21,6 +21,12 @@ def short(n):
 
 
 passes = sum(int(r['Calls']) for r in rows if 'label_epilogue' in r['Name'])
+# Launches that are not part of a pass: the process's ONE-TIME parameter upload / flat-buffer set-up (`__amd_rocclr_copyBuffer`,
+# a constant 882 calls whatever --steps is) and the allocator's fills.  They are listed apart, not divided by the number of passes.
+ONE_TIME = ('__amd_rocclr_copyBuffer', '__amd_rocclr_fillBuffer', 'FillFunctor', 'spin_kernel')
+one_time = [{'kernel': short(r['Name']), 'calls': int(r['Calls']), 'total_us': round(float(r['TotalDurationNs']) / 1e3, 1)}
+            for r in rows if any(k in r['Name'] for k in ONE_TIME)]
+rows = [r for r in rows if not any(k in r['Name'] for k in ONE_TIME)]
 tab, tot = [], 0.0
 for r in rows:
     name = short(r['Name'])
@@ -39,7 +45,8 @@ tab.sort(key=lambda e: -e['us_per_pass'])
 for e in tab:
     e['share'] = round(e['us_per_pass'] / tot, 3)
 res = {'source': 'rocprofv3 --kernel-trace --stats of bench.py --profile-pass --in-flight 1 (bs16, 16x3x288x480), %d passes' % passes,
-       'kernel_us_per_pass': round(tot, 1), 'kernels': tab[:24]}
+       'kernel_us_per_pass': round(tot, 1), 'kernels': tab[:24],
+       'not_in_a_pass': {'note': 'one-time set-up launches of the process (state-dict upload, fills): excluded from the per-pass table', 'rows': one_time}}
 json.dump(res, open(out, 'w'), indent=1)
 print('kernel time per pass: %.1f us over %d passes' % (tot, passes))
 for e in tab[:20]:
