@@ -140,6 +140,17 @@ int mspl_eesp_dw_exp_pack(const float* w4, const float* bscale, const float* bsh
                           int32_t n, int32_t H, int32_t W, const int32_t dil[4], float* packed, void* stream);
 int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H, int32_t W,
                          const mspl_epilogue_t* ep, float* out, void* stream);
+/* The same launch + the NEXT block's proj_1x1 (nn_layers/eesp.py:67 of the following EESP block: grouped 1x1 over the 4n channels
+ * this launch has just produced, + BatchNorm + PReLU) as a second matrix stage on the accumulators: group g's n output rows are
+ * exactly the input channels of the next projection's group g.  next_packed: mspl_eesp_dw_exp_next_pack_floats(n) floats written
+ * by mspl_eesp_dw_exp_next_pack from the next block's proj_1x1 weight (n, n); nscale / nshift / nalpha (n): its folded BatchNorm
+ * and PReLU; rnext (N,n,H,W): the reduced tensor the next block's K2 reads (what mspl_conv1x1_fwd would have produced from `out`;
+ * equal to it up to the summation order of the K = n products: the four K-slices of a group are summed through LDS). */
+int64_t mspl_eesp_dw_exp_next_pack_floats(int32_t n);
+int mspl_eesp_dw_exp_next_pack(const float* w1, int32_t n, float* next_packed, void* stream);
+int mspl_eesp_dw_exp_next_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H, int32_t W,
+                              const mspl_epilogue_t* ep, float* out, const float* next_packed, const float* nscale,
+                              const float* nshift, const float* nalpha, float* rnext, void* stream);
 
 /* AvgPool2d(kernel 3, stride 2, padding 1, count_include_pad) + epilogue.
  *     Replaces nn_layers/eesp.py:115,128 and the image pyramid of :136-140.

@@ -46,6 +46,9 @@ SIGNATURES = {
     'mspl_eesp_dw_exp_pack_floats': [c_i32],
     'mspl_eesp_dw_exp_pack': [c_f32p] * 5 + [c_i32] * 3 + [ctypes.POINTER(c_i32), c_f32p, ctypes.c_void_p],
     'mspl_eesp_dw_exp_fwd': [c_f32p, c_f32p, ctypes.POINTER(c_i32)] + [c_i32] * 4 + [_EP, c_f32p, ctypes.c_void_p],
+    'mspl_eesp_dw_exp_next_pack_floats': [c_i32],
+    'mspl_eesp_dw_exp_next_pack': [c_f32p, c_i32, c_f32p, ctypes.c_void_p],
+    'mspl_eesp_dw_exp_next_fwd': [c_f32p, c_f32p, ctypes.POINTER(c_i32)] + [c_i32] * 4 + [_EP, c_f32p] + [c_f32p] * 5 + [ctypes.c_void_p],
     'mspl_conv1x1_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p, ctypes.c_void_p],
     'mspl_conv3x3_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
                          ctypes.c_void_p],
@@ -150,6 +153,7 @@ def _load():
     lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
     lib.mspl_nid_workspace_floats.restype = ctypes.c_int64
     lib.mspl_eesp_dw_exp_pack_floats.restype = ctypes.c_int64
+    lib.mspl_eesp_dw_exp_next_pack_floats.restype = ctypes.c_int64
     lib.mspl_label_epilogue_hist_workspace_bytes.restype = ctypes.c_int64
     lib.mspl_png_writer_create.restype = ctypes.c_void_p          # a handle
     lib.mspl_png_writer_submit.restype = ctypes.c_int64           # a ticket (or a negative status)

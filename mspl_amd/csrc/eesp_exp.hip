@@ -79,16 +79,33 @@ __global__ void eesp_exp_pack_kernel(const float* __restrict__ w4, const float* 
     }
 }
 
+// The NEXT block's proj_1x1 (grouped 1x1, n outputs, n inputs per group = exactly one group's 4n/4 output rows of this block) as a
+// second matrix stage on the accumulators (see the kernel's epilogue): its weights in the lane order of the A operand of k-step j,
+// np[((g*RTPG + rt)*16 + j)*64 + lane] = w1[g*M1 + (lane & 31)][rt*32 + (j & 3) + 8*(j >> 2) + 4*(lane >> 5)], rows >= M1 = n/4 zero.
+__global__ void eesp_exp_pack_next_kernel(const float* __restrict__ w1, int n, float* __restrict__ np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rtpg = n / 32, m1 = n / 4;
+    if (i >= 4 * rtpg * 16 * 64) return;
+    const int lane = i & 63, j = (i >> 6) & 15, wv = i >> 10;
+    const int rt = wv % rtpg, g = wv / rtpg;
+    const int m = lane & 31;
+    const int k = rt * 32 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+    np[i] = m < m1 ? w1[(size_t)(g * m1 + m) * n + k] : 0.f;
+}
+
 // ------------------------------------------------------------------ the fused kernel
 // Measured on the way (in-kernel s_memrealtime timelines, tools/xe_stamp.sh): a split into four matrix waves + four depthwise
 // waves per workgroup (one of each per SIMD) does NOT overlap the two kinds of work -- the depthwise waves' step got 1.2 us
 // longer exactly while the matrix waves' 1.1 us of v_mfma_f32_32x32x2_f32 ran: the fp32 MFMA runs at the vector rate and holds
 // the SIMD's vector issue.  So every wave does both, and a step costs (vector work) + (matrix work) per SIMD.
-template <int NCH, int W, int TH, int KC, int GPW, class DS>
+template <int NCH, int W, int TH, int KC, int GPW, class DS, bool NEXT>
 __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __restrict__ r, const float* __restrict__ dwp,
                                                              const float* __restrict__ ap, const float* __restrict__ escale,
                                                              const float* __restrict__ eshift, const float* __restrict__ ealpha,
                                                              const float* __restrict__ res, float* __restrict__ out,
+                                                             const float* __restrict__ npw, const float* __restrict__ nscale,
+                                                             const float* __restrict__ nshift, const float* __restrict__ nalpha,
+                                                             float* __restrict__ rnext,
                                                              int H, int bands, int nwg, unsigned long long* __restrict__ stamps) {
     constexpr int MAXD = DS::maxd();
     constexpr int ROWS = TH + 2 * MAXD;
@@ -294,6 +311,61 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
             v0 = v0 > 0.f ? v0 : alv[q] * v0;
             v1 = v1 > 0.f ? v1 : alv[q] * v1;
             if (pok) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
+            if (NEXT) { acc0[rr] = v0; acc1[rr] = v1; }
+        }
+    }
+    if (NEXT) {
+        // ---- the next block's proj_1x1 on what this workgroup holds: group g's n output rows are exactly the input channels of
+        // its group g.  Register j of a lane is row (j & 3) + 8 (j >> 2) + 4 half of the wave's tile at the lane's pixel: as the B
+        // operand of k-step j it pairs two rows of the tile (the weights are packed in that order), so the 32 x 64 tile feeds 16
+        // MFMAs per pixel sub-tile without moving; the RTPG waves of a group each hold a K-slice: their partial tiles are summed
+        // through LDS (the row buffers are free), every wave finishes 16 / RTPG register rows: folded BN, PReLU, 8-byte stores.
+        constexpr int M1 = NCH / 4;
+        constexpr int RPW = 16 / RTPG;                             // accumulator registers a wave finishes
+        float npa[16];
+        {
+            const float* npl = npw + ((size_t)(g * RTPG + rtile) * 16) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) npa[j] = npl[j * 64];
+        }
+        floatx16 p0, p1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { p0[i] = 0.f; p1[i] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(npa[j], acc0[j], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(npa[j], acc1[j], p1, 0, 0, 0);
+        }
+        static_assert(2 * KC * ROWS * RS >= 8 * 16 * 64, "the row buffers hold the eight partial tiles");
+        float* red = &rt_[0][0];
+        float sres[2][RPW];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub) __syncthreads();                              // the first round's sums are read
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) red[(wave * 16 + r2) * 64 + lane] = sub ? p1[r2] : p0[r2];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int r2 = rtile * RPW + q;
+                float t = red[((gl * RTPG) * 16 + r2) * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < RTPG; ++w2) t += red[((gl * RTPG + w2) * 16 + r2) * 64 + lane];
+                sres[sub][q] = t;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r2 = rtile * RPW + q;
+            const int row = (r2 & 3) + 8 * (r2 >> 2) + 4 * half;
+            if (row < M1 && pok) {
+                const int ch = g * M1 + row;
+                const float sc = nscale[ch], sh = nshift[ch], al = nalpha[ch];
+                float v0 = fmaf(sres[0][q], sc, sh), v1 = fmaf(sres[1][q], sc, sh);
+                v0 = v0 > 0.f ? v0 : al * v0;
+                v1 = v1 > 0.f ? v1 : al * v1;
+                *reinterpret_cast<float2*>(rnext + ((size_t)img * NCH + ch) * HW + (size_t)y0 * W + 2 * li) = make_float2(v0, v1);
+            }
         }
     }
 #ifdef MSPL_DEBUG_STAMPS
@@ -349,9 +421,9 @@ extern "C" int mspl_eesp_dw_exp_pack(const float* w4, const float* bscale, const
     return MSPL_OK;
 }
 
-extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H,
-                                    int32_t W, const mspl_epilogue_t* ep, float* out, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int xe_launch(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H, int32_t W,
+                     const mspl_epilogue_t* ep, float* out, const float* next_packed, const float* nscale, const float* nshift,
+                     const float* nalpha, float* rnext, hipStream_t stream) {
     MSPL_REQUIRE(r && packed && dil && ep && out, MSPL_ERR_NULL_POINTER, "eesp_dw_exp: null pointer");
     MSPL_REQUIRE(N >= 1 && H >= 1, MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: N=%d H=%d", N, H);
     if (int rc = check_epi(ep, 4 * n, "eesp_dw_exp")) return rc;
@@ -362,8 +434,12 @@ extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const i
     const XePlan p = xe_plan(n, H, W, dil);
     MSPL_REQUIRE(p.kind != 0, MSPL_ERR_UNSUPPORTED, "eesp_dw_exp: n=%d H=%d W=%d dil=%d,%d,%d,%d not covered", n, H, W, dil[0], dil[1], dil[2], dil[3]);
     MSPL_REQUIRE((((uintptr_t)r | (uintptr_t)out | (uintptr_t)ep->residual | (uintptr_t)packed | (uintptr_t)ep->scale | (uintptr_t)ep->shift |
-                   (uintptr_t)ep->alpha) & 15) == 0, MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: operands must be 16-byte aligned");
+                   (uintptr_t)ep->alpha | (uintptr_t)rnext | (uintptr_t)next_packed) & 15) == 0, MSPL_ERR_BAD_SHAPE,
+                 "eesp_dw_exp: operands must be 16-byte aligned");
     MSPL_REQUIRE((int64_t)N * 4 * n * H * W < (1ll << 31), MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: tensor too large");
+    const bool next = next_packed != nullptr;
+    MSPL_REQUIRE(!next || (nscale && nshift && nalpha && rnext), MSPL_ERR_NULL_POINTER,
+                 "eesp_dw_exp: the next projection needs its packed weights, scale, shift, alpha and a destination");
     const int bands = ceil_div(H, p.TH);
     const int64_t nwg = (int64_t)N * bands * (4 / p.GPW);
     MSPL_REQUIRE(nwg < (1ll << 30), MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: grid too large");
@@ -374,12 +450,13 @@ extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const i
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_XE_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 8 * 12 * sizeof(unsigned long long));
     unsigned long long* stamps = nwg <= 8192 ? stamp_buf : nullptr;
-    if (p.kind == 1)
-        hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>>), grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift,
-                           ep->alpha, ep->residual, out, H, bands, (int)nwg, stamps);
-    else
-        hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>>), grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift,
-                           ep->alpha, ep->residual, out, H, bands, (int)nwg, stamps);
+#define XE_GO(NX) do { \
+    if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), grid, blk, 0, stream, r, dwp, ap, ep->scale, \
+                                        ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps); \
+    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), grid, blk, 0, stream, r, dwp, ap, ep->scale, \
+                            ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps); } while (0)
+    if (next) XE_GO(true); else XE_GO(false);
+#undef XE_GO
     MSPL_CHECK_LAUNCH("eesp_dw_exp");
     if (stamps) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
         (void)hipDeviceSynchronize();
@@ -396,4 +473,28 @@ extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const i
         fprintf(stderr, "\n");
     }
     return MSPL_OK;
+}
+
+extern "C" int mspl_eesp_dw_exp_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H,
+                                    int32_t W, const mspl_epilogue_t* ep, float* out, void* stream_) {
+    return xe_launch(r, packed, dil, N, n, H, W, ep, out, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int64_t mspl_eesp_dw_exp_next_pack_floats(int32_t n) { return 4ll * (n / 32) * 16 * 64; }
+
+extern "C" int mspl_eesp_dw_exp_next_pack(const float* w1, int32_t n, float* next_packed, void* stream_) {
+    MSPL_REQUIRE(w1 && next_packed, MSPL_ERR_NULL_POINTER, "eesp_dw_exp_next_pack: null pointer");
+    MSPL_REQUIRE(n == 64 || n == 128, MSPL_ERR_UNSUPPORTED, "eesp_dw_exp_next_pack: n=%d not covered", n);
+    const int total = 4 * (n / 32) * 16 * 64;
+    hipLaunchKernelGGL(eesp_exp_pack_next_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w1, n,
+                       next_packed);
+    MSPL_CHECK_LAUNCH("eesp_dw_exp_next_pack");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_eesp_dw_exp_next_fwd(const float* r, const float* packed, const int32_t dil[4], int32_t N, int32_t n, int32_t H,
+                                         int32_t W, const mspl_epilogue_t* ep, float* out, const float* next_packed,
+                                         const float* nscale, const float* nshift, const float* nalpha, float* rnext, void* stream_) {
+    MSPL_REQUIRE(next_packed && nscale && nshift && nalpha && rnext, MSPL_ERR_NULL_POINTER, "eesp_dw_exp_next: null pointer");
+    return xe_launch(r, packed, dil, N, n, H, W, ep, out, next_packed, nscale, nshift, nalpha, rnext, static_cast<hipStream_t>(stream_));
 }

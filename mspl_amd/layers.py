@@ -197,6 +197,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
 _FUSED_DW_EXP = os.environ.get('MSPL_EESP_EXP', '1') != '0'   # inference: K2 + K3 of a stride-1 EESP block as one launch
+_FUSED_NEXT_PROJ = os.environ.get('MSPL_EESP_NEXT', '1') != '0'   # ... and the following block's proj_1x1 inside that launch
 _FUSED_EESP_TRAIN = os.environ.get('MSPL_FUSED_EESP_TRAIN', '1') != '0'  # EESP block as one autograd node (frozen BatchNorm)
 _FUSED_PYR_TRAIN = os.environ.get('MSPL_FUSED_PYR_TRAIN', '1') != '0'    # pyramid body as one autograd node (frozen BatchNorm)
 
@@ -444,17 +445,38 @@ class EESP(nn.Module):
         residual = input if (self.stride == 1 and exp.conv.out_channels == input.shape[1]) else None
         return _conv_bn_act(cat, exp.conv, exp.bn, self.module_act.weight, residual=residual)
 
-    def forward(self, input):
+    def _fused_dw_exp(self, shape):
+        """True when K2 + K3 of this block run as one launch for an input of `shape` (inference path)."""
+        exp = self.conv_1x1_exp
+        return (self.stride == 1 and exp.conv.out_channels == shape[1] and _FUSED_DW_EXP
+                and ops.eesp_dw_exp_fits((shape[0], self.proj_1x1.conv.out_channels) + tuple(shape[2:]), self.dilations))
+
+    def _next_proj(self):
+        """This block's proj_1x1 in the form the PREVIOUS block's fused launch computes it: (packed weight, scale, shift, alpha)."""
+        pj = self.proj_1x1
+        ps, pb = bn_fold(pj.bn)
+        return cached(self, 'nextproj', [pj.conv.weight], lambda: ops.eesp_dw_exp_next_pack(pj.conv.weight)), ps, pb, pj.act.weight
+
+    def forward(self, input, _reduced=None, _next=None):
+        """_reduced: this block's proj_1x1 output when the previous block's launch has already produced it; _next: the following
+        block of a chain (run_eesp_chain): the call then returns (output, that block's reduced tensor or None)."""
         if _training_path():
             return self._forward_train(input)
         exp = self.conv_1x1_exp
-        if (self.stride == 1 and exp.conv.out_channels == input.shape[1] and _FUSED_DW_EXP
-                and ops.eesp_dw_exp_fits((input.shape[0], self.proj_1x1.conv.out_channels) + tuple(input.shape[2:]), self.dilations)):
+        if self._fused_dw_exp(input.shape):
             # K2 + K3 in one launch: the 4n-channel concatenation stays on the CU (csrc/eesp_exp.hip)
-            o1 = self.proj_1x1(input)
+            o1 = self.proj_1x1(input) if _reduced is None else _reduced
             scale, shift = bn_fold(exp.bn)
-            return ops.eesp_dw_exp(o1, self._dw_exp_packed(input.shape[2], input.shape[3]), self.dilations,
-                                   Epi(scale, shift, self.module_act.weight, residual=input))
+            ep = Epi(scale, shift, self.module_act.weight, residual=input)
+            packed = self._dw_exp_packed(input.shape[2], input.shape[3])
+            nxt = _next is not None and _FUSED_NEXT_PROJ and _next._fused_dw_exp(input.shape) \
+                and _next.proj_1x1.conv.out_channels == self.proj_1x1.conv.out_channels and _next.proj_1x1.conv.groups == 4
+            if nxt:
+                return ops.eesp_dw_exp(o1, packed, self.dilations, ep, next_proj=_next._next_proj())
+            y = ops.eesp_dw_exp(o1, packed, self.dilations, ep)
+            return (y, None) if _next is not None else y
+        if _next is not None:
+            return self.forward(input), None
         cat = self.reduce_transform(input)
         scale, shift = bn_fold(self.conv_1x1_exp.bn)
         if self.stride == 2 and self.downAvg:
@@ -462,6 +484,24 @@ class EESP(nn.Module):
         residual = input if (self.stride == 1 and self.conv_1x1_exp.conv.out_channels == input.shape[1]) else None
         return ops.conv1x1(cat, self.conv_1x1_exp.conv.weight, self.k,
                            Epi(scale, shift, self.module_act.weight, residual=residual))
+
+
+def run_eesp_chain(blocks, x):
+    """x through consecutive stride-1 EESP blocks (a level's stack).  On the inference path each block's fused K2 + K3 launch also
+    computes the NEXT block's proj_1x1 (csrc/eesp_exp.hip), so a chain of B blocks is B + 1 launches instead of 3 B."""
+    blocks = list(blocks)
+    if _training_path():
+        for m in blocks:
+            x = m(x)
+        return x
+    reduced = None
+    for i, m in enumerate(blocks):
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        if nxt is None:
+            x = m(x, _reduced=reduced)
+        else:
+            x, reduced = m(x, _reduced=reduced, _next=nxt)
+    return x
 
 
 class ImagePyramid:

@@ -21,7 +21,7 @@ from torch.nn import init
 
 from . import ops
 from . import autograd as ag
-from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path, cached,
+from .layers import (C, CBR, DownSampler, EESP, EfficientPWConv, EfficientPyrPool, ImagePyramid, _training_path, cached, run_eesp_chain,
                      decoder_merge, fork, join, wait_mark)
 
 sc_ch_dict = {
@@ -164,11 +164,9 @@ class _SegBase(nn.Module):
             return a1[2:], a2[2:], a3[2:], l4
         l2 = b.level2_0(l1, pyr if image_for_l2 else None)
         l3 = b.level3_0(l2, pyr)
-        for i, layer in enumerate(b.level3):
-            l3 = (layer if i == 0 else l3_tail[i])(l3)
+        l3 = run_eesp_chain([layer if i == 0 else l3_tail[i] for i, layer in enumerate(b.level3)], l3)
         l4 = b.level4_0(l3, pyr)
-        for layer in b.level4:
-            l4 = layer(l4)
+        l4 = run_eesp_chain(b.level4, l4)
         return l1, l2, l3, l4
 
     def _encode_rgbd(self, x, x_d):

@@ -188,17 +188,36 @@ def eesp_dw_exp_pack(w4, bscale, bshift, balpha, wexp, H, W, dilations):
     return packed
 
 
-def eesp_dw_exp(r, packed, dilations, ep):
+def eesp_dw_exp_next_pack(w1):
+    """The next block's proj_1x1 weight (n, n[, 1, 1]) in the operand order of mspl_eesp_dw_exp_next_fwd (cache it per weight version)."""
+    w1 = _f32(w1, 'next projection weight')
+    n = w1.shape[0]
+    if w1.numel() != n * n:
+        raise RuntimeError('mspl_amd: next projection weight %s, expected (%d,%d)' % (tuple(w1.shape), n, n))
+    packed = torch.empty(int(lib.mspl_eesp_dw_exp_next_pack_floats(n)), device=w1.device, dtype=torch.float32)
+    check(lib.mspl_eesp_dw_exp_next_pack(_p(w1), n, _p(packed), _stream()))
+    return packed
+
+
+def eesp_dw_exp(r, packed, dilations, ep, next_proj=None):
     """K2 + K3 of a stride-1 EESP block: r (N,n,H,W) -> (N,4n,H,W); ep carries conv_1x1_exp's folded BN, module_act's slope
-    and the residual (the block's input)."""
+    and the residual (the block's input).  next_proj = (packed weight, scale, shift, alpha) of the FOLLOWING block's proj_1x1: the
+    launch then also returns that block's reduced tensor (N,n,H,W): (y, r_next)."""
     r = _f32(r, 'r')
     N, n, H, W = r.shape
     packed = _vec(packed, int(lib.mspl_eesp_dw_exp_pack_floats(n)), 'packed')
     dst = torch.empty((N, 4 * n, H, W), device=r.device, dtype=torch.float32)
     s, keep = _build(ep, dst, 0, N, 4 * n, H * W)
     d = (ctypes.c_int32 * 4)(*[int(v) for v in dilations])
-    check(lib.mspl_eesp_dw_exp_fwd(_p(r), _p(packed), d, N, n, H, W, ctypes.byref(s), _p(dst), _stream()))
-    return dst
+    if next_proj is None:
+        check(lib.mspl_eesp_dw_exp_fwd(_p(r), _p(packed), d, N, n, H, W, ctypes.byref(s), _p(dst), _stream()))
+        return dst
+    npk = _vec(next_proj[0], int(lib.mspl_eesp_dw_exp_next_pack_floats(n)), 'next_packed')
+    ns, nb, na = _vec(next_proj[1], n, 'nscale'), _vec(next_proj[2], n, 'nshift'), _vec(next_proj[3], n, 'nalpha')
+    rn = torch.empty((N, n, H, W), device=r.device, dtype=torch.float32)
+    check(lib.mspl_eesp_dw_exp_next_fwd(_p(r), _p(packed), d, N, n, H, W, ctypes.byref(s), _p(dst), _p(npk), _p(ns), _p(nb), _p(na), _p(rn),
+                                        _stream()))
+    return dst, rn
 
 
 def conv1x1(x, w, groups=1, ep=None, out=None):

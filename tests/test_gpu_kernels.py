@@ -111,6 +111,35 @@ def test_eesp_dw_exp(cfg):
     assert not ops.eesp_dw_exp_fits((N, n, H, W), [1, 1, 1, 2])
 
 
+@pytest.mark.parametrize('cfg', [(2, 128, 18, 30, [1, 1, 2, 3]), (3, 128, 5, 30, [1, 1, 2, 3]), (17, 128, 18, 30, [1, 1, 2, 3]),
+                                 (2, 64, 36, 60, [1, 2, 3, 4]), (1, 64, 3, 60, [1, 2, 3, 4])])
+def test_eesp_dw_exp_next_projection(cfg):
+    """The fused K2 + K3 launch that also computes the FOLLOWING block's proj_1x1 (grouped 1x1 + BN + PReLU over its own output):
+    the block output stays bit-identical to the launch without it, the reduced tensor equals conv1x1 on that output up to the
+    summation order of the K = n products (torch fp32 as the reference)."""
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    N, n, H, W, dil = cfg
+    r = rnd(N, n, H, W, seed=1)
+    x_in = rnd(N, 4 * n, H, W, seed=6)
+    w = rnd(4, n, 3, 3, seed=2, scale=0.3)
+    bs, bb, ba = rnd(4 * n, seed=3).abs() + 0.5, rnd(4 * n, seed=4) * 0.1, rnd(4 * n, seed=5).abs() * 0.3
+    wexp = rnd(4 * n, n, 1, 1, seed=7, scale=0.1)
+    es, eb, ea = rnd(4 * n, seed=8).abs() + 0.5, rnd(4 * n, seed=9) * 0.1, rnd(4 * n, seed=10).abs() * 0.3
+    w1 = rnd(n, n, 1, 1, seed=11, scale=0.1)
+    ns, nb, na = rnd(n, seed=12).abs() + 0.5, rnd(n, seed=13) * 0.1, rnd(n, seed=14).abs() * 0.3
+    d = lambda t: t.to(DEV)
+    packed = ops.eesp_dw_exp_pack(d(w), d(bs), d(bb), d(ba), d(wexp), H, W, dil)
+    ep = Epi(d(es), d(eb), d(ea), residual=d(x_in))
+    alone = ops.eesp_dw_exp(d(r), packed, dil, ep)
+    y, rn = ops.eesp_dw_exp(d(r), packed, dil, ep, next_proj=(ops.eesp_dw_exp_next_pack(d(w1)), d(ns), d(nb), d(na)))
+    assert torch.equal(y, alone)
+    ref = F.prelu(F.conv2d(alone.cpu(), w1, None, 1, 0, 1, 4) * ns.view(1, -1, 1, 1) + nb.view(1, -1, 1, 1), na)
+    close(rn, ref)
+    two = ops.conv1x1(alone, d(w1), 4, Epi(d(ns), d(nb), d(na)))
+    close(rn, two.cpu(), atol=1e-5)
+
+
 @pytest.mark.parametrize('cfg', [(2, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 128, 4, 16, 30, [1, 1, 2, 3]), (2, 256, 64, 4, 18, 30, [1, 2, 3, 4]),
                                  (1, 256, 64, 4, 8, 12, [1, 2, 3, 4]), (3, 512, 128, 4, 6, 10, [1, 1, 2, 3]), (1, 256, 128, 4, 10, 44, [1, 2, 3, 4]),
                                  (32, 512, 128, 4, 18, 30, [1, 1, 2, 3]), (1, 512, 64, 4, 20, 36, [1, 1, 2, 3])])
