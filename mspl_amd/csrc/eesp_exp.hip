@@ -81,12 +81,12 @@ __global__ void eesp_exp_pack_kernel(const float* __restrict__ w4, const float* 
 
 // The NEXT block's proj_1x1 (grouped 1x1, n outputs, n inputs per group = exactly one group's 4n/4 output rows of this block) as a
 // second matrix stage on the accumulators (see the kernel's epilogue): its weights in the lane order of the A operand of k-step j,
-// np[((g*RTPG + rt)*16 + j)*64 + lane] = w1[g*M1 + (lane & 31)][rt*32 + (j & 3) + 8*(j >> 2) + 4*(lane >> 5)], rows >= M1 = n/4 zero.
+// np[((g*RTPG + rt)*64 + lane)*16 + j] = w1[g*M1 + (lane & 31)][rt*32 + (j & 3) + 8*(j >> 2) + 4*(lane >> 5)], rows >= M1 = n/4 zero.
 __global__ void eesp_exp_pack_next_kernel(const float* __restrict__ w1, int n, float* __restrict__ np) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int rtpg = n / 32, m1 = n / 4;
     if (i >= 4 * rtpg * 16 * 64) return;
-    const int lane = i & 63, j = (i >> 6) & 15, wv = i >> 10;
+    const int j = i & 15, lane = (i >> 4) & 63, wv = i >> 10;
     const int rt = wv % rtpg, g = wv / rtpg;
     const int m = lane & 31;
     const int k = rt * 32 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
@@ -124,8 +124,10 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     static_assert(PXV <= 64 && (W % 2) == 0 && MAXD <= P, "band geometry");
     static_assert(KC % 8 == 0 && NCH % KC == 0 && NCHUNK >= 2, "chunking");
 
-    __shared__ __attribute__((aligned(16))) float rt_[2][KC * ROWS * RS];
-    __shared__ __attribute__((aligned(16))) float bb_[2][GPW * KC * 64];
+    constexpr int RT_F = KC * ROWS * RS, BB_F = GPW * KC * 64;          // floats of one row buffer / one B-operand buffer
+    __shared__ __attribute__((aligned(16))) float lds_[2 * RT_F + 2 * BB_F];
+    float* const rt_[2] = {lds_, lds_ + RT_F};
+    float* const bb_[2] = {lds_ + 2 * RT_F, lds_ + 2 * RT_F + BB_F};
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     for (int i = tid; i < 2 * KC * ROWS * 2 * P; i += 512) {
         const int c8 = i % (2 * P);
         const int rr = i / (2 * P);                              // (buffer, channel, row) flattened
-        (&rt_[0][0])[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
+        lds_[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
     }
     store_chunk(rt_[0]);
     load_chunk(1);
@@ -270,6 +272,9 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     const int ch0 = g * NCH + rtile * 32 + 4 * half;
     const size_t obase = ((size_t)img * 4 * NCH + ch0) * HW + (size_t)y0 * W + 2 * li;
     float2 resv[16];
+    constexpr int M1 = NCH / 4;                                    // rows of a group of the next projection
+    constexpr int RPW = 16 / RTPG;                                 // accumulator registers of the next stage that a wave finishes
+    float4 npa4[4], nsc4[RPW / 4], nsh4[RPW / 4], nal4[RPW / 4];
 
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
@@ -292,27 +297,37 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     }
 
     // ---- epilogue: folded BN, + residual, PReLU (the order of conv1x1's epilogue)
-    float4 sc4[4], sh4[4], al4[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        sc4[rg] = *reinterpret_cast<const float4*>(escale + ch0 + 8 * rg);
-        sh4[rg] = *reinterpret_cast<const float4*>(eshift + ch0 + 8 * rg);
-        al4[rg] = *reinterpret_cast<const float4*>(ealpha + ch0 + 8 * rg);
-    }
+    for (int hf = 0; hf < 2; ++hf) {               // two halves (register budget); the next stage's weights are requested between them
+        float4 sc4[2], sh4[2], al4[2];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const float scv[4] = {sc4[rg].x, sc4[rg].y, sc4[rg].z, sc4[rg].w}, shv[4] = {sh4[rg].x, sh4[rg].y, sh4[rg].z, sh4[rg].w};
-        const float alv[4] = {al4[rg].x, al4[rg].y, al4[rg].z, al4[rg].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = rg * 4 + q;
-            float v0 = fmaf(acc0[rr], scv[q], shv[q]) + resv[rr].x;
-            float v1 = fmaf(acc1[rr], scv[q], shv[q]) + resv[rr].y;
-            v0 = v0 > 0.f ? v0 : alv[q] * v0;
-            v1 = v1 > 0.f ? v1 : alv[q] * v1;
-            if (pok) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
-            if (NEXT) { acc0[rr] = v0; acc1[rr] = v1; }
+        for (int r2 = 0; r2 < 2; ++r2) {
+            sc4[r2] = *reinterpret_cast<const float4*>(escale + ch0 + 8 * (2 * hf + r2));
+            sh4[r2] = *reinterpret_cast<const float4*>(eshift + ch0 + 8 * (2 * hf + r2));
+            al4[r2] = *reinterpret_cast<const float4*>(ealpha + ch0 + 8 * (2 * hf + r2));
         }
+        if (NEXT && hf == 1) {
+            const float4* npl = reinterpret_cast<const float4*>(npw) + ((size_t)(g * RTPG + rtile) * 64 + lane) * 4;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) npa4[j4] = npl[j4];
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int rg = 2 * hf + r2;
+            const float scv[4] = {sc4[r2].x, sc4[r2].y, sc4[r2].z, sc4[r2].w}, shv[4] = {sh4[r2].x, sh4[r2].y, sh4[r2].z, sh4[r2].w};
+            const float alv[4] = {al4[r2].x, al4[r2].y, al4[r2].z, al4[r2].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = rg * 4 + q;
+                float v0 = fmaf(acc0[rr], scv[q], shv[q]) + resv[rr].x;
+                float v1 = fmaf(acc1[rr], scv[q], shv[q]) + resv[rr].y;
+                v0 = v0 > 0.f ? v0 : alv[q] * v0;
+                v1 = v1 > 0.f ? v1 : alv[q] * v1;
+                if (pok) *reinterpret_cast<float2*>(out + obase + (size_t)(q + 8 * rg) * HW) = make_float2(v0, v1);
+                if (NEXT) { acc0[rr] = v0; acc1[rr] = v1; }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (NEXT) {
         // ---- the next block's proj_1x1 on what this workgroup holds: group g's n output rows are exactly the input channels of
@@ -320,14 +335,16 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
         // operand of k-step j it pairs two rows of the tile (the weights are packed in that order), so the 32 x 64 tile feeds 16
         // MFMAs per pixel sub-tile without moving; the RTPG waves of a group each hold a K-slice: their partial tiles are summed
         // through LDS (the row buffers are free), every wave finishes 16 / RTPG register rows: folded BN, PReLU, 8-byte stores.
-        constexpr int M1 = NCH / 4;
-        constexpr int RPW = 16 / RTPG;                             // accumulator registers a wave finishes
-        float npa[16];
-        {
-            const float* npl = npw + ((size_t)(g * RTPG + rtile) * 16) * 64 + lane;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) npa[j] = npl[j * 64];
+        for (int q4 = 0; q4 < RPW / 4; ++q4) {
+            const int chn = g * M1 + 8 * ((rtile * RPW) / 4 + q4) + 4 * half;          // four consecutive rows per register quad
+            const bool okc = 8 * ((rtile * RPW) / 4 + q4) + 4 * half < M1;
+            nsc4[q4] = okc ? *reinterpret_cast<const float4*>(nscale + chn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            nsh4[q4] = okc ? *reinterpret_cast<const float4*>(nshift + chn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            nal4[q4] = okc ? *reinterpret_cast<const float4*>(nalpha + chn) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const float npa[16] = {npa4[0].x, npa4[0].y, npa4[0].z, npa4[0].w, npa4[1].x, npa4[1].y, npa4[1].z, npa4[1].w,
+                               npa4[2].x, npa4[2].y, npa4[2].z, npa4[2].w, npa4[3].x, npa4[3].y, npa4[3].z, npa4[3].w};
         floatx16 p0, p1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { p0[i] = 0.f; p1[i] = 0.f; }
@@ -336,21 +353,40 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
             p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(npa[j], acc0[j], p0, 0, 0, 0);
             p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(npa[j], acc1[j], p1, 0, 0, 0);
         }
-        static_assert(2 * KC * ROWS * RS >= 8 * 16 * 64, "the row buffers hold the eight partial tiles");
-        float* red = &rt_[0][0];
+        // a wave keeps the RPW registers it finishes and sends the others to the waves that finish them: one round through LDS
+        // (all of it is free once every wave is past the last step) for both pixel sub-tiles
+        constexpr int SLOT = (RTPG - 1) * RPW;                     // registers a wave receives per sub-tile
+        static_assert(2 * RT_F + 2 * BB_F >= 2 * 8 * SLOT * 64, "LDS holds the exchanged partial tiles");
+        float* red = lds_;
+        __syncthreads();                                           // every wave has finished the last step's LDS reads
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int dw = r2 / RPW;                            // destination wave inside the group (compile time)
+                if (dw != rtile) {                                  // uniform
+                    const int si = rtile < dw ? rtile : rtile - 1;
+                    red[((sub * 8 + gl * RTPG + dw) * SLOT + si * RPW + (r2 % RPW)) * 64 + lane] = sub ? p1[r2] : p0[r2];
+                }
+            }
+        }
+        __syncthreads();
         float sres[2][RPW];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            if (sub) __syncthreads();                              // the first round's sums are read
-#pragma unroll
-            for (int r2 = 0; r2 < 16; ++r2) red[(wave * 16 + r2) * 64 + lane] = sub ? p1[r2] : p0[r2];
-            __syncthreads();
 #pragma unroll
             for (int q = 0; q < RPW; ++q) {
-                const int r2 = rtile * RPW + q;
-                float t = red[((gl * RTPG) * 16 + r2) * 64 + lane];
+                float own = 0.f;
 #pragma unroll
-                for (int w2 = 1; w2 < RTPG; ++w2) t += red[((gl * RTPG + w2) * 16 + r2) * 64 + lane];
+                for (int r2 = 0; r2 < 16; ++r2)
+                    if (r2 == rtile * RPW + q) own = sub ? p1[r2] : p0[r2];          // (rtile is uniform: a select chain, no indexing)
+                float t = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < RTPG; ++w2) {                 // partials in wave order, the own one from registers
+                    const int si = w2 < rtile ? w2 : w2 - 1;
+                    const float v = (w2 == rtile) ? own : red[((sub * 8 + gl * RTPG + rtile) * SLOT + si * RPW + q) * 64 + lane];
+                    t = (w2 == 0) ? v : t + v;
+                }
                 sres[sub][q] = t;
             }
         }
@@ -360,7 +396,10 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
             const int row = (r2 & 3) + 8 * (r2 >> 2) + 4 * half;
             if (row < M1 && pok) {
                 const int ch = g * M1 + row;
-                const float sc = nscale[ch], sh = nshift[ch], al = nalpha[ch];
+                const float4 s4 = nsc4[q >> 2], h4 = nsh4[q >> 2], a4 = nal4[q >> 2];
+                const float sc = (q & 3) == 0 ? s4.x : (q & 3) == 1 ? s4.y : (q & 3) == 2 ? s4.z : s4.w;
+                const float sh = (q & 3) == 0 ? h4.x : (q & 3) == 1 ? h4.y : (q & 3) == 2 ? h4.z : h4.w;
+                const float al = (q & 3) == 0 ? a4.x : (q & 3) == 1 ? a4.y : (q & 3) == 2 ? a4.z : a4.w;
                 float v0 = fmaf(sres[0][q], sc, sh), v1 = fmaf(sres[1][q], sc, sh);
                 v0 = v0 > 0.f ? v0 : al * v0;
                 v1 = v1 > 0.f ? v1 : al * v1;
