@@ -661,7 +661,8 @@ def main():
         kind, _, a_, kw = c
         n_, ch_, hi_, wi_ = a_[0].shape
         if kind == 'exp':
-            return mult * 4 * n_ * 9 * ch_ * hi_ * wi_
+            # (+ n*H*W written when the launch also computes the next block's proj_1x1)
+            return mult * 4 * n_ * (9 + (1 if kw.get('next_proj') is not None else 0)) * ch_ * hi_ * wi_
         st_ = a_[3] if len(a_) > 3 else kw.get('stride', 1)
         ho_, wo_ = (hi_ - 1) // st_ + 1, (wi_ - 1) // st_ + 1
         return mult * 4 * n_ * ch_ * (hi_ * wi_ + 4 * ho_ * wo_)
@@ -671,7 +672,8 @@ def main():
         if kind != 'exp':
             return 0
         n_, ch_, hi_, wi_ = a_[0].shape
-        return mult * 2 * n_ * hi_ * wi_ * 4 * ch_ * ch_          # the grouped expansion: 4n outputs x n inputs per pixel
+        # the grouped expansion: 4n outputs x n inputs per pixel; + the next block's grouped projection (n outputs x n inputs) when fused in
+        return mult * 2 * n_ * hi_ * wi_ * (4 + (1 if c[3].get('next_proj') is not None else 0)) * ch_ * ch_
 
     REPS = 20
     iso_ms = []
@@ -882,12 +884,12 @@ def main():
             # launches that remain (the strided blocks); `roofline_family` = all thirteen against their bytes, for continuity with
             # rounds 1-3 (whose `roofline` was the thirteen standalone K2 launches: 0.30 of the HBM roof)
             'roofline': dict(roof_exp(ip1 if 'exp' in ip1 else iso) or {}, **{
-                'kernel': 'eesp_dw_exp (K2 + K3 of a stride-1 EESP block in one launch: depthwise branches -> LDS -> MFMA B operand; '
-                          '%d launches/forward, the dominant kernel of a pass)' % n_exp,
+                'kernel': 'eesp_dw_exp (K2 + K3 of a stride-1 EESP block, and the NEXT block\'s proj_1x1, in one launch: depthwise branches -> LDS '
+                          '-> MFMA B operand -> second matrix stage on the accumulators; %d launches/forward, the dominant kernel of a pass)' % n_exp,
                 'traffic': fam_traffic.get('exp'), 'traffic_source': fam_traffic.get('source'),
-                'accounting_note': family_note + '.  achieved = the expansion\'s matrix FLOPs (2 * 4n * n per pixel) / launch time; the depthwise '
+                'accounting_note': family_note + '.  achieved = the matrix FLOPs (expansion 2 * 4n * n per pixel, + 2 * n * n where the next projection is fused in) / launch time; the depthwise '
                                    'vector work (36 FMAs per reduced channel and pixel) runs on the same SIMD issue and is not counted; '
-                                   'hbm_view = 4 * 9n * H * W bytes per image / launch time',
+                                   'hbm_view = 4 * 9n * H * W (+ 4 * n * H * W) bytes per image / launch time',
                 'timing': ('HIP event pair around each launch of one eager pass at batch 16 (stream parked behind a spin kernel; the '
                            'pair\'s own overhead, calibrated per shape on the isolated kernel, subtracted; median of 7 passes); '
                            'rocprofv3 in the same kind of pass: rocprof_avg_launch_us' if 'exp' in ip1 else
