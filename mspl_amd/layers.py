@@ -407,7 +407,7 @@ class EESP(nn.Module):
         def build():
             bs, bb = bn_fold(br.bn)
             return ops.eesp_dw_exp_pack(self._dw_weights(), bs, bb, br.act.weight, exp.conv.weight, H, W, self.dilations)
-        return cached(self, 'dwexp', deps, build)
+        return cached(self, 'dwexp%dx%d' % (H, W), deps, build)       # (the chunking of the packed block follows the launch plan of the shape)
 
     def reduce_transform(self, input):
         """K1 + K2: returns the BN+PReLU'd concatenation that feeds conv_1x1_exp."""
