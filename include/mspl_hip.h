@@ -132,8 +132,9 @@ int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const float* psca
  *   w4 (4,n,3,3), br_after_cat's folded scale/shift and PReLU slope (4n each) and conv_1x1_exp's weight (4n, n) -- the caller
  *   caches it per weight version.  ep: scale/shift (conv_1x1_exp's folded BN), alpha (module_act) and residual (the block's
  *   input, (N,4n,H,W)) are all required; nothing else may be set.  out (N,4n,H,W).
- * Covered (mspl_eesp_dw_exp_fits returns 1): (n, W, dil) = (128, 30, {1,1,2,3}) or (64, 60, {1,2,3,4}), any H; callers run the
- * two-launch form otherwise (_fwd / _pack return MSPL_ERR_UNSUPPORTED). */
+ * Covered (mspl_eesp_dw_exp_fits returns 1): (n, W, dil) = (128, 30 | 32, {1,1,2,3}) or (64, 60 | 64, {1,2,3,4}) -- levels 4 / 3 of
+ * ESPDNet(-UE) s=2.0 for 480- and 512-pixel-wide inputs --, any H; callers run the two-launch form otherwise (_fwd / _pack return
+ * MSPL_ERR_UNSUPPORTED). */
 int mspl_eesp_dw_exp_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t dil[4], uint32_t launch_flags);
 int64_t mspl_eesp_dw_exp_pack_floats(int32_t n);
 int mspl_eesp_dw_exp_pack(const float* w4, const float* bscale, const float* bshift, const float* balpha, const float* wexp,

@@ -421,15 +421,16 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
 
 // ------------------------------------------------------------------ host side
 struct XePlan {
-    int kind;        // 0: none, 1: n = 128, W = 30, dil {1,1,2,3}; 2: n = 64, W = 60, dil {1,2,3,4}
+    int kind;        // 0: none; 1: n = 128, W = 30; 2: n = 64, W = 60 (288x480 / 256x480 inputs); 3: n = 128, W = 32; 4: n = 64, W = 64 (512-wide inputs)
     int TH, KC, GPW;
 };
 
 static XePlan xe_plan(int n, int H, int W, const int32_t* dil) {
     XePlan p = {0, 0, 0, 0};
     if (H < 1) return p;
-    if (n == 128 && W == 30 && dil[0] == 1 && dil[1] == 1 && dil[2] == 2 && dil[3] == 3) { p.kind = 1; p.TH = 2; p.KC = 16; p.GPW = 2; }
-    else if (n == 64 && W == 60 && dil[0] == 1 && dil[1] == 2 && dil[2] == 3 && dil[3] == 4) { p.kind = 2; p.TH = 1; p.KC = 8; p.GPW = 4; }
+    const bool d1123 = dil[0] == 1 && dil[1] == 1 && dil[2] == 2 && dil[3] == 3, d1234 = dil[0] == 1 && dil[1] == 2 && dil[2] == 3 && dil[3] == 4;
+    if (n == 128 && d1123 && (W == 30 || W == 32)) { p.kind = W == 30 ? 1 : 3; p.TH = 2; p.KC = 16; p.GPW = 2; }
+    else if (n == 64 && d1234 && (W == 60 || W == 64)) { p.kind = W == 60 ? 2 : 4; p.TH = 1; p.KC = 8; p.GPW = 4; }
     return p;
 }
 
@@ -489,13 +490,15 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_XE_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 8 * 12 * sizeof(unsigned long long));
     unsigned long long* stamps = nwg <= 8192 ? stamp_buf : nullptr;
+#define XE_ARGS grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps
 #define XE_GO(NX) do { \
-    if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), grid, blk, 0, stream, r, dwp, ap, ep->scale, \
-                                        ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps); \
-    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), grid, blk, 0, stream, r, dwp, ap, ep->scale, \
-                            ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps); } while (0)
+    if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
+    else if (p.kind == 2) hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), XE_ARGS); \
+    else if (p.kind == 3) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 32, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
+    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 64, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), XE_ARGS); } while (0)
     if (next) XE_GO(true); else XE_GO(false);
 #undef XE_GO
+#undef XE_ARGS
     MSPL_CHECK_LAUNCH("eesp_dw_exp");
     if (stamps) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
         (void)hipDeviceSynchronize();
