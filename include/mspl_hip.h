@@ -324,6 +324,15 @@ int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin
                          int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
                          float* gw, void* stream);
 
+/* DownSampler tail (nn_layers/eesp.py:131-144) without materialising torch.cat: y = PReLU(cat[a, b] + reinf).  a (N,nin,HW): avg-pooled
+ * input; b (N,C-nin,HW): the strided EESP branch; reinf (N,C,HW) or NULL; alpha (C).  Backward: ga / gb (shapes of a / b, contiguous),
+ * greinf (N,C,HW; NULL iff reinf is), galpha (C, ACCUMULATED with atomics: caller zeroes).  HW % 4 == 0, 16-byte aligned operands
+ * (MSPL_ERR_UNSUPPORTED otherwise: callers fall back to cat + mspl_pointwise_fwd / mspl_affine_prelu_bwd). */
+int mspl_down_tail_fwd(const float* a, const float* b, const float* reinf, const float* alpha, int32_t N, int32_t nin, int32_t C,
+                       int32_t HW, float* y, void* stream);
+int mspl_down_tail_bwd(const float* a, const float* b, const float* reinf, const float* gy, const float* alpha, int32_t N, int32_t nin,
+                       int32_t C, int32_t HW, float* ga, float* gb, float* greinf, float* galpha, void* stream);
+
 /* Backward of y = PReLU((c + pre_add) * scale + shift + residual) (folded eval BatchNorm + PReLU, mspl_pointwise_fwd).
  * Any of pre_add/residual/scale/shift/alpha may be NULL.  Outputs: gz = dL/d(pre-activation) (also the residual's
  * gradient; may be NULL), gc = gz*scale (gradient of c and pre_add; may be NULL); gscale/gshift/galpha (C floats each,

@@ -734,6 +734,46 @@ def eesp_dw(x, ws, dil, stride):
     return EespDwFn.apply(x, ws[0], ws[1], ws[2], ws[3], dil, stride)
 
 
+class DownTailFn(torch.autograd.Function):
+    """y = PReLU(cat[a, b] + reinf): the tail of a DownSampler (nn_layers/eesp.py:131-144) as one forward and one backward launch.
+    The node-per-op form ran torch.cat, then the affine/PReLU kernel; in the backward autograd's CatBackward handed out two channel
+    SLICES of one gradient tensor, which had to be copied into contiguous tensors before the pool's and the EESP block's backward
+    kernels could take them (3 cat + 6 copy launches per step over the three DownSamplers)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, reinf):
+        a, b = _c(a), _c(b)
+        reinf = None if reinf is None else _c(reinf)
+        N, nin = a.shape[:2]
+        C = nin + b.shape[1]
+        hw = a[0, 0].numel()
+        y = torch.empty((N, C) + tuple(a.shape[2:]), device=a.device, dtype=torch.float32)
+        check(lib.mspl_down_tail_fwd(_p(a), _p(b), _p(reinf), _p(alpha), N, nin, C, hw, _p(y), _stream()))
+        ctx.save_for_backward(a, b, alpha, reinf)
+        ctx.sink = _sink(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, b, alpha, reinf = ctx.saved_tensors
+        gy = _c(gy)
+        N, nin = a.shape[:2]
+        C = nin + b.shape[1]
+        hw = a[0, 0].numel()
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        gr = torch.empty_like(reinf) if reinf is not None else None
+        gal = ctx.sink if ctx.sink is not None else torch.zeros(C, device=a.device)
+        check(lib.mspl_down_tail_bwd(_p(a), _p(b), _p(reinf), _p(gy), _p(alpha), N, nin, C, hw, _p(ga), _p(gb), _p(gr), _p(gal), _stream()))
+        return ga, gb, (None if ctx.sink is not None else gal), gr
+
+
+def down_tail(a, b, alpha, reinf=None):
+    """PReLU(cat[a, b] + reinf); planes that are not a multiple of 4 pixels take the node-per-op form."""
+    if a[0, 0].numel() % 4 or a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+        return affine_prelu(torch.cat([a, b], 1), None, None, alpha, residual=reinf)
+    return DownTailFn.apply(a, b, alpha, reinf)
+
+
 def affine_prelu(c, scale=None, shift=None, alpha=None, pre_add=None, residual=None):
     return AffinePReLUFn.apply(c, scale, shift, alpha, pre_add, residual, None, None, None, None)
 

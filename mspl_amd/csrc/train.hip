@@ -920,6 +920,100 @@ static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const f
     return MSPL_OK;
 }
 
+// ---- DownSampler tail (nn_layers/eesp.py:131-144): y = PReLU(cat[a, b] + reinf) without the concatenation.  a (N,nin,HW): the
+// pooled input, b (N,C-nin,HW): the strided EESP branch, reinf (N,C,HW) or null.  Forward: one pass reading the two sources where
+// torch.cat + add + PReLU made three; backward: dL/da, dL/db land in two CONTIGUOUS tensors (the slices of one gradient that
+// autograd's CatBackward hands out had to be copied before our kernels could take them) and d alpha is reduced on the way.
+__global__ __launch_bounds__(256) void down_tail_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ r, const float* __restrict__ alpha, int nin, int C,
+                                                            int HW4, float* __restrict__ y) {
+    const int plane = blockIdx.z * gridDim.y + blockIdx.y;              // n * C + c
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n = plane / C, c = plane - n * C;
+    if (q >= HW4) return;
+    const float4* src = reinterpret_cast<const float4*>(c < nin ? a + ((size_t)n * nin + c) * (size_t)HW4 * 4
+                                                                : b + ((size_t)n * (C - nin) + (c - nin)) * (size_t)HW4 * 4);
+    float4 v = src[q];
+    if (r) {
+        const float4 t = reinterpret_cast<const float4*>(r + (size_t)plane * HW4 * 4)[q];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float al = alpha[c];
+    v.x = v.x > 0.f ? v.x : al * v.x; v.y = v.y > 0.f ? v.y : al * v.y;
+    v.z = v.z > 0.f ? v.z : al * v.z; v.w = v.w > 0.f ? v.w : al * v.w;
+    reinterpret_cast<float4*>(y + (size_t)plane * HW4 * 4)[q] = v;
+}
+
+__global__ __launch_bounds__(256) void down_tail_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ r, const float* __restrict__ gy,
+                                                            const float* __restrict__ alpha, int nin, int C, int HW4, int chunks,
+                                                            float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gr,
+                                                            float* __restrict__ galpha) {
+    int bid = blockIdx.x;
+    const int chunk = bid % chunks;  bid /= chunks;
+    const int c = bid % C, n = bid / C;
+    const size_t soff = (c < nin ? ((size_t)n * nin + c) : ((size_t)n * (C - nin) + (c - nin))) * (size_t)HW4;
+    const float4* src = reinterpret_cast<const float4*>(c < nin ? a : b) + soff;
+    float4* gsrc = reinterpret_cast<float4*>(c < nin ? ga : gb) + soff;
+    const size_t poff = ((size_t)n * C + c) * (size_t)HW4;
+    const float4* r4 = r ? reinterpret_cast<const float4*>(r) + poff : nullptr;
+    const float4* g4 = reinterpret_cast<const float4*>(gy) + poff;
+    float4* gr4 = gr ? reinterpret_cast<float4*>(gr) + poff : nullptr;
+    const float al = alpha[c];
+    const int per = (HW4 + chunks - 1) / chunks, q0 = chunk * per, q1 = min(HW4, q0 + per);
+    float s_alpha = 0.f;
+    auto one = [&](float z, float g) { if (z > 0.f) return g; s_alpha += g * z; return al * g; };
+    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+        float4 z = src[q];
+        if (r4) { const float4 t = r4[q]; z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w; }
+        const float4 g = g4[q];
+        float4 gz;
+        gz.x = one(z.x, g.x); gz.y = one(z.y, g.y); gz.z = one(z.z, g.z); gz.w = one(z.w, g.w);
+        gsrc[q] = gz;
+        if (gr4) gr4[q] = gz;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s_alpha += __shfl_down(s_alpha, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s_alpha;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(galpha + c, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+extern "C" int mspl_down_tail_fwd(const float* a, const float* b, const float* reinf, const float* alpha, int32_t N, int32_t nin,
+                                  int32_t C, int32_t HW, float* y, void* stream) {
+    MSPL_REQUIRE(a && b && alpha && y, MSPL_ERR_NULL_POINTER, "down_tail_fwd: null pointer");
+    MSPL_REQUIRE(N > 0 && nin > 0 && nin < C && HW > 0, MSPL_ERR_BAD_SHAPE, "down_tail_fwd: bad shape N=%d nin=%d C=%d HW=%d", N, nin, C, HW);
+    MSPL_REQUIRE((HW & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)reinf | (uintptr_t)y)) & 15) == 0, MSPL_ERR_UNSUPPORTED,
+                 "down_tail_fwd: planes must be a multiple of 4 pixels and 16-byte aligned");
+    const int64_t planes = (int64_t)N * C;
+    MSPL_REQUIRE(planes < 65535ll * 65535ll, MSPL_ERR_BAD_SHAPE, "down_tail_fwd: too many planes");
+    const int gy = planes < 65535 ? (int)planes : 65535;
+    MSPL_REQUIRE(planes % gy == 0 || planes < 65535, MSPL_ERR_UNSUPPORTED, "down_tail_fwd: plane count %lld", (long long)planes);
+    const dim3 grid((unsigned)ceil_div(HW / 4, 256), (unsigned)gy, (unsigned)(planes / gy));
+    hipLaunchKernelGGL(down_tail_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, reinf, alpha, nin, C, HW / 4, y);
+    MSPL_CHECK_LAUNCH("down_tail_fwd");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_down_tail_bwd(const float* a, const float* b, const float* reinf, const float* gy, const float* alpha, int32_t N,
+                                  int32_t nin, int32_t C, int32_t HW, float* ga, float* gb, float* greinf, float* galpha, void* stream) {
+    MSPL_REQUIRE(a && b && gy && alpha && ga && gb && galpha, MSPL_ERR_NULL_POINTER, "down_tail_bwd: null pointer");
+    MSPL_REQUIRE((reinf == nullptr) == (greinf == nullptr), MSPL_ERR_NULL_POINTER, "down_tail_bwd: reinf and greinf go together");
+    MSPL_REQUIRE(N > 0 && nin > 0 && nin < C && HW > 0, MSPL_ERR_BAD_SHAPE, "down_tail_bwd: bad shape N=%d nin=%d C=%d HW=%d", N, nin, C, HW);
+    MSPL_REQUIRE((HW & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)reinf | (uintptr_t)gy | (uintptr_t)ga | (uintptr_t)gb |
+                                     (uintptr_t)greinf)) & 15) == 0, MSPL_ERR_UNSUPPORTED,
+                 "down_tail_bwd: planes must be a multiple of 4 pixels and 16-byte aligned");
+    int chunks = 1;
+    while ((int64_t)N * C * chunks < 4096 && HW / 4 / (chunks * 2) >= 512) chunks *= 2;
+    const int64_t blocks = (int64_t)N * C * chunks;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "down_tail_bwd: grid too large");
+    hipLaunchKernelGGL(down_tail_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, reinf, gy, alpha, nin, C, HW / 4,
+                       chunks, ga, gb, greinf, galpha);
+    MSPL_CHECK_LAUNCH("down_tail_bwd");
+    return MSPL_OK;
+}
+
 extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy,
                                      const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
                                      int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,

@@ -565,17 +565,17 @@ class DownSampler(nn.Module):
         # tensor are summed by ONE launch instead of pairwise ATen adds)
         avg_out = ag.avgpool(input)
         eesp_out = self.eesp(input if alias is None else alias)
-        out = torch.cat([avg_out, eesp_out], 1)           # data movement only
         reinf = None
         if input2 is not None:
             with torch.no_grad():                          # the image carries no gradient
                 pyr = input2 if isinstance(input2, ImagePyramid) else ImagePyramid(input2)
-                img = pyr.at_height(out.shape[2])
-            if img.shape[3] != out.shape[3]:
+                img = pyr.at_height(avg_out.shape[2])
+            if img.shape[3] != avg_out.shape[3]:
                 raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton '
-                                   'dimension 3' % (out.shape[3], img.shape[3]))
+                                   'dimension 3' % (avg_out.shape[3], img.shape[3]))
             reinf = self.inp_reinf(img)
-        return ag.affine_prelu(out, None, None, self.act.weight, residual=reinf)
+        # PReLU(cat[avg_out, eesp_out] + reinf) without the concatenation (autograd.DownTailFn)
+        return ag.down_tail(avg_out, eesp_out, self.act.weight, reinf)
 
     def forward(self, input, input2=None, _alias=None):
         if _training_path():

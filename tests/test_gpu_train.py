@@ -84,6 +84,23 @@ def test_affine_prelu_fn():
     check_op(lambda c_, sh_: ag.affine_prelu(c_, None, sh_, None), lambda c_, sh_: c_ + sh_.view(1, -1, 1, 1), [c, sh])
 
 
+@pytest.mark.parametrize('shape', [(2, 6, 10, 8, 12), (1, 32, 96, 64, 120), (3, 5, 3, 2, 2), (2, 4, 4, 7, 9)])
+@pytest.mark.parametrize('with_reinf', [True, False])
+def test_down_tail_fn(shape, with_reinf):
+    """PReLU(cat[a, b] + reinf), the DownSampler tail without the concatenation (autograd.DownTailFn), forward and every gradient
+    against torch autograd; the last shape (63 pixels per plane) takes the cat + affine fallback."""
+    from mspl_amd import autograd as ag
+    N, nin, nb, h, w = shape
+    a, b = rnd(N, nin, h, w, seed=1), rnd(N, nb, h, w, seed=2)
+    al = rnd(nin + nb, seed=3).abs() * 0.3
+    if with_reinf:
+        r = rnd(N, nin + nb, h, w, seed=4)
+        check_op(lambda a_, b_, al_, r_: ag.down_tail(a_, b_, al_, r_), lambda a_, b_, al_, r_: F.prelu(torch.cat([a_, b_], 1) + r_, al_),
+                 [a, b, al, r])
+    else:
+        check_op(lambda a_, b_, al_: ag.down_tail(a_, b_, al_), lambda a_, b_, al_: F.prelu(torch.cat([a_, b_], 1), al_), [a, b, al])
+
+
 @pytest.mark.parametrize('cfg', [(2, 32, 24, 4, 9, 13, 1, 1, True), (1, 64, 64, 4, 6, 10, 1, 1, False), (2, 3, 8, 1, 12, 16, 3, 2, False),
                                  (1, 16, 16, 16, 11, 9, 3, 1, True), (1, 24, 12, 4, 8, 8, 3, 2, False), (2, 8, 13, 1, 10, 12, 1, 1, False),
                                  (2, 512, 16, 1, 18, 30, 1, 1, False),     # split-K form of the 1x1
