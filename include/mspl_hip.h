@@ -387,6 +387,11 @@ int mspl_hff_bn_prelu_suffix_bwd(const float* z, const float* gy, const float* s
 int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
                          int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
                          float* gaux, float* kld_out, void* stream);
+/* The same with the loss AND both gradients multiplied by out_scale (a micro-batch lane of a step back-propagates loss / lanes:
+ * the factor rides on the kernel's 1/npix instead of two full-size multiplies in the backward). */
+int mspl_uw_loss_scaled_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
+                                int32_t N, int32_t C, int32_t HW, float ce_scale, float out_scale, float* loss_acc,
+                                float* gpred, float* gaux, float* kld_out, void* stream);
 
 /* K13  dense (groups = 1) 1x1 / dilated 3x3 convolution on the fp32 matrix cores: the ASPP heads of nn_layers/aspp.py:7-99
  *      (Conv2d(Cin, Cout, k, padding = dilation, dilation) + BatchNorm + ReLU).  x: (N,Cin,H,W); w_packed: the conv weight

@@ -258,7 +258,9 @@ def _affine_backward(c, scale, shift, alpha, pre_add, residual, mean, inv, bn, s
     gz = torch.empty_like(c) if residual is not None else None
     gc = torch.empty_like(c)
     s_sc, s_sh, s_al = sinks
-    gacc = torch.zeros(3, C, device=dev) if (s_sc is None or s_sh is None or s_al is None) else None
+    # (a zeroed accumulator only for a gradient that is wanted and has no sink)
+    need = (scale is not None and s_sc is None) or (shift is not None and s_sh is None) or (alpha is not None and s_al is None)
+    gacc = torch.zeros(3, C, device=dev) if need else None
     gsc = (s_sc if s_sc is not None else gacc[0]) if scale is not None else None
     gsh = (s_sh if s_sh is not None else gacc[1]) if shift is not None else None
     gal = (s_al if s_al is not None else gacc[2]) if alpha is not None else None
@@ -704,25 +706,31 @@ class ChannelScaleFn(torch.autograd.Function):
 
 
 class UWLossFn(torch.autograd.Function):
-    """K11: criterion(pred + 0.5*aux, target, kld) * ce_scale + kld.mean() with kld = PixelwiseKLD(pred, aux)."""
+    """K11: (criterion(pred + 0.5*aux, target, kld) * ce_scale + kld.mean()) * out_scale with kld = PixelwiseKLD(pred, aux).
+    out_scale rides on the kernel's 1/npix (a micro-batch lane back-propagates loss / lanes).  root=True: the caller promises that
+    this value is the ROOT of the backward (`loss.backward()` on it, upstream gradient 1): the backward then hands out the gradients
+    the forward kernel wrote instead of multiplying both full-size tensors by a one."""
 
     @staticmethod
-    def forward(ctx, pred, aux, target, class_weights, ce_scale):
+    def forward(ctx, pred, aux, target, class_weights, ce_scale, out_scale, root):
         pred, aux = _c(pred), _c(aux)
         N, C = pred.shape[:2]
         hw = pred[0, 0].numel()
         target = _c(target.to(torch.int64))
         loss = torch.zeros(1, device=pred.device, dtype=torch.float32)
         gpred, gaux = torch.empty_like(pred), torch.empty_like(aux)
-        check(lib.mspl_uw_loss_fwd_bwd(_p(pred), _p(aux), _p(target), _p(_c(class_weights.float())), N, C, hw, float(ce_scale),
-                                       _p(loss), _p(gpred), _p(gaux), None, _stream()))
+        check(lib.mspl_uw_loss_scaled_fwd_bwd(_p(pred), _p(aux), _p(target), _p(_c(class_weights.float())), N, C, hw, float(ce_scale),
+                                              float(out_scale), _p(loss), _p(gpred), _p(gaux), None, _stream()))
         ctx.save_for_backward(gpred, gaux)
+        ctx.root = bool(root)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         gpred, gaux = ctx.saved_tensors
-        return gpred * g, gaux * g, None, None, None
+        if ctx.root:
+            return gpred, gaux, None, None, None, None, None
+        return gpred * g, gaux * g, None, None, None, None, None
 
 
 # functional spellings
@@ -916,5 +924,5 @@ gap_gate = GapGateFn.apply
 channel_scale = ChannelScaleFn.apply
 
 
-def uw_loss(pred, aux, target, class_weights, ce_scale=20.0):
-    return UWLossFn.apply(pred, aux, target, class_weights, ce_scale)
+def uw_loss(pred, aux, target, class_weights, ce_scale=20.0, out_scale=1.0, root=False):
+    return UWLossFn.apply(pred, aux, target, class_weights, ce_scale, out_scale, root)

@@ -1150,17 +1150,29 @@ extern "C" int mspl_gap_gate_bwd_accum(const float* ggate, const float* gate, co
 }
 
 /* loss_acc (1 float, device) is ACCUMULATED into (caller zeroes).  gpred/gaux/kld_out may be NULL (forward only). */
-extern "C" int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
-                                    int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
-                                    float* gaux, float* kld_out, void* stream) {
+static int uw_loss_launch(const float* pred, const float* aux, const int64_t* target, const float* class_weights, int32_t N, int32_t C,
+                          int32_t HW, float ce_scale, float out_scale, float* loss_acc, float* gpred, float* gaux, float* kld_out,
+                          void* stream) {
     MSPL_REQUIRE(pred && aux && target && class_weights && loss_acc, MSPL_ERR_NULL_POINTER, "uw_loss: null pointer");
     MSPL_REQUIRE((gpred == nullptr) == (gaux == nullptr), MSPL_ERR_NULL_POINTER, "uw_loss: gpred and gaux go together");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "uw_loss: bad shape N=%d C=%d HW=%d", N, C, HW);
     const int64_t total = (int64_t)N * HW;
     hipLaunchKernelGGL(uw_loss_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, aux, target,
-                       class_weights, N, C, HW, ce_scale, 1.0f / (float)total, loss_acc, gpred, gaux, kld_out);
+                       class_weights, N, C, HW, ce_scale, out_scale / (float)total, loss_acc, gpred, gaux, kld_out);
     MSPL_CHECK_LAUNCH("uw_loss");
     return MSPL_OK;
+}
+
+extern "C" int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
+                                    int32_t N, int32_t C, int32_t HW, float ce_scale, float* loss_acc, float* gpred,
+                                    float* gaux, float* kld_out, void* stream) {
+    return uw_loss_launch(pred, aux, target, class_weights, N, C, HW, ce_scale, 1.0f, loss_acc, gpred, gaux, kld_out, stream);
+}
+
+extern "C" int mspl_uw_loss_scaled_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
+                                           int32_t N, int32_t C, int32_t HW, float ce_scale, float out_scale, float* loss_acc,
+                                           float* gpred, float* gaux, float* kld_out, void* stream) {
+    return uw_loss_launch(pred, aux, target, class_weights, N, C, HW, ce_scale, out_scale, loss_acc, gpred, gaux, kld_out, stream);
 }
 
 extern "C" int mspl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

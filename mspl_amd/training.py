@@ -145,7 +145,7 @@ class GraphedTrainStep:
                 with torch.enable_grad(), ag.grad_sinks(), tr.active():
                     layers.prefold_frozen_bn(model)
                     pred, aux = model(self.images)
-                    self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale)
+                    self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale, root=True)
                     self.loss.backward()
         else:
             # what every lane needs first: zeroed gradients, this step's transposed weights and folded BatchNorms (their tensors live
@@ -173,7 +173,7 @@ class GraphedTrainStep:
                     with torch.cuda.graph(g, stream=st):
                         with torch.enable_grad(), ag.grad_sinks(), tr.active(refresh=False):
                             pred, aux = model(self.images[i * b:(i + 1) * b])
-                            loss = ag.uw_loss(pred, aux, self.labels[i * b:(i + 1) * b], self.cw, ce_scale) * (1.0 / self.lanes)
+                            loss = ag.uw_loss(pred, aux, self.labels[i * b:(i + 1) * b], self.cw, ce_scale, out_scale=1.0 / self.lanes, root=True)
                             loss.backward()
                     self.lane_graphs.append(g)
                     self.lane_losses.append(loss)
