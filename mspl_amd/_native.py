@@ -83,6 +83,9 @@ SIGNATURES = {
     'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
+    'mspl_bn_fused_workspace_bytes': [c_i32],
+    'mspl_bn_batch_stats_fused_fwd': [c_f32p, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float] + [c_f32p] * 4 + [ctypes.c_void_p] + [c_f32p] * 4 + [ctypes.c_void_p],
+    'mspl_bn_train_prelu_bwd': [c_f32p] * 9 + [c_i32] * 3 + [c_f32p, c_f32p, ctypes.c_void_p, c_i32] + [c_f32p] * 5 + [ctypes.c_void_p],
     'mspl_down_tail_fwd': [c_f32p] * 4 + [c_i32] * 4 + [c_f32p, ctypes.c_void_p],
     'mspl_down_tail_bwd': [c_f32p] * 5 + [c_i32] * 4 + [c_f32p] * 4 + [ctypes.c_void_p],
     'mspl_bn_prelu_bwd': [c_f32p] * 9 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
@@ -157,6 +160,7 @@ def _load():
     lib.mspl_pyr_down_prep_lds_bytes.restype = ctypes.c_int64      # a size query, not a status
     lib.mspl_nid_workspace_floats.restype = ctypes.c_int64
     lib.mspl_eesp_dw_exp_pack_floats.restype = ctypes.c_int64
+    lib.mspl_bn_fused_workspace_bytes.restype = ctypes.c_int64
     lib.mspl_eesp_dw_exp_next_pack_floats.restype = ctypes.c_int64
     lib.mspl_label_epilogue_hist_workspace_bytes.restype = ctypes.c_int64
     lib.mspl_png_writer_create.restype = ctypes.c_void_p          # a handle

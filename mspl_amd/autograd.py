@@ -849,30 +849,31 @@ class BNBatchStatsFn(torch.autograd.Function):
 
 class BNTrainPReLUFn(torch.autograd.Function):
     """y = PReLU(BatchNorm_train(z) + residual) with batch statistics (nn.BatchNorm2d in train(), the supervised loop), as ONE
-    autograd node: statistics + fold kernel, affine / PReLU kernel; backward: the affine backward (gc, d scale, d shift, d alpha),
-    one C-thread kernel for (d gamma, d beta, p, q), and ONE pointwise launch gz = p * z + q + gc.  As two nodes (BNBatchStatsFn +
-    AffinePReLUFn) autograd added the two full-size gradients of z with an ATen kernel per BatchNorm and accumulated d gamma / d beta
-    with two more (320 `add_` launches, 1.85 ms of a 17.5 ms iteration)."""
+    autograd node of FOUR launches: statistics + fold (the workgroup that adds a channel's last partial finishes the channel), the
+    affine / PReLU kernel; backward: the affine backward whose last workgroup per channel turns the sums into (d gamma, d beta, p, q),
+    and ONE pointwise launch gz = p * z + q + gc.  `ws`: the BatchNorm's persistent workspace (zeroed once, handed back zeroed by both
+    kernels: no memset, no finalize launch, no coefficient launch, no zeros() per call -- eight launches before).  As two nodes
+    (BNBatchStatsFn + AffinePReLUFn) autograd added the two full-size gradients of z with an ATen kernel per BatchNorm and accumulated
+    d gamma / d beta with two more (320 `add_` launches, 1.85 ms of a 17.5 ms iteration)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, alpha, residual, running_mean, running_var, eps, momentum):
+    def forward(ctx, z, gamma, beta, alpha, residual, running_mean, running_var, eps, momentum, ws):
         z = _c(z)
         residual = None if residual is None else _c(residual)
         N, C = z.shape[:2]
         hw = z[0, 0].numel()
-        ws = torch.empty(2 * C, dtype=torch.float64, device=z.device)
         st = torch.empty(4, C, dtype=torch.float32, device=z.device)       # mean, invstd, scale, shift
         gamma_c, beta_c = _c(gamma), _c(beta)
-        check(lib.mspl_bn_batch_stats_fold_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma_c),
-                                               _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _stream()))
+        check(lib.mspl_bn_batch_stats_fused_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma_c),
+                                                _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _stream()))
         y = ops.pointwise(z, Epi(st[2], st[3], alpha, residual=residual))
-        ctx.save_for_backward(z, gamma_c, alpha, residual, st)
+        ctx.save_for_backward(z, gamma_c, alpha, residual, st, ws)
         ctx.sinks = (_sink(gamma), _sink(beta), _sink(alpha))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        z, gamma, alpha, residual, st = ctx.saved_tensors
+        z, gamma, alpha, residual, st, ws = ctx.saved_tensors
         mean, invstd, scale, shift = st[0], st[1], st[2], st[3]
         gy = _c(gy)
         N, C = z.shape[:2]
@@ -880,18 +881,26 @@ class BNTrainPReLUFn(torch.autograd.Function):
         s_g, s_b, s_a = ctx.sinks
         gres = torch.empty_like(z) if residual is not None else None
         gc = torch.empty_like(z)
-        acc = torch.zeros(3, C, device=z.device)                          # d scale, d shift, d alpha (when it has no sink)
-        gal = (s_a if s_a is not None else acc[2]) if alpha is not None else None
-        check(lib.mspl_affine_prelu_bwd(_p(z), None, _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), N, C, hw,
-                                        _p(gres), _p(gc), _p(acc[0]), _p(acc[1]), _p(gal), _stream()))
+        gal = None
+        if alpha is not None:
+            gal = s_a if s_a is not None else torch.zeros(C, device=z.device)
         direct = s_g is not None and s_b is not None
         out = torch.empty(4, C, dtype=torch.float32, device=z.device)      # d gamma, d beta, p, q
-        check(lib.mspl_bn_batch_stats_bwd_coeffs(_p(acc[0]), _p(acc[1]), _p(gamma), _p(mean), _p(invstd), _p(scale), C,
-                                                 float(N * hw), 1 if direct else 0, _p(s_g if direct else out[0]),
-                                                 _p(s_b if direct else out[1]), _p(out[2]), _p(out[3]), _stream()))
+        check(lib.mspl_bn_train_prelu_bwd(_p(z), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(gamma), _p(mean), _p(invstd),
+                                          N, C, hw, _p(gres), _p(gc), _p(ws), 1 if direct else 0, _p(s_g if direct else out[0]),
+                                          _p(s_b if direct else out[1]), _p(gal), _p(out[2]), _p(out[3]), _stream()))
         gz = ops.pointwise(z, Epi(out[2], out[3], residual=gc))           # p * z + q + gc
         return (gz, None if direct else out[0], None if direct else out[1],
-                None if (alpha is None or s_a is not None) else acc[2], gres, None, None, None, None)
+                None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None)
+
+
+def _bn_workspace(bn, device):
+    """The BatchNorm's persistent, zeroed workspace of the two fused kernels (they hand it back zeroed)."""
+    ws = bn.__dict__.get('_mspl_bn_ws')
+    if ws is None or ws.device != device:
+        ws = torch.zeros(int(lib.mspl_bn_fused_workspace_bytes(bn.num_features)) // 8 + 1, dtype=torch.float64, device=device)
+        bn.__dict__['_mspl_bn_ws'] = ws
+    return ws
 
 
 def bn_train_prelu(z, bn, alpha=None, residual=None):
@@ -899,7 +908,8 @@ def bn_train_prelu(z, bn, alpha=None, residual=None):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
-    y = BNTrainPReLUFn.apply(z, bn.weight, bn.bias, alpha, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+    y = BNTrainPReLUFn.apply(z, bn.weight, bn.bias, alpha, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                             _bn_workspace(bn, z.device))
     with torch.no_grad():
         bn.num_batches_tracked += 1
     return y

@@ -75,6 +75,76 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// Statistics + finalize in ONE launch: the workgroup that adds the last partial of a channel (device-scope counter; the classic
+// "last block done" pattern with the partials carried by atomics: adds -> wait for their acknowledgement -> counter) finishes that channel -- mean, 1/std, the fold, the running-statistics
+// update -- and hands the channel's workspace back zeroed, so the caller keeps ONE persistent workspace per BatchNorm (zeroed once) and
+// neither a memset nor a finalize launch runs per call.  ws: [2C doubles | C counters].
+__global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __restrict__ z, int C, int HW, int per_block, unsigned per_channel,
+                                                             double* __restrict__ ws, unsigned* __restrict__ cnt, double M, float eps,
+                                                             float momentum, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ scale,
+                                                             float* __restrict__ shift) {
+    const int c = blockIdx.z, n = blockIdx.y;
+    const float k = z[(size_t)c * HW];
+    const float* p = z + ((size_t)n * C + c) * (size_t)HW;
+    const int lo = blockIdx.x * per_block;
+    const int hi = min(HW, lo + per_block);
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0 && (per_block & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float a = p[i] - k;
+            s1 += a;
+            s2 += a * a;
+        }
+    }
+    double d1 = s1, d2 = s2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        d1 += __shfl_down(d1, o, 64);
+        d2 += __shfl_down(d2, o, 64);
+    }
+    __shared__ double part[8];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = d1; part[4 + (threadIdx.x >> 6)] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(ws + 2 * c, (part[0] + part[1]) + (part[2] + part[3]));
+        atomicAdd(ws + 2 * c + 1, (part[4] + part[5]) + (part[6] + part[7]));
+        // the sums travel by device-scope atomics (performed at the memory side): waiting for them to be acknowledged orders them before
+        // the counter atomic -- no __threadfence(), whose L2 write-back costs microseconds per workgroup on this chip (measured: the
+        // iteration went from 15 to 28 ms with two fences per workgroup)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(cnt + c, 1u) == per_channel - 1) {                 // every other workgroup of this channel has added
+            // read-and-clear with atomics (they execute at the memory side, after every add above)
+            const double e1 = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(ws + 2 * c), 0ull)) / M;
+            const double e2 = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(ws + 2 * c + 1), 0ull)) / M;
+            cnt[c] = 0u;
+            const double mu = (double)k + e1;
+            double var = e2 - e1 * e1;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+            mean[c] = mf;
+            invstd[c] = isf;
+            const float sc = gamma[c] * isf;
+            scale[c] = sc;
+            shift[c] = beta[c] + (-mf) * sc;
+            if (running_mean) {
+                const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        }
+    }
+}
+
 // Backward of the batch statistics' dependence on z (autograd.BNBatchStatsFn): with t = d scale - mean * d shift per channel,
 //   d gamma = t * invstd,   gz = p * z + q  with  p = -gamma * t * invstd^3 / M,  q = -d shift * scale / M - p * mean.
 // One launch of C threads instead of eight ATen launches on C-element tensors per BatchNorm (~110 BatchNorms per iteration).
@@ -132,6 +202,35 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
                                             double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
     return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int64_t mspl_bn_fused_workspace_bytes(int32_t C) {
+    // forward: 2C doubles + C counters; backward (mspl_bn_train_prelu_bwd): 2C floats + C counters, placed behind it
+    return (int64_t)C * (16 + 4 + 8 + 4) + 64;
+}
+
+extern "C" int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                             float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                             void* ws_zeroed, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    MSPL_REQUIRE(z && ws_zeroed && mean && invstd && gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fused: null pointer");
+    MSPL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MSPL_ERR_NULL_POINTER,
+                 "bn_batch_stats_fused: running_mean and running_var go together");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0 && N <= 65535 && C <= 65535, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: bad shape N=%d C=%d HW=%d",
+                 N, C, HW);
+    MSPL_REQUIRE(((uintptr_t)ws_zeroed & 7) == 0, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: workspace must be 8-byte aligned");
+    int chunks = ceil_div(2048, N * C);
+    if (chunks < 1) chunks = 1;
+    int per_block = ceil_div(HW, chunks);
+    if (per_block < 4096) per_block = 4096;
+    per_block = (per_block + 3) & ~3;
+    chunks = ceil_div(HW, per_block);
+    double* sums = static_cast<double*>(ws_zeroed);
+    unsigned* cnt = reinterpret_cast<unsigned*>(sums + 2 * (size_t)C);
+    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(256), 0, (hipStream_t)stream, z, C, HW,
+                       per_block, (unsigned)(chunks * N), sums, cnt, (double)N * (double)HW, eps, momentum, running_mean, running_var, mean,
+                       invstd, gamma, beta, scale, shift);
+    MSPL_CHECK_LAUNCH("bn_batch_stats_fused");
+    return MSPL_OK;
 }
 
 extern "C" int mspl_bn_batch_stats_bwd_coeffs(const float* gscale, const float* gshift, const float* gamma, const float* mean,

@@ -272,6 +272,17 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_weight_kernel(const float* __
         atomicAdd(&gw[((size_t)grp * M + m0 + tmi) * K + k0 + tki], acc);
 }
 
+// Batch-statistics BatchNorm (the supervised loop): what follows the channel sums of the affine backward -- d gamma, d beta and the
+// coefficients of gz = p * z + q (mspl_bn_batch_stats_bwd_coeffs) -- done by the workgroup that adds a channel's last partial ("last
+// block done": atomic adds -> their acknowledgement -> counter), which also hands the two sums and the counter back zeroed (persistent workspace).
+struct BnTail {
+    unsigned* cnt;            // null: no tail (gscale / gshift are the caller's accumulators)
+    unsigned per_channel;     // workgroups per channel
+    const float* gamma;  const float* mean;  const float* invstd;
+    float inv_m;  int accumulate;
+    float* ggamma;  float* gbeta;  float* pc;  float* qc;
+};
+
 // ---- affine + PReLU backward.  Forward: z = (c + pre) * scale + shift + res ; y = z > 0 ? z : alpha * z.
 // Outputs gz (optional) and gc = gz * scale; per-channel sums into gscale / gshift / galpha (atomics; zeroed by caller).
 __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __restrict__ c, const float* __restrict__ pre,
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
                                                                float* __restrict__ gz_out, float* __restrict__ gc_out,
                                                                float* __restrict__ gscale, float* __restrict__ gshift,
                                                                float* __restrict__ galpha, const float* __restrict__ bn_mean,
-                                                               const float* __restrict__ bn_inv) {
+                                                               const float* __restrict__ bn_inv, BnTail tl) {
     int b = blockIdx.x;
     const int chunk = b % chunks;  b /= chunks;
     const int ch = b % C;
@@ -355,6 +366,21 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
         if (gscale) atomicAdd(&gscale[ch], bn_inv ? (t_scale - bn_mean[ch] * t_shift) * bn_inv[ch] : t_scale);
         if (gshift) atomicAdd(&gshift[ch], t_shift);
         if (galpha && act) atomicAdd(&galpha[ch], (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]));
+        if (tl.cnt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (atomics acknowledged before the counter: see bn_stats_fused_kernel)
+            if (atomicAdd(tl.cnt + ch, 1u) == tl.per_channel - 1) {
+                const float dsc = __uint_as_float(atomicExch(reinterpret_cast<unsigned*>(gscale + ch), 0u));      // read and clear
+                const float dsh = __uint_as_float(atomicExch(reinterpret_cast<unsigned*>(gshift + ch), 0u));
+                tl.cnt[ch] = 0u;
+                const float is = tl.invstd[ch], mu = tl.mean[ch];
+                const float t = dsc + (-mu) * dsh;
+                tl.ggamma[ch] = tl.accumulate ? tl.ggamma[ch] + t * is : t * is;
+                tl.gbeta[ch] = tl.accumulate ? tl.gbeta[ch] + dsh : dsh;
+                const float p = ((tl.gamma[ch] * t) * (is * is * is)) * (-tl.inv_m);
+                tl.pc[ch] = p;
+                tl.qc[ch] = (dsh * sc) * (-tl.inv_m) - p * mu;
+            }
+        }
     }
 }
 
@@ -907,15 +933,16 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
 static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const float* residual, const float* gy,
                                    const float* scale, const float* shift, const float* alpha, int32_t N, int32_t C,
                                    int32_t HW, float* gz, float* gc, float* gscale, float* gshift, float* galpha,
-                                   const float* bn_mean, const float* bn_inv, void* stream) {
+                                   const float* bn_mean, const float* bn_inv, void* stream, BnTail tl = BnTail()) {
     MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
     int chunks = 1;
     while ((int64_t)N * C * chunks < 4096 && HW / (chunks * 2) >= 2048) chunks *= 2;
     const int64_t blocks = (int64_t)N * C * chunks;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: grid too large");
+    tl.per_channel = (unsigned)(N * chunks);
     hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, pre_add, residual, gy,
-                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha, bn_mean, bn_inv);
+                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha, bn_mean, bn_inv, tl);
     MSPL_CHECK_LAUNCH("affine_prelu_bwd");
     return MSPL_OK;
 }
@@ -1020,6 +1047,24 @@ extern "C" int mspl_affine_prelu_bwd(const float* c, const float* pre_add, const
                                      void* stream) {
     return affine_prelu_bwd_launch(c, pre_add, residual, gy, scale, shift, alpha, N, C, HW, gz, gc, gscale, gshift, galpha, nullptr,
                                    nullptr, stream);
+}
+
+extern "C" int mspl_bn_train_prelu_bwd(const float* z, const float* residual, const float* gy, const float* scale, const float* shift,
+                                       const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
+                                       int32_t HW, float* gres, float* gc, void* ws_zeroed, int32_t accumulate, float* ggamma, float* gbeta,
+                                       float* galpha, float* p, float* q, void* stream) {
+    MSPL_REQUIRE(scale && shift && gamma && mean && invstd && ws_zeroed && ggamma && gbeta && p && q && gc, MSPL_ERR_NULL_POINTER,
+                 "bn_train_prelu_bwd: null pointer");
+    MSPL_REQUIRE(((uintptr_t)ws_zeroed & 7) == 0, MSPL_ERR_BAD_SHAPE, "bn_train_prelu_bwd: workspace must be 8-byte aligned");
+    // the backward's part of the BatchNorm's persistent workspace (mspl_bn_fused_workspace_bytes): behind the forward's 2C doubles + C counters
+    float* sums = reinterpret_cast<float*>(static_cast<char*>(ws_zeroed) + (size_t)C * 20 + ((8 - ((size_t)C * 20) % 8) % 8));
+    BnTail tl = BnTail();
+    tl.cnt = reinterpret_cast<unsigned*>(sums + 2 * (size_t)C);
+    tl.gamma = gamma; tl.mean = mean; tl.invstd = invstd;
+    tl.inv_m = (float)(1.0 / ((double)N * (double)HW)); tl.accumulate = accumulate;
+    tl.ggamma = ggamma; tl.gbeta = gbeta; tl.pc = p; tl.qc = q;
+    return affine_prelu_bwd_launch(z, nullptr, residual, gy, scale, shift, alpha, N, C, HW, gres, gc, sums, sums + C, galpha, nullptr, nullptr,
+                                   stream, tl);
 }
 
 extern "C" int mspl_bn_prelu_bwd(const float* c, const float* pre_add, const float* residual, const float* gy, const float* scale,
