@@ -492,14 +492,16 @@ int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t H
 /* The training-mode BatchNorm + PReLU node of the supervised loop with HALF the launches: a per-BatchNorm persistent workspace
  * (mspl_bn_fused_workspace_bytes(C) bytes, zeroed ONCE by the caller, handed back zeroed by every call) replaces the memset + finalize
  * launches of mspl_bn_batch_stats_fold_fwd and the separate mspl_bn_batch_stats_bwd_coeffs launch: the workgroup that adds a
- * channel's last partial finishes the channel.  _fused_fwd: same outputs as _fold_fwd.  mspl_bn_train_prelu_bwd: the backward of
+ * channel's last partial finishes the channel.  _fused_fwd: same outputs as _fold_fwd; num_batches_tracked (may be NULL): the module's
+ * int64 counter, incremented by one (nn.BatchNorm2d does it per forward: an ATen launch per BatchNorm otherwise).  mspl_bn_train_prelu_bwd: the backward of
  * y = PReLU(z * scale + shift + residual) with (scale, shift) the batch-statistics fold of z: gres (may be NULL), gc = direct gradient
  * of z through the affine map, ggamma / gbeta (accumulate != 0: added to), galpha (ACCUMULATED, caller zeroes or passes the parameter's
  * gradient), and the coefficients p, q (C floats each) of the statistics' path: dL/dz = p * z + q + gc (one mspl_pointwise_fwd). */
 int64_t mspl_bn_fused_workspace_bytes(int32_t C);
 int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                   float* running_mean, float* running_var, const float* gamma, const float* beta,
-                                  void* ws_zeroed, float* mean, float* invstd, float* scale, float* shift, void* stream);
+                                  void* ws_zeroed, float* mean, float* invstd, float* scale, float* shift,
+                                  int64_t* num_batches_tracked, void* stream);
 int mspl_bn_train_prelu_bwd(const float* z, const float* residual, const float* gy, const float* scale, const float* shift,
                             const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
                             int32_t HW, float* gres, float* gc, void* ws_zeroed, int32_t accumulate, float* ggamma, float* gbeta,

@@ -857,7 +857,7 @@ class BNTrainPReLUFn(torch.autograd.Function):
     d gamma / d beta with two more (320 `add_` launches, 1.85 ms of a 17.5 ms iteration)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, alpha, residual, running_mean, running_var, eps, momentum, ws):
+    def forward(ctx, z, gamma, beta, alpha, residual, running_mean, running_var, eps, momentum, ws, nbt):
         z = _c(z)
         residual = None if residual is None else _c(residual)
         N, C = z.shape[:2]
@@ -865,7 +865,7 @@ class BNTrainPReLUFn(torch.autograd.Function):
         st = torch.empty(4, C, dtype=torch.float32, device=z.device)       # mean, invstd, scale, shift
         gamma_c, beta_c = _c(gamma), _c(beta)
         check(lib.mspl_bn_batch_stats_fused_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma_c),
-                                                _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _stream()))
+                                                _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(nbt), _stream()))
         y = ops.pointwise(z, Epi(st[2], st[3], alpha, residual=residual))
         ctx.save_for_backward(z, gamma_c, alpha, residual, st, ws)
         ctx.sinks = (_sink(gamma), _sink(beta), _sink(alpha))
@@ -891,7 +891,7 @@ class BNTrainPReLUFn(torch.autograd.Function):
                                           _p(s_b if direct else out[1]), _p(gal), _p(out[2]), _p(out[3]), _stream()))
         gz = ops.pointwise(z, Epi(out[2], out[3], residual=gc))           # p * z + q + gc
         return (gz, None if direct else out[0], None if direct else out[1],
-                None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None)
+                None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None, None)
 
 
 def _bn_workspace(bn, device):
@@ -908,11 +908,11 @@ def bn_train_prelu(z, bn, alpha=None, residual=None):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
-    y = BNTrainPReLUFn.apply(z, bn.weight, bn.bias, alpha, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
-                             _bn_workspace(bn, z.device))
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
-    return y
+    nbt = bn.num_batches_tracked          # incremented by the statistics kernel (an int64 CUDA scalar; nn.BatchNorm2d adds 1 per forward)
+    if not (nbt.is_cuda and nbt.dtype == torch.int64):
+        raise RuntimeError('mspl_amd: num_batches_tracked must be an int64 tensor on the device')
+    return BNTrainPReLUFn.apply(z, bn.weight, bn.bias, alpha, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                _bn_workspace(bn, z.device), nbt)
 
 
 def bn_batch_stats(z, bn):

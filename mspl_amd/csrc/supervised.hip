@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __rest
                                                              float* __restrict__ running_var, float* __restrict__ mean,
                                                              float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ scale,
-                                                             float* __restrict__ shift) {
+                                                             float* __restrict__ shift, long long* __restrict__ nbt) {
     const int c = blockIdx.z, n = blockIdx.y;
     const float k = z[(size_t)c * HW];
     const float* p = z + ((size_t)n * C + c) * (size_t)HW;
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __rest
                 running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
                 running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
             }
+            if (nbt && c == 0) *nbt += 1;                               // nn.BatchNorm2d's num_batches_tracked (one writer)
         }
     }
 }
@@ -211,7 +212,8 @@ extern "C" int64_t mspl_bn_fused_workspace_bytes(int32_t C) {
 
 extern "C" int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                              float* running_mean, float* running_var, const float* gamma, const float* beta,
-                                             void* ws_zeroed, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+                                             void* ws_zeroed, float* mean, float* invstd, float* scale, float* shift,
+                                             int64_t* num_batches_tracked, void* stream) {
     MSPL_REQUIRE(z && ws_zeroed && mean && invstd && gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fused: null pointer");
     MSPL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MSPL_ERR_NULL_POINTER,
                  "bn_batch_stats_fused: running_mean and running_var go together");
@@ -228,7 +230,7 @@ extern "C" int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t 
     unsigned* cnt = reinterpret_cast<unsigned*>(sums + 2 * (size_t)C);
     hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(256), 0, (hipStream_t)stream, z, C, HW,
                        per_block, (unsigned)(chunks * N), sums, cnt, (double)N * (double)HW, eps, momentum, running_mean, running_var, mean,
-                       invstd, gamma, beta, scale, shift);
+                       invstd, gamma, beta, scale, shift, reinterpret_cast<long long*>(num_batches_tracked));
     MSPL_CHECK_LAUNCH("bn_batch_stats_fused");
     return MSPL_OK;
 }
