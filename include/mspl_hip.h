@@ -497,6 +497,10 @@ int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t H
  * y = PReLU(z * scale + shift + residual) with (scale, shift) the batch-statistics fold of z: gres (may be NULL), gc = direct gradient
  * of z through the affine map, ggamma / gbeta (accumulate != 0: added to), galpha (ACCUMULATED, caller zeroes or passes the parameter's
  * gradient), and the coefficients p, q (C floats each) of the statistics' path: dL/dz = p * z + q + gc (one mspl_pointwise_fwd). */
+/* Statistics path of a batch-statistics BatchNorm over a concatenation whose gradient is branch-major (the pyramid body's merge_layer.0):
+ * g (nb,N,P,HW) += p[i*P+c] * z[n, i*P+c] + q[i*P+c] with z (N, nb*P, HW); HW % 4 == 0. */
+int mspl_bn_stats_path_add(float* g, const float* z, const float* p, const float* q, int32_t N, int32_t P, int32_t nb, int32_t HW,
+                           void* stream);
 int64_t mspl_bn_fused_workspace_bytes(int32_t C);
 int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                   float* running_mean, float* running_var, const float* gamma, const float* beta,

@@ -554,6 +554,164 @@ class PyrBodyFn(torch.autograd.Function):
                 *[ret(wsinks[i], g_stage[i]) for i in range(nb)])
 
 
+_CONST_VECS = {}
+
+
+def _const_vec(value, n, device):
+    """A cached vector of `n` copies of `value` (identity BatchNorm folds of the batch-statistics pyramid node)."""
+    key = (float(value), int(n), str(device))
+    t = _CONST_VECS.get(key)
+    if t is None:
+        t = _CONST_VECS[key] = torch.full((int(n),), float(value), device=device, dtype=torch.float32)
+    return t
+
+
+class PyrBodyBNFn(torch.autograd.Function):
+    """PyrBodyFn for BatchNorms in train() (the supervised loop): the same fused kernels, run around the two batch-statistics passes.
+
+    forward   the fused training kernel once for the branch values (zcat does not depend on the BatchNorms), the statistics of the
+              concatenation -> merge_layer.0's fold, the fused kernel again for the merge convolution over PReLU(BN(zcat)), the
+              statistics of its bare result -> merge_layer.2's fold, one affine / PReLU launch.  (The branches are computed twice: two
+              launches of ~60-120 us against ~20 launches of the node-per-op form.)
+    backward  merge_layer.2's BatchNorm + PReLU as in BNTrainPReLUFn (direct path + p * z + q); mspl_pyrpool_merge_bwd with that
+              BatchNorm as the IDENTITY (its gradient is already applied) and RAW (d scale, d shift) sums for merge_layer.0, whose
+              statistics path is then added to the branch-major gradient (mspl_bn_stats_path_add); the branch backward as in PyrBodyFn.
+    bnp0 / bnp2: (running_mean, running_var, eps, momentum, workspace, num_batches_tracked) of the two BatchNorms."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, bnp0, bnp2, br_gamma, br_beta, br_alpha, merge_w, m_gamma, m_beta, m_alpha, *stage_ws):
+        x = _c(x)
+        N, P, h, w = x.shape
+        nb = len(sizes)
+        dev = x.device
+        down = [i for i, (hs_, ws_) in enumerate(sizes) if (hs_ < h or ws_ < w)]
+        pooled, down_es = {}, [None] * nb
+        for i in down:
+            pooled[i] = ops.adaptive_avgpool(x, sizes[i])
+            down_es[i] = ops.conv3x3(pooled[i], stage_ws[i], P)
+        hs = (ctypes.c_int32 * nb)(*[int(s_[0]) for s_ in sizes])
+        ws = (ctypes.c_int32 * nb)(*[int(s_[1]) for s_ in sizes])
+        sw, de = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+        keep = []
+        for i in range(nb):
+            if i in down:
+                de[i] = down_es[i].data_ptr()
+            else:
+                t = _c(stage_ws[i])
+                keep.append(t)
+                sw[i] = t.data_ptr()
+        merge_w = _c(merge_w)
+        br_alpha_c = _c(br_alpha)
+        C0 = nb * P
+        one0, zero0 = _const_vec(1.0, C0, dev), _const_vec(0.0, C0, dev)
+        mraw = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
+        zcat = torch.empty((N, C0, h, w), device=dev, dtype=torch.float32)
+        ep, keep2 = ops._build(Epi(), mraw, 0, N, P, h * w)                   # bare merge convolution
+        # (1) branch values
+        check(lib.mspl_pyrpool_fused_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(one0), _p(zero0), _p(br_alpha_c),
+                                               _p(merge_w), ctypes.byref(ep), _p(mraw), _p(zcat), _stream()))
+        # (2) merge_layer.0: statistics of the concatenation
+        rm0, rv0, eps0, mom0, ws0, nbt0 = bnp0
+        st0 = torch.empty(4, C0, dtype=torch.float32, device=dev)             # mean, invstd, scale, shift
+        g0, b0 = _c(br_gamma), _c(br_beta)
+        check(lib.mspl_bn_batch_stats_fused_fwd(_p(zcat), N, C0, h * w, eps0, mom0, _p(rm0), _p(rv0), _p(g0), _p(b0), _p(ws0),
+                                                _p(st0[0]), _p(st0[1]), _p(st0[2]), _p(st0[3]), _p(nbt0), _stream()))
+        # (3) the merge convolution over PReLU(BN(zcat)) (the kernel recomputes the branches)
+        check(lib.mspl_pyrpool_fused_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(st0[2]), _p(st0[3]), _p(br_alpha_c),
+                                               _p(merge_w), ctypes.byref(ep), _p(mraw), _p(zcat), _stream()))
+        # (4) merge_layer.2's BatchNorm + PReLU
+        rm2, rv2, eps2, mom2, ws2, nbt2 = bnp2
+        st2 = torch.empty(4, P, dtype=torch.float32, device=dev)
+        g2, b2 = _c(m_gamma), _c(m_beta)
+        check(lib.mspl_bn_batch_stats_fused_fwd(_p(mraw), N, P, h * w, eps2, mom2, _p(rm2), _p(rv2), _p(g2), _p(b2), _p(ws2),
+                                                _p(st2[0]), _p(st2[1]), _p(st2[2]), _p(st2[3]), _p(nbt2), _stream()))
+        y = ops.pointwise(mraw, Epi(st2[2], st2[3], m_alpha))
+        ctx.save_for_backward(x, zcat, mraw, st0, st2, br_alpha_c, merge_w, m_alpha, g0, g2, ws2, *stage_ws, *[pooled[i] for i in down])
+        ctx.sizes, ctx.down = [tuple(int(v) for v in s_) for s_ in sizes], down
+        ctx.sinks = ([_sink(t) for t in (br_gamma, br_beta, br_alpha, merge_w, m_gamma, m_beta, m_alpha)],
+                     [_sink(t) for t in stage_ws])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sv = ctx.saved_tensors
+        x, zcat, mraw, st0, st2, br_alpha, merge_w, m_alpha, g0, g2, ws2 = sv[:11]
+        sizes, down = ctx.sizes, ctx.down
+        nb = len(sizes)
+        stage_ws = sv[11:11 + nb]
+        pooled = dict(zip(down, sv[11 + nb:]))
+        gy = _c(gy)
+        N, P, h, w = x.shape
+        dev = x.device
+        C0 = nb * P
+        psinks, wsinks = ctx.sinks
+
+        def dst(sink, shape):
+            return sink if sink is not None else torch.zeros(shape, device=dev, dtype=torch.float32)
+        # merge_layer.2's BatchNorm + PReLU (batch statistics): direct path + statistics path
+        direct2 = psinks[4] is not None and psinks[5] is not None
+        out2 = torch.empty(4, P, dtype=torch.float32, device=dev)             # d gamma, d beta, p, q
+        gal2 = dst(psinks[6], (P,)) if m_alpha is not None else None
+        gc2 = torch.empty_like(mraw)
+        check(lib.mspl_bn_train_prelu_bwd(_p(mraw), None, _p(gy), _p(st2[2]), _p(st2[3]), _p(m_alpha), _p(g2), _p(st2[0]), _p(st2[1]),
+                                          N, P, h * w, None, _p(gc2), _p(ws2), 1 if direct2 else 0,
+                                          _p(psinks[4] if direct2 else out2[0]), _p(psinks[5] if direct2 else out2[1]), _p(gal2),
+                                          _p(out2[2]), _p(out2[3]), _stream()))
+        g_mraw = ops.pointwise(mraw, Epi(out2[2], out2[3], residual=gc2))      # p * z + q + gc
+        # the merge convolution and merge_layer.0's direct path; raw (d scale, d shift) sums of merge_layer.0
+        raw0 = torch.zeros(2, C0, device=dev, dtype=torch.float32)
+        scratch2 = torch.zeros(2, P, device=dev, dtype=torch.float32)         # (merge_layer.2 is the identity here: sums not used)
+        g_br_alpha = dst(psinks[2], (C0,))
+        g_merge_w = dst(psinks[3], tuple(merge_w.shape))
+        gt = torch.empty((nb, N, P, h, w), device=dev, dtype=torch.float32)
+        check(lib.mspl_pyrpool_merge_bwd(_p(g_mraw), _p(mraw), _p(zcat), N, P, h, w, nb, _p(st0[2]), _p(st0[3]), _p(br_alpha), None, None,
+                                         _p(merge_w), _p(_const_vec(1.0, P, dev)), _p(_const_vec(0.0, P, dev)), None, None, None, _p(gt),
+                                         _p(raw0[0]), _p(raw0[1]), _p(g_br_alpha), _p(g_merge_w), _p(scratch2[0]), _p(scratch2[1]), None,
+                                         _stream()))
+        direct0 = psinks[0] is not None and psinks[1] is not None
+        out0 = torch.empty(4, C0, dtype=torch.float32, device=dev)            # d gamma, d beta, p, q
+        check(lib.mspl_bn_batch_stats_bwd_coeffs(_p(raw0[0]), _p(raw0[1]), _p(g0), _p(st0[0]), _p(st0[1]), _p(st0[2]), C0,
+                                                 float(N * h * w), 1 if direct0 else 0, _p(psinks[0] if direct0 else out0[0]),
+                                                 _p(psinks[1] if direct0 else out0[1]), _p(out0[2]), _p(out0[3]), _stream()))
+        check(lib.mspl_bn_stats_path_add(_p(gt), _p(zcat), _p(out0[2]), _p(out0[3]), N, P, nb, h * w, _stream()))
+        # the branches (as in PyrBodyFn)
+        g_stage = [dst(wsinks[i], tuple(stage_ws[i].shape)) for i in range(nb)]
+        adds = []
+        for i in down:
+            hs_, ws_ = sizes[i]
+            g_e = torch.empty((N, P, hs_, ws_), device=dev, dtype=torch.float32)
+            check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
+            g_pool = ops.conv3x3(g_e, _transposed_weights(stage_ws[i], P, 3), P, 1)
+            check(lib.mspl_conv_bwd_weight(_p(g_e), _p(pooled[i]), N, P, P, P, hs_, ws_, 3, 1, 1, 1, _p(g_stage[i]), _stream()))
+            g_xi = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
+            check(lib.mspl_adaptive_avgpool_bwd(_p(g_pool), N, P, h, w, hs_, ws_, _p(g_xi), _stream()))
+            adds.append(g_xi)
+        up = [i for i in range(nb) if i not in down]
+        nbp = len(up)
+        hsa = (ctypes.c_int32 * nbp)(*[sizes[i][0] for i in up])
+        wsa = (ctypes.c_int32 * nbp)(*[sizes[i][1] for i in up])
+        swp = (ctypes.c_void_p * nbp)(*[stage_ws[i].data_ptr() for i in up])
+        gtp = (ctypes.c_void_p * nbp)(*[gt[i].data_ptr() for i in up])
+        gwp = (ctypes.c_void_p * nbp)(*[g_stage[i].data_ptr() for i in up])
+        gx = torch.empty_like(x)
+        check(lib.mspl_pyrpool_branch_bwd(_p(x), N, P, h, w, nbp, hsa, wsa, swp, gtp, gwp, _p(adds[0] if adds else None),
+                                          _p(adds[1] if len(adds) > 1 else None), _p(gx), _stream()))
+        ret = lambda sink, t: None if sink is not None else t          # noqa: E731
+        return (gx, None, None, None,
+                None if direct0 else out0[0], None if direct0 else out0[1], ret(psinks[2], g_br_alpha), ret(psinks[3], g_merge_w),
+                None if direct2 else out2[0], None if direct2 else out2[1],
+                None if m_alpha is None else ret(psinks[6], gal2),
+                *[ret(wsinks[i], g_stage[i]) for i in range(nb)])
+
+
+def bn_train_params(bn, device):
+    """(running_mean, running_var, eps, momentum, workspace, num_batches_tracked) of a BatchNorm2d in train() for the fused nodes."""
+    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+        raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
+                           'not on the path (the reference uses the defaults everywhere)')
+    return (bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), _bn_workspace(bn, device), bn.num_batches_tracked)
+
+
 def pyr_body_fits(shape, sizes):
     """True when the fused training body (PyrBodyFn) covers an (N,P,h,w) projection with these branch sizes: every branch purely up
     (>= the map in both directions) or purely down, one to three of the former, at most two of the latter, tiles fit LDS."""

@@ -183,6 +183,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     p[i] = pi - lr * b;
 }
 
+// Batch-statistics path of a BatchNorm over a concatenation whose gradient is kept BRANCH-major (the pyramid body):
+//   g[i][n][c][.] += p[i*P + c] * z[n][i*P + c][.] + q[i*P + c]        g: (nb, N, P, HW), z: (N, nb*P, HW)
+__global__ __launch_bounds__(256) void bn_stats_path_add_kernel(float* __restrict__ g, const float* __restrict__ z,
+                                                                const float* __restrict__ p, const float* __restrict__ q, int N, int P,
+                                                                int nb, int HW4) {
+    const long long plane = (long long)blockIdx.z * gridDim.y + blockIdx.y;      // (i * N + n) * P + c
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (plane >= (long long)nb * N * P || t >= HW4) return;
+    const int c = (int)(plane % P);
+    const long long in_ = plane / P;
+    const int n = (int)(in_ % N), i = (int)(in_ / N);
+    const int ch = i * P + c;
+    const float pc = p[ch], qc = q[ch];
+    float4* gp = reinterpret_cast<float4*>(g) + plane * HW4 + t;
+    const float4 zv = reinterpret_cast<const float4*>(z)[((long long)n * nb * P + ch) * HW4 + t];
+    float4 gv = *gp;
+    gv.x += fmaf(pc, zv.x, qc); gv.y += fmaf(pc, zv.y, qc); gv.z += fmaf(pc, zv.z, qc); gv.w += fmaf(pc, zv.w, qc);
+    *gp = gv;
+}
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -203,6 +223,21 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
                                             double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
     return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int mspl_bn_stats_path_add(float* g, const float* z, const float* p, const float* q, int32_t N, int32_t P, int32_t nb,
+                                      int32_t HW, void* stream) {
+    MSPL_REQUIRE(g && z && p && q, MSPL_ERR_NULL_POINTER, "bn_stats_path_add: null pointer");
+    MSPL_REQUIRE(N > 0 && P > 0 && nb > 0 && HW > 0 && (HW & 3) == 0, MSPL_ERR_BAD_SHAPE, "bn_stats_path_add: bad shape N=%d P=%d nb=%d HW=%d",
+                 N, P, nb, HW);
+    MSPL_REQUIRE((((uintptr_t)g | (uintptr_t)z) & 15) == 0, MSPL_ERR_BAD_SHAPE, "bn_stats_path_add: operands must be 16-byte aligned");
+    const int64_t planes = (int64_t)nb * N * P;
+    MSPL_REQUIRE(planes <= 65535ll * 65535ll, MSPL_ERR_BAD_SHAPE, "bn_stats_path_add: too many planes");
+    const int gy = planes < 65535 ? (int)planes : 65535;
+    const dim3 grid((unsigned)ceil_div(HW / 4, 256), (unsigned)gy, (unsigned)ceil_div64(planes, gy));
+    hipLaunchKernelGGL(bn_stats_path_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, z, p, q, N, P, nb, HW / 4);
+    MSPL_CHECK_LAUNCH("bn_stats_path_add");
+    return MSPL_OK;
 }
 
 extern "C" int64_t mspl_bn_fused_workspace_bytes(int32_t C) {

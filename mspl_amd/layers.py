@@ -728,14 +728,24 @@ class EfficientPyrPool(nn.Module):
         return ag.PyrBodyFn.apply(x, sizes, fold(bn0), fold(bn2), bn0.weight, bn0.bias, act0.weight, conv2.weight, bn2.weight,
                                   bn2.bias, act2.weight, *[st.weight for st in self.stages])
 
+    def _body_train_bn(self, x, sizes):
+        """The same body with BatchNorms in train() (batch statistics: the supervised loop), autograd.PyrBodyBNFn."""
+        bn0, act0 = self.merge_layer[0].br[0], self.merge_layer[0].br[1]
+        mcbr = self.merge_layer[2].cbr
+        conv2, bn2, act2 = mcbr[0], mcbr[1], mcbr[2]
+        return ag.PyrBodyBNFn.apply(x, sizes, ag.bn_train_params(bn0, x.device), ag.bn_train_params(bn2, x.device), bn0.weight, bn0.bias,
+                                    act0.weight, conv2.weight, bn2.weight, bn2.bias, act2.weight, *[st.weight for st in self.stages])
+
     def _forward_train(self, x):
         x = self.projection_layer(x)
         height, width = x.shape[2:]
         P = self.proj_planes
         sizes = self.branch_sizes(height, width)
-        frozen = not (self.merge_layer[0].br[0].training or self.merge_layer[2].cbr[1].training)
-        if _FUSED_PYR_TRAIN and frozen and ag.pyr_body_fits(x.shape, sizes):
-            out = self._body_train_fused(x, sizes)
+        bn0, bn2 = self.merge_layer[0].br[0], self.merge_layer[2].cbr[1]
+        frozen = not (bn0.training or bn2.training)
+        both_train = bn0.training and bn2.training
+        if _FUSED_PYR_TRAIN and (frozen or both_train) and ag.pyr_body_fits(x.shape, sizes) and (frozen or (height * width) % 4 == 0):
+            out = self._body_train_fused(x, sizes) if frozen else self._body_train_bn(x, sizes)
             conv = self.merge_layer[3]
             if self.last_layer_br:
                 return _conv_bn_act(out, conv, self.br.br[0], self.br.br[1].weight)

@@ -485,6 +485,52 @@ def test_fused_pyramid_training_equals_node_per_op(cfg):
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize('cfg', [(2, 32, 24, 16, 30, True), (2, 24, 5, 32, 60, False), (1, 16, 13, 64, 120, False),
+                                 (2, 16, 20, 18, 34, True), (4, 48, 32, 40, 72, True), (3, 16, 8, 8, 12, True)])
+def test_fused_pyramid_batch_statistics_equals_node_per_op(cfg):
+    """autograd.PyrBodyBNFn (BatchNorms in train(): the supervised loop) against the node-per-op training path: output, input gradient,
+    every parameter gradient, and the BatchNorms' buffers (running statistics, num_batches_tracked) after the step."""
+    from mspl_amd import autograd as ag, layers
+    N, cin, cout, h, w, last_br = cfg
+    m = _pyr_module(cin, cout, last_br, 79).train()
+    assert ag.pyr_body_fits((N, 16, h, w), m.branch_sizes(h, w)) and (h * w) % 4 == 0
+    x = rnd(N, cin, h, w, seed=15).to(DEV)
+    go = rnd(N, cout, h, w, seed=16).to(DEV)
+    start = {k: v.clone() for k, v in m.state_dict().items()}
+    res, calls = {}, []
+    orig = ag.PyrBodyBNFn.apply
+    for fused in (False, True):
+        prev = layers._FUSED_PYR_TRAIN
+        layers._FUSED_PYR_TRAIN = fused
+        m.load_state_dict(start)
+        ag.PyrBodyBNFn.apply = lambda *a: (calls.append(fused), orig(*a))[1]
+        try:
+            xi = x.clone().requires_grad_(True)
+            for p in m.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                y = m(xi)
+                y.backward(go)
+            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                          {k: v.clone() for k, v in m.named_buffers()})
+        finally:
+            layers._FUSED_PYR_TRAIN = prev
+            ag.PyrBodyBNFn.apply = orig
+    assert calls == [True]
+    close(res[True][0], res[False][0], atol=5e-5, rtol=2e-4)
+    close(res[True][1], res[False][1], atol=1e-4, rtol=2e-3)
+    for k in res[False][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 3e-3 * scale + 2e-5, (k, float((a - b).abs().max()), scale)
+    for k, b in res[False][3].items():
+        a = res[True][3][k]
+        if b.dtype == torch.int64:
+            assert torch.equal(a, b), k
+        else:
+            close(a, b, atol=1e-6, rtol=1e-5)
+
+
 def test_fused_pyramid_training_with_gradient_sinks():
     """Inside grad_sinks() the fused node adds its parameter gradients straight into existing .grad buffers (the flat optimizer
     buffers of the train step): same values as the returned-gradient form, accumulated on top of what the buffers held."""
