@@ -497,6 +497,11 @@ int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t H
  * y = PReLU(z * scale + shift + residual) with (scale, shift) the batch-statistics fold of z: gres (may be NULL), gc = direct gradient
  * of z through the affine map, ggamma / gbeta (accumulate != 0: added to), galpha (ACCUMULATED, caller zeroes or passes the parameter's
  * gradient), and the coefficients p, q (C floats each) of the statistics' path: dL/dz = p * z + q + gc (one mspl_pointwise_fwd). */
+/* merge_layer.0 (BatchNorm fold + PReLU over the concatenation), Shuffle and merge_layer.2's grouped 3x3 from KEPT branch values
+ * (nn_layers/efficient_pyramid_pool.py:51-58): out (N,P,h,w) = the bare convolution result, zcat (N, nb*P, h, w) in torch.cat order,
+ * merge_w (P, nb, 3, 3).  The batch-statistics pyramid node runs it between the two statistics passes. */
+int mspl_pyrpool_merge_fwd(const float* zcat, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const float* br_scale,
+                           const float* br_shift, const float* br_alpha, const float* merge_w, float* out, void* stream);
 /* Statistics path of a batch-statistics BatchNorm over a concatenation whose gradient is branch-major (the pyramid body's merge_layer.0):
  * g (nb,N,P,HW) += p[i*P+c] * z[n, i*P+c] + q[i*P+c] with z (N, nb*P, HW); HW % 4 == 0. */
 int mspl_bn_stats_path_add(float* g, const float* z, const float* p, const float* q, int32_t N, int32_t P, int32_t nb, int32_t HW,

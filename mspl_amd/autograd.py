@@ -569,10 +569,9 @@ def _const_vec(value, n, device):
 class PyrBodyBNFn(torch.autograd.Function):
     """PyrBodyFn for BatchNorms in train() (the supervised loop): the same fused kernels, run around the two batch-statistics passes.
 
-    forward   the fused training kernel once for the branch values (zcat does not depend on the BatchNorms), the statistics of the
-              concatenation -> merge_layer.0's fold, the fused kernel again for the merge convolution over PReLU(BN(zcat)), the
-              statistics of its bare result -> merge_layer.2's fold, one affine / PReLU launch.  (The branches are computed twice: two
-              launches of ~60-120 us against ~20 launches of the node-per-op form.)
+    forward   the fused training kernel for the branch values (zcat does not depend on the BatchNorms), the statistics of the
+              concatenation -> merge_layer.0's fold, mspl_pyrpool_merge_fwd (fold + PReLU + Shuffle + grouped 3x3 from the kept
+              branch values), the statistics of its bare result -> merge_layer.2's fold, one affine / PReLU launch.
     backward  merge_layer.2's BatchNorm + PReLU as in BNTrainPReLUFn (direct path + p * z + q); mspl_pyrpool_merge_bwd with that
               BatchNorm as the IDENTITY (its gradient is already applied) and RAW (d scale, d shift) sums for merge_layer.0, whose
               statistics path is then added to the branch-major gradient (mspl_bn_stats_path_add); the branch backward as in PyrBodyFn.
@@ -606,26 +605,28 @@ class PyrBodyBNFn(torch.autograd.Function):
         one0, zero0 = _const_vec(1.0, C0, dev), _const_vec(0.0, C0, dev)
         mraw = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
         zcat = torch.empty((N, C0, h, w), device=dev, dtype=torch.float32)
-        ep, keep2 = ops._build(Epi(), mraw, 0, N, P, h * w)                   # bare merge convolution
+        y = torch.empty_like(mraw)
+        # (the streaming form of the kernel wants the raw-output slot; y is scratch until step 4)
+        ep, keep2 = ops._build(Epi(raw_out=mraw), y, 0, N, P, h * w)
         # (1) branch values
         check(lib.mspl_pyrpool_fused_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(one0), _p(zero0), _p(br_alpha_c),
-                                               _p(merge_w), ctypes.byref(ep), _p(mraw), _p(zcat), _stream()))
+                                               _p(merge_w), ctypes.byref(ep), _p(y), _p(zcat), _stream()))
         # (2) merge_layer.0: statistics of the concatenation
         rm0, rv0, eps0, mom0, ws0, nbt0 = bnp0
         st0 = torch.empty(4, C0, dtype=torch.float32, device=dev)             # mean, invstd, scale, shift
         g0, b0 = _c(br_gamma), _c(br_beta)
         check(lib.mspl_bn_batch_stats_fused_fwd(_p(zcat), N, C0, h * w, eps0, mom0, _p(rm0), _p(rv0), _p(g0), _p(b0), _p(ws0),
                                                 _p(st0[0]), _p(st0[1]), _p(st0[2]), _p(st0[3]), _p(nbt0), _stream()))
-        # (3) the merge convolution over PReLU(BN(zcat)) (the kernel recomputes the branches)
-        check(lib.mspl_pyrpool_fused_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, de, _p(st0[2]), _p(st0[3]), _p(br_alpha_c),
-                                               _p(merge_w), ctypes.byref(ep), _p(mraw), _p(zcat), _stream()))
+        # (3) the merge convolution over PReLU(BN(zcat)), from the kept branch values
+        check(lib.mspl_pyrpool_merge_fwd(_p(zcat), N, P, h, w, nb, _p(st0[2]), _p(st0[3]), _p(br_alpha_c), _p(merge_w), _p(mraw),
+                                         _stream()))
         # (4) merge_layer.2's BatchNorm + PReLU
         rm2, rv2, eps2, mom2, ws2, nbt2 = bnp2
         st2 = torch.empty(4, P, dtype=torch.float32, device=dev)
         g2, b2 = _c(m_gamma), _c(m_beta)
         check(lib.mspl_bn_batch_stats_fused_fwd(_p(mraw), N, P, h * w, eps2, mom2, _p(rm2), _p(rv2), _p(g2), _p(b2), _p(ws2),
                                                 _p(st2[0]), _p(st2[1]), _p(st2[2]), _p(st2[3]), _p(nbt2), _stream()))
-        y = ops.pointwise(mraw, Epi(st2[2], st2[3], m_alpha))
+        y = ops.pointwise(mraw, Epi(st2[2], st2[3], m_alpha), out=y)
         ctx.save_for_backward(x, zcat, mraw, st0, st2, br_alpha_c, merge_w, m_alpha, g0, g2, ws2, *stage_ws, *[pooled[i] for i in down])
         ctx.sizes, ctx.down = [tuple(int(v) for v in s_) for s_ in sizes], down
         ctx.sinks = ([_sink(t) for t in (br_gamma, br_beta, br_alpha, merge_w, m_gamma, m_beta, m_alpha)],

@@ -203,6 +203,85 @@ __global__ __launch_bounds__(256) void bn_stats_path_add_kernel(float* __restric
     *gp = gv;
 }
 
+// merge_layer.0 .. merge_layer.2's convolution from the KEPT branch values (the batch-statistics pyramid node: the branch values are
+// computed once, their statistics give merge_layer.0's fold, and this kernel finishes the forward without evaluating the branches a
+// second time):  out[n][c] = sum_i conv3x3( PReLU(zcat[n][i*P + c] * scale[i*P + c] + shift[i*P + c]), merge_w[c][i] ), zero padding
+// applied AFTER the activation (efficient_pyramid_pool.py:51-58: BR, Shuffle(groups = nb), grouped 3x3 with groups = P).
+// A workgroup owns a TH x TW tile of one (image, channel) plane; all nb halo tiles are fetched into registers up front, then pass
+// through a double-buffered LDS tile (one barrier per branch).
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void pyr_merge_fwd_kernel(const float* __restrict__ zcat, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, const float* __restrict__ al,
+                                                            const float* __restrict__ mw, int P, int nb, int h, int w, int tiles_x,
+                                                            int tiles_y, float* __restrict__ out) {
+    static_assert(TW * TH == 1024 && TW % 4 == 0, "256 threads x 4 pixels");
+    constexpr int LW = TW + 4, BH = TH + 2, BW = TW + 2, NE = BH * BW, PER = (NE + 255) / 256, MAXB = 5;
+    __shared__ __attribute__((aligned(16))) float tile[2][BH * LW + 4];
+    int bid = blockIdx.x;
+    const int txi = bid % tiles_x;  bid /= tiles_x;
+    const int tyi = bid % tiles_y;  bid /= tiles_y;
+    const int c = bid % P, n = bid / P;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const int tid = threadIdx.x;
+    const size_t hw = (size_t)h * w;
+    int goff[PER], loff[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid + 256 * k, r = e / BW, q = e - r * BW;
+        const int py = y0 - 1 + r, px = x0 - 1 + q;
+        loff[k] = e < NE ? r * LW + q : -1;
+        goff[k] = (e < NE && py >= 0 && py < h && px >= 0 && px < w) ? py * w + px : -1;
+    }
+    float v[MAXB][PER];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        if (i >= nb) break;
+        const float* pl = zcat + ((size_t)n * nb * P + (size_t)i * P + c) * hw;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[i][k] = goff[k] >= 0 ? pl[goff[k]] : 0.f;
+    }
+    const int ty = tid / (TW / 4), xs = tid - ty * (TW / 4);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        if (i >= nb) break;
+        const int ch = i * P + c;
+        const float s0 = sc[ch], s1 = sh[ch], a0 = al[ch];
+        float* buf = tile[i & 1];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            float b = fmaf(v[i][k], s0, s1);
+            b = b > 0.f ? b : a0 * b;
+            if (loff[k] >= 0) buf[loff[k]] = goff[k] >= 0 ? b : 0.f;
+        }
+        __syncthreads();
+        const float* wm = mw + ((size_t)c * nb + i) * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = buf + (ty + ky) * LW + xs * 4;
+            const float4 a = *reinterpret_cast<const float4*>(row);
+            const float2 b2 = *reinterpret_cast<const float2*>(row + 4);
+            const float rv[6] = {a.x, a.y, a.z, a.w, b2.x, b2.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf(wm[ky * 3 + 0], rv[j], acc[j]);
+                acc[j] = fmaf(wm[ky * 3 + 1], rv[j + 1], acc[j]);
+                acc[j] = fmaf(wm[ky * 3 + 2], rv[j + 2], acc[j]);
+            }
+        }
+    }
+    const int y = y0 + ty, xb = x0 + xs * 4;
+    if (y >= h || xb >= w) return;
+    float* dst = out + ((size_t)n * P + c) * hw + (size_t)y * w + xb;
+    if ((w & 3) == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (xb + j < w) dst[j] = acc[j];
+    }
+}
+
 }  // namespace mspl
 
 using namespace mspl;
@@ -223,6 +302,28 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
                                             double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
     return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int mspl_pyrpool_merge_fwd(const float* zcat, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const float* br_scale,
+                                      const float* br_shift, const float* br_alpha, const float* merge_w, float* out, void* stream) {
+    MSPL_REQUIRE(zcat && br_scale && br_shift && br_alpha && merge_w && out, MSPL_ERR_NULL_POINTER, "pyrpool_merge_fwd: null pointer");
+    MSPL_REQUIRE(N > 0 && P > 0 && h > 0 && w > 0 && (int64_t)h * w < (1ll << 31), MSPL_ERR_BAD_SHAPE,
+                 "pyrpool_merge_fwd: bad shape N=%d P=%d %dx%d", N, P, h, w);
+    MSPL_REQUIRE(nb >= 1 && nb <= 5, MSPL_ERR_UNSUPPORTED, "pyrpool_merge_fwd: %d branches (1..5)", nb);
+    MSPL_REQUIRE((w & 3) != 0 || (((uintptr_t)out) & 15) == 0, MSPL_ERR_BAD_SHAPE, "pyrpool_merge_fwd: out must be 16-byte aligned");
+    const bool narrow = w <= 32;
+    const int TW = narrow ? 32 : 64, TH = narrow ? 32 : 16;
+    const int tx = ceil_div(w, TW), ty = ceil_div(h, TH);
+    const int64_t blocks = (int64_t)N * P * tx * ty;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "pyrpool_merge_fwd: grid too large");
+    if (narrow)
+        hipLaunchKernelGGL((pyr_merge_fwd_kernel<32, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, zcat, br_scale, br_shift,
+                           br_alpha, merge_w, P, nb, h, w, tx, ty, out);
+    else
+        hipLaunchKernelGGL((pyr_merge_fwd_kernel<64, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, zcat, br_scale, br_shift,
+                           br_alpha, merge_w, P, nb, h, w, tx, ty, out);
+    MSPL_CHECK_LAUNCH("pyrpool_merge_fwd");
+    return MSPL_OK;
 }
 
 extern "C" int mspl_bn_stats_path_add(float* g, const float* z, const float* p, const float* q, int32_t N, int32_t P, int32_t nb,

@@ -334,6 +334,20 @@ def pointwise(x, ep, out=None):
     return dst
 
 
+def pyrpool_merge(zcat, scale, shift, alpha, merge_w, out=None):
+    """merge_layer.0's fold + PReLU, Shuffle(groups=nb) and merge_layer.2's grouped 3x3 over kept branch values zcat (N, nb*P, h, w);
+    merge_w (P, nb, 3, 3).  Returns the bare convolution result (N, P, h, w)."""
+    zcat, merge_w = _f32(zcat, 'zcat'), _f32(merge_w, 'merge_w')
+    N, C, h, w = zcat.shape
+    P, nb = merge_w.shape[:2]
+    if C != P * nb or tuple(merge_w.shape[2:]) != (3, 3) or any(t.numel() != C for t in (scale, shift, alpha)):
+        raise RuntimeError('mspl_amd: pyrpool_merge operands do not match: zcat %s merge_w %s' % (tuple(zcat.shape), tuple(merge_w.shape)))
+    dst = torch.empty((N, P, h, w), device=zcat.device, dtype=torch.float32) if out is None else out
+    check(lib.mspl_pyrpool_merge_fwd(_p(zcat), N, P, h, w, nb, _p(_f32(scale, 'scale')), _p(_f32(shift, 'shift')), _p(_f32(alpha, 'alpha')),
+                                     _p(merge_w), _p(dst), _stream()))
+    return dst
+
+
 def gap_gate(x, w):
     """sigmoid(W . mean_hw(x)) -> (N, Cout)."""
     x, w = _f32(x, 'x'), _f32(w, 'w')

@@ -502,3 +502,21 @@ def test_label_epilogue_hist_fits_and_fallback():
         hh = torch.zeros(C, dtype=torch.int64, device=DEV)
         one = ops.label_epilogue_hist(m2, a2, (192, 480), hh, C)
         assert torch.equal(one['labels'], ops.label_epilogue(m2, a2, (192, 480))['labels']) and int(hh.sum()) == 192 * 480
+
+
+@pytest.mark.parametrize('cfg', [(2, 6, 5, 16, 30), (1, 16, 5, 40, 72), (3, 4, 3, 33, 65), (2, 8, 5, 7, 9), (1, 3, 1, 18, 130), (2, 5, 4, 35, 32)])
+def test_pyrpool_merge_from_kept_branches(cfg):
+    """mspl_pyrpool_merge_fwd against the definition (BatchNorm fold + PReLU, channel shuffle, grouped 3x3 with zero padding after the
+    activation): both tile shapes, ragged tiles, widths that are not a multiple of 4, fewer than five branches."""
+    import torch.nn.functional as F
+    from mspl_amd import ops
+    N, P, nb, h, w = cfg
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(N, nb * P, h, w, generator=g)
+    sc, sh, al = torch.rand(nb * P, generator=g) + 0.5, torch.randn(nb * P, generator=g), torch.rand(nb * P, generator=g) * 0.3
+    mw = torch.randn(P, nb, 3, 3, generator=g) * 0.3
+    a = F.prelu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), al)
+    a = a.view(N, nb, P, h, w).transpose(1, 2).reshape(N, nb * P, h, w)           # Shuffle(groups=nb)
+    want = F.conv2d(a, mw, None, 1, 1, 1, P)
+    got = ops.pyrpool_merge(z.to(DEV), sc.to(DEV), sh.to(DEV), al.to(DEV), mw.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
