@@ -79,29 +79,50 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 // "last block done" pattern with the partials carried by atomics: adds -> wait for their acknowledgement -> counter) finishes that channel -- mean, 1/std, the fold, the running-statistics
 // update -- and hands the channel's workspace back zeroed, so the caller keeps ONE persistent workspace per BatchNorm (zeroed once) and
 // neither a memset nor a finalize launch runs per call.  ws: [2C doubles | C counters].
-__global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __restrict__ z, int C, int HW, int per_block, unsigned per_channel,
+__global__ __launch_bounds__(256) void bn_stats_fused_kernel(const float* __restrict__ z, int N, int C, int HW, unsigned per_channel,
                                                              double* __restrict__ ws, unsigned* __restrict__ cnt, double M, float eps,
                                                              float momentum, float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float* __restrict__ mean,
                                                              float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ scale,
                                                              float* __restrict__ shift, long long* __restrict__ nbt) {
-    const int c = blockIdx.z, n = blockIdx.y;
+    // grid (parts, C): a workgroup owns one of `parts` contiguous ranges of the channel's N * HW elements (the N planes taken as one
+    // sequence), so a channel sees `parts` atomic chains whatever N is (N * chunks before: 25 of the 33 us at 16 x 16 x 144x240)
+    const int c = blockIdx.y, rng = blockIdx.x, parts = gridDim.x;
     const float k = z[(size_t)c * HW];
-    const float* p = z + ((size_t)n * C + c) * (size_t)HW;
-    const int lo = blockIdx.x * per_block;
-    const int hi = min(HW, lo + per_block);
+    const bool vec = (HW & 3) == 0;
+    const int L = vec ? (HW >> 2) : HW;
+    const long long total = (long long)N * L;
+    const long long per = (total + parts - 1) / parts;
+    const long long u0 = (long long)rng * per, u1 = min(total, u0 + per);
+    const int step_n = 256 / L, step_q = 256 - step_n * L;
+    long long u = u0 + threadIdx.x;
+    int n = (int)(u / L), q = (int)(u - (long long)n * L);
+    auto advance = [&]() { u += 256; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
     float s1 = 0.f, s2 = 0.f;
-    if ((HW & 3) == 0 && (per_block & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
+    if (vec) {
+        auto acc4 = [&](const float4& v) {
             const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
             s1 += (a + b) + (cc + d);
             s2 += (a * a + b * b) + (cc * cc + d * d);
+        };
+        while (u + 768 < u1) {                      // four 16-byte loads in flight per thread
+            const float4* p0 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+            const float4* p1 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+            const float4* p2 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+            const float4* p3 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+            const float4 v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+            acc4(v0); acc4(v1); acc4(v2); acc4(v3);
+        }
+        while (u < u1) {
+            const float4 v = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW)[q];
+            advance();
+            acc4(v);
         }
     } else {
-        for (int i = lo + threadIdx.x; i < hi; i += 256) {
-            const float a = p[i] - k;
+        while (u < u1) {
+            const float a = z[((size_t)n * C + c) * (size_t)HW + q] - k;
+            advance();
             s1 += a;
             s2 += a * a;
         }
@@ -356,16 +377,16 @@ extern "C" int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t 
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0 && N <= 65535 && C <= 65535, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: bad shape N=%d C=%d HW=%d",
                  N, C, HW);
     MSPL_REQUIRE(((uintptr_t)ws_zeroed & 7) == 0, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: workspace must be 8-byte aligned");
-    int chunks = ceil_div(2048, N * C);
-    if (chunks < 1) chunks = 1;
-    int per_block = ceil_div(HW, chunks);
-    if (per_block < 4096) per_block = 4096;
-    per_block = (per_block + 3) & ~3;
-    chunks = ceil_div(HW, per_block);
+    static const int target = getenv("MSPL_BN_BLOCKS") ? atoi(getenv("MSPL_BN_BLOCKS")) : 768;
+    const int64_t units = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW);
+    int64_t parts = ceil_div64(target, C);
+    if (parts > units / 512) parts = units / 512;
+    if (parts < 1) parts = 1;
+    if (parts > 65535) parts = 65535;
     double* sums = static_cast<double*>(ws_zeroed);
     unsigned* cnt = reinterpret_cast<unsigned*>(sums + 2 * (size_t)C);
-    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)chunks, (unsigned)N, (unsigned)C), dim3(256), 0, (hipStream_t)stream, z, C, HW,
-                       per_block, (unsigned)(chunks * N), sums, cnt, (double)N * (double)HW, eps, momentum, running_mean, running_var, mean,
+    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, (hipStream_t)stream, z, N, C, HW,
+                       (unsigned)parts, sums, cnt, (double)N * (double)HW, eps, momentum, running_mean, running_var, mean,
                        invstd, gamma, beta, scale, shift, reinterpret_cast<long long*>(num_batches_tracked));
     MSPL_CHECK_LAUNCH("bn_batch_stats_fused");
     return MSPL_OK;

@@ -288,19 +288,18 @@ struct BnTail {
 __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __restrict__ c, const float* __restrict__ pre,
                                                                const float* __restrict__ res, const float* __restrict__ gy,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               const float* __restrict__ alpha, int C, int HW, int chunks,
+                                                               const float* __restrict__ alpha, int N, int C, int HW, int parts,
                                                                float* __restrict__ gz_out, float* __restrict__ gc_out,
                                                                float* __restrict__ gscale, float* __restrict__ gshift,
                                                                float* __restrict__ galpha, const float* __restrict__ bn_mean,
                                                                const float* __restrict__ bn_inv, BnTail tl) {
-    int b = blockIdx.x;
-    const int chunk = b % chunks;  b /= chunks;
-    const int ch = b % C;
-    const int n = b / C;
+    // A workgroup owns one of `parts` contiguous ranges of a channel's N * HW elements (the N planes taken as one sequence): the
+    // number of same-address atomics per channel is `parts`, whatever N is.  (One workgroup per (image, channel, chunk) made it
+    // N * chunks: at 16 x 16 x 144x240 the 256 atomic chains per channel cost 55 of the kernel's 81 us.)
+    const int ch = blockIdx.x / parts, rng = blockIdx.x - ch * parts;
     const float sc = scale ? scale[ch] : 1.f, sh = shift ? shift[ch] : 0.f;
     const bool act = alpha != nullptr;
     const float al = act ? alpha[ch] : 1.f;
-    const size_t base = ((size_t)n * C + ch) * (size_t)HW;
     float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
     auto one = [&](float cv, float pv, float rv, float g, float& gz, float& gcv) {
         const float u = cv + pv;
@@ -311,38 +310,43 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
         s_shift += gz;
         gcv = gz * sc;
     };
-    if ((HW & 3) == 0) {                       // 16-byte operands, two independent quads in flight per iteration
-        const int q4 = HW >> 2, per = (q4 + chunks - 1) / chunks;
-        const int q0 = chunk * per, q1 = min(q4, q0 + per);
-        const float4* c4 = reinterpret_cast<const float4*>(c + base);
-        const float4* p4 = pre ? reinterpret_cast<const float4*>(pre + base) : nullptr;
-        const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
-        const float4* g4 = reinterpret_cast<const float4*>(gy + base);
-        float4* z4 = gz_out ? reinterpret_cast<float4*>(gz_out + base) : nullptr;
-        float4* o4 = gc_out ? reinterpret_cast<float4*>(gc_out + base) : nullptr;
+    const bool vec = (HW & 3) == 0;
+    const int L = vec ? (HW >> 2) : HW;                    // units (quads or elements) per plane
+    const long long total = (long long)N * L;
+    const long long per = (total + parts - 1) / parts;
+    const long long u0 = (long long)rng * per, u1 = min(total, u0 + per);
+    const int step_n = 256 / L, step_q = 256 - step_n * L;
+    long long u = u0 + threadIdx.x;
+    int n = (int)(u / L), q = (int)(u - (long long)n * L);
+    auto advance = [&]() { u += 256; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
+    if (vec) {                                 // 16-byte operands, two independent quads in flight per iteration
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = q0 + threadIdx.x; q < q1; q += 512) {
-            const int qb = q + 256;
-            const bool hb = qb < q1;
-            const float4 ca = c4[q], ga = g4[q], pa = p4 ? p4[q] : zero, ra = r4 ? r4[q] : zero;
-            const float4 cb = hb ? c4[qb] : zero, gb = hb ? g4[qb] : zero, pb = (hb && p4) ? p4[qb] : zero, rb = (hb && r4) ? r4[qb] : zero;
+        while (u < u1) {
+            const size_t oa = (((size_t)n * C + ch) * (size_t)HW) + 4 * (size_t)q;
+            advance();
+            const bool hb = u < u1;
+            const size_t ob = hb ? (((size_t)n * C + ch) * (size_t)HW) + 4 * (size_t)q : oa;
+            advance();
+            const float4 ca = *reinterpret_cast<const float4*>(c + oa), ga = *reinterpret_cast<const float4*>(gy + oa);
+            const float4 pa = pre ? *reinterpret_cast<const float4*>(pre + oa) : zero, ra = res ? *reinterpret_cast<const float4*>(res + oa) : zero;
+            const float4 cb = *reinterpret_cast<const float4*>(c + ob), gb = *reinterpret_cast<const float4*>(gy + ob);
+            const float4 pb = pre ? *reinterpret_cast<const float4*>(pre + ob) : zero, rb = res ? *reinterpret_cast<const float4*>(res + ob) : zero;
             float4 gz, gc;
             one(ca.x, pa.x, ra.x, ga.x, gz.x, gc.x); one(ca.y, pa.y, ra.y, ga.y, gz.y, gc.y);
             one(ca.z, pa.z, ra.z, ga.z, gz.z, gc.z); one(ca.w, pa.w, ra.w, ga.w, gz.w, gc.w);
-            if (z4) z4[q] = gz;
-            if (o4) o4[q] = gc;
+            if (gz_out) *reinterpret_cast<float4*>(gz_out + oa) = gz;
+            if (gc_out) *reinterpret_cast<float4*>(gc_out + oa) = gc;
             if (hb) {
                 one(cb.x, pb.x, rb.x, gb.x, gz.x, gc.x); one(cb.y, pb.y, rb.y, gb.y, gz.y, gc.y);
                 one(cb.z, pb.z, rb.z, gb.z, gz.z, gc.z); one(cb.w, pb.w, rb.w, gb.w, gz.w, gc.w);
-                if (z4) z4[qb] = gz;
-                if (o4) o4[qb] = gc;
+                if (gz_out) *reinterpret_cast<float4*>(gz_out + ob) = gz;
+                if (gc_out) *reinterpret_cast<float4*>(gc_out + ob) = gc;
             }
         }
     } else {
-        const int per = (HW + chunks - 1) / chunks;
-        const int p0 = chunk * per, p1 = min(HW, p0 + per);
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            const size_t o = base + p;
+        while (u < u1) {
+            const size_t o = (((size_t)n * C + ch) * (size_t)HW) + (size_t)q;
+            advance();
             float gz, gc;
             one(c[o], pre ? pre[o] : 0.f, res ? res[o] : 0.f, gy[o], gz, gc);
             if (gz_out) gz_out[o] = gz;
@@ -936,13 +940,18 @@ static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const f
                                    const float* bn_mean, const float* bn_inv, void* stream, BnTail tl = BnTail()) {
     MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
-    int chunks = 1;
-    while ((int64_t)N * C * chunks < 4096 && HW / (chunks * 2) >= 2048) chunks *= 2;
-    const int64_t blocks = (int64_t)N * C * chunks;
+    // ~MSPL_AFF_BLOCKS workgroups (default 768: three per CU keep the memory system busy with two 16-byte loads per operand in
+    // flight per thread), at least ~2 units per thread, and as few same-address atomic chains per channel as that allows
+    static const int target = getenv("MSPL_AFF_BLOCKS") ? atoi(getenv("MSPL_AFF_BLOCKS")) : 768;
+    const int64_t units = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW);
+    int64_t parts = ceil_div64(target, C);
+    if (parts > units / 512) parts = units / 512;
+    if (parts < 1) parts = 1;
+    const int64_t blocks = (int64_t)C * parts;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: grid too large");
-    tl.per_channel = (unsigned)(N * chunks);
+    tl.per_channel = (unsigned)parts;
     hipLaunchKernelGGL(affine_prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, c, pre_add, residual, gy,
-                       scale, shift, alpha, C, HW, chunks, gz, gc, gscale, gshift, galpha, bn_mean, bn_inv, tl);
+                       scale, shift, alpha, N, C, HW, (int)parts, gz, gc, gscale, gshift, galpha, bn_mean, bn_inv, tl);
     MSPL_CHECK_LAUNCH("affine_prelu_bwd");
     return MSPL_OK;
 }
