@@ -4,6 +4,8 @@
 //   SegmentationLoss (loss_type 'ce')          :11-52     nn.CrossEntropyLoss(weight, ignore_index): sum(w[t]*nll) / sum_{valid}(w[t])
 // The fused K11 kernel (train.hip) covers the exact uest combination in one pass; these serve callers that compose
 // the modules themselves.  One thread per pixel, classes streamed with a running log-sum-exp; NCHW fp32, int64 targets.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -64,9 +66,10 @@ __global__ __launch_bounds__(256) void kld_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ target,
                                                       const float* __restrict__ u, const float* __restrict__ cw, int ignore,
                                                       int C, int HW, float* __restrict__ sums, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // grid-stride with a bounded grid: a workgroup ends with two atomics on the same two addresses, and such a chain advances at
+    // ~12-25 ns per link (one workgroup per 256 pixels: 8 640 links = 200 of the kernel's 231 us at 16 x 13 x 288x480)
     float num = 0.f, den = 0.f;
-    if (idx < total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int n = (int)(idx / HW), p = (int)(idx - (int64_t)n * HW);
         const int64_t t = target[idx];
         if (t >= 0 && t < C && t != ignore) {
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
             for (int c = 0; c < C; ++c) lse_push(l, a[(size_t)c * HW]);
             const float nll = (l.m + logf(l.s)) - a[(size_t)t * HW];
             const float w = cw ? cw[t] : 1.f;
-            num = w * nll * (u ? expf(-u[idx]) : 1.f);
-            den = w;
+            num += w * nll * (u ? expf(-u[idx]) : 1.f);
+            den += w;
         }
     }
 #pragma unroll
@@ -145,7 +148,9 @@ extern "C" int mspl_weighted_ce_fwd(const float* pred, const int64_t* target, co
     MSPL_REQUIRE(pred && target && sums, MSPL_ERR_NULL_POINTER, "weighted_ce: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "weighted_ce: bad shape N=%d C=%d HW=%d", N, C, HW);
     const int64_t total = (int64_t)N * HW;
-    hipLaunchKernelGGL(wce_fwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, pred, target,
+    static const int max_blocks = getenv("MSPL_LOSS_BLOCKS") ? atoi(getenv("MSPL_LOSS_BLOCKS")) : 512;
+    const int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), max_blocks);
+    hipLaunchKernelGGL(wce_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
                        u_weight, class_weights, ignore_index, C, HW, sums, total);
     MSPL_CHECK_LAUNCH("weighted_ce_fwd");
     return MSPL_OK;
