@@ -36,24 +36,33 @@ struct MbGeom {
     float *g_m_scale, *g_m_shift, *g_m_alpha;                            // P
 };
 
+// One WAVE per branch: a workgroup (NB waves) owns a 16-row band of one (image, channel) plane and walks its 64-column tiles.  All
+// waves build the g_m halo tile in LDS together; then wave i evaluates branch i for the tile's 256 1x4 strips (four per lane).  A lane
+// so carries ONE branch's nine weight-gradient accumulators and three BatchNorm / PReLU sums (12 registers instead of 60), its
+// branch's constants are wave-uniform scalars, and the final reduction is 12 values per wave.  (One thread per strip doing all five
+// branches: 234 VGPRs, 204 spilled SGPRs, two waves per SIMD, 378 ds_bpermute in the tail -- 248 us for 16 x 16 x 144x240 whose
+// traffic is ~85 us.)
 // (the plane's constants come through `const float* __restrict__` kernel arguments of their own: only then does hipcc read the
-// wave-uniform values with scalar loads into SGPRs -- through the geometry struct they cost ~75 VGPRs and a wave per SIMD)
+// wave-uniform values with scalar loads into SGPRs)
 template <int NB>
-__global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mraw,
-                                                            const float* __restrict__ zcat, const float* __restrict__ k_merge_w,
-                                                            const float* __restrict__ k_br_scale, const float* __restrict__ k_br_shift,
-                                                            const float* __restrict__ k_br_alpha, const float* __restrict__ k_m_scale,
-                                                            const float* __restrict__ k_m_shift, const float* __restrict__ k_m_alpha,
-                                                            MbGeom g, float* __restrict__ gt) {
+__global__ __launch_bounds__(64 * NB) void pyr_merge_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ mraw,
+                                                               const float* __restrict__ zcat, const float* __restrict__ k_merge_w,
+                                                               const float* __restrict__ k_br_scale, const float* __restrict__ k_br_shift,
+                                                               const float* __restrict__ k_br_alpha, const float* __restrict__ k_m_scale,
+                                                               const float* __restrict__ k_m_shift, const float* __restrict__ k_m_alpha,
+                                                               MbGeom g, float* __restrict__ gt) {
+    constexpr int NT = 64 * NB;
+    constexpr int NEL = (MB_TH + 2) * (MB_TW + 2);
+    constexpr int NST = (NEL + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float G[(MB_TH + 2) * MB_GS];
-    constexpr int NRED = NB * 12 + 3;
-    __shared__ float red[4][NRED];
+    __shared__ float redq[NB][3];
     int b = blockIdx.x;
     const int ty = b % g.tiles_y;  b /= g.tiles_y;
     const int c = b % g.P;
     const int n = b / g.P;
     const int y0 = ty * MB_TH;
-    const int tid = threadIdx.x, r = tid >> 4, s4 = (tid & 15) * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bi = __builtin_amdgcn_readfirstlane(tid >> 6);             // this wave's branch
     const int h = g.h, w = g.w;
     const size_t plane = (size_t)h * w;
     const float* gyp = gy + ((size_t)n * g.P + c) * plane;
@@ -63,35 +72,53 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
     const float mal = mact ? k_m_alpha[c] : 1.f;
     const bool vec = (w & 3) == 0;
 
-    float wm[NB][9], bs[NB], bh[NB], ba[NB];
+    float wmi[9];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+    for (int k = 0; k < 9; ++k) wmi[k] = k_merge_w[((size_t)c * NB + bi) * 9 + k];
+    const int ch = bi * g.P + c;
+    const float bs = k_br_scale[ch], bh = k_br_shift[ch], ba = k_br_alpha[ch];
+    const float* zpl = zcat + (((size_t)n * NB + bi) * g.P + c) * plane;
+    float* opl = gt + (((size_t)bi * g.N + n) * g.P + c) * plane;
+    float dw[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wm[i][k] = k_merge_w[((size_t)c * NB + i) * 9 + k];
-        bs[i] = k_br_scale[i * g.P + c];  bh[i] = k_br_shift[i * g.P + c];  ba[i] = k_br_alpha[i * g.P + c];
-    }
-    float dw[NB][9], a_sc[NB], a_sh[NB], a_al[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dw[i][k] = 0.f;
-        a_sc[i] = a_sh[i] = a_al[i] = 0.f;
-    }
+    for (int k = 0; k < 9; ++k) dw[k] = 0.f;
+    float a_sc = 0.f, a_sh = 0.f, a_al = 0.f;
     float q_sc = 0.f, q_sh = 0.f, q_al = 0.f;
 
     for (int tx = 0; tx < g.tiles_x; ++tx) {
         const int x0 = tx * MB_TW;
+        // this wave's branch values of its four strips requested FIRST: they do not depend on the g_m tile, so their round trip runs
+        // under the tile's own loads and arithmetic
+        float zall[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int sidx = lane + 64 * it, r = sidx >> 4, s4 = (sidx & 15) * 4;
+            const int y = y0 + r, xb = x0 + s4;
+            if (y < h && xb < w) {
+                const float* zp = zpl + (size_t)y * w + xb;
+                if (vec) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(zp);
+                    zall[it][0] = t4.x; zall[it][1] = t4.y; zall[it][2] = t4.z; zall[it][3] = t4.w;
+                } else {
+                    const int nv = min(4, w - xb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zall[it][j] = j < nv ? zp[j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zall[it][j] = 0.f;
+            }
+        }
         // ---- g_m = dL/dm on the tile + a one-pixel halo (zero outside the image): BatchNorm/PReLU backward of merge_layer.2
         {
-            constexpr int NST = ((MB_TH + 2) * (MB_TW + 2) + 255) / 256;       // 5 elements per thread
             float gvv[NST], mvv[NST];
             // all loads of the tile first, then the arithmetic (interleaved, hipcc waits for each pair before the next is issued)
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
-                const int t = tid + 256 * k;
+                const int t = tid + NT * k;
                 const int R = t / (MB_TW + 2), Cq = t - R * (MB_TW + 2);
                 const int py = y0 - 1 + R, px = x0 - 1 + Cq;
-                const bool in = t < (MB_TH + 2) * (MB_TW + 2) && py >= 0 && py < h && px >= 0 && px < w;
+                const bool in = t < NEL && py >= 0 && py < h && px >= 0 && px < w;
                 const size_t o = (size_t)min(max(py, 0), h - 1) * w + min(max(px, 0), w - 1);
                 const float a = gyp[o], b2 = mp[o];
                 gvv[k] = in ? a : 0.f;
@@ -100,8 +127,8 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
-                const int t = tid + 256 * k;
-                if (t < (MB_TH + 2) * (MB_TW + 2)) {
+                const int t = tid + NT * k;
+                if (t < NEL) {
                     const int R = t / (MB_TW + 2), Cq = t - R * (MB_TW + 2);
                     const int py = y0 - 1 + R, px = x0 - 1 + Cq;
                     const bool in = py >= 0 && py < h && px >= 0 && px < w;
@@ -119,57 +146,43 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        const int y = y0 + r, xb = x0 + s4;
-        if (y < h && xb < w) {
-            float win[3][6];
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                const float4 a = *reinterpret_cast<const float4*>(&G[(r + rr) * MB_GS + s4]);
-                const float2 b2 = *reinterpret_cast<const float2*>(&G[(r + rr) * MB_GS + s4 + 4]);
-                win[rr][0] = a.x; win[rr][1] = a.y; win[rr][2] = a.z; win[rr][3] = a.w; win[rr][4] = b2.x; win[rr][5] = b2.y;
-            }
-            const int nv = min(4, w - xb);
-            const size_t pix = (size_t)y * w + xb;
-            // every branch's values requested before the first use (one memory round trip instead of NB dependent ones)
-            float zall[NB][4];
+        for (int it = 0; it < 4; ++it) {
+            const int sidx = lane + 64 * it, r = sidx >> 4, s4 = (sidx & 15) * 4;
+            const int y = y0 + r, xb = x0 + s4;
+            if (y < h && xb < w) {
+                float win[3][6];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const float* zp = zcat + (((size_t)n * NB + i) * g.P + c) * plane + pix;
-                if (vec) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(zp);
-                    zall[i][0] = t4.x; zall[i][1] = t4.y; zall[i][2] = t4.z; zall[i][3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) zall[i][j] = j < nv ? zp[j] : 0.f;
+                for (int rr = 0; rr < 3; ++rr) {
+                    const float4 a = *reinterpret_cast<const float4*>(&G[(r + rr) * MB_GS + s4]);
+                    const float2 b2 = *reinterpret_cast<const float2*>(&G[(r + rr) * MB_GS + s4 + 4]);
+                    win[rr][0] = a.x; win[rr][1] = a.y; win[rr][2] = a.z; win[rr][3] = a.w; win[rr][4] = b2.x; win[rr][5] = b2.y;
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                float* op = gt + (((size_t)i * g.N + n) * g.P + c) * plane + pix;
+                const int nv = min(4, w - xb);
+                float* op = opl + (size_t)y * w + xb;
                 float ov[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool live = j < nv;
-                    const float zvj = zall[i][j];
-                    const float u = zvj * bs[i] + bh[i];
+                    const float zvj = zall[it][j];
+                    const float u = zvj * bs + bh;
                     const bool pos = u > 0.f;
-                    const float yv = live ? (pos ? u : ba[i] * u) : 0.f;
+                    const float yv = live ? (pos ? u : ba * u) : 0.f;
                     float gyi = 0.f;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
                             const float gm = win[2 - ky][j + 2 - kx];
-                            gyi = fmaf(wm[i][ky * 3 + kx], gm, gyi);
-                            dw[i][ky * 3 + kx] = fmaf(yv, gm, dw[i][ky * 3 + kx]);
+                            gyi = fmaf(wmi[ky * 3 + kx], gm, gyi);
+                            dw[ky * 3 + kx] = fmaf(yv, gm, dw[ky * 3 + kx]);
                         }
                     if (!live) gyi = 0.f;
-                    const float gz = pos ? gyi : ba[i] * gyi;
-                    a_sc[i] += gz * zvj;
-                    a_sh[i] += gz;
-                    if (!pos) a_al[i] += gyi * u;
-                    ov[j] = gz * bs[i];
+                    const float gz = pos ? gyi : ba * gyi;
+                    a_sc += gz * zvj;
+                    a_sh += gz;
+                    if (!pos) a_al += gyi * u;
+                    ov[j] = gz * bs;
                 }
                 if (vec) {
                     *reinterpret_cast<float4*>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
@@ -182,38 +195,37 @@ __global__ __launch_bounds__(256) void pyr_merge_bwd_kernel(const float* __restr
         __syncthreads();      // the next tile overwrites G
     }
 
-    // ---- parameter gradients: wave sums -> LDS -> one atomic per value and workgroup
-    float v[NRED];
+    // ---- parameter gradients: 15 wave sums; the branch's twelve go out from this wave, merge_layer.2's three through LDS
+    float v[15];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+    for (int k = 0; k < 9; ++k) v[k] = dw[k];
+    v[9] = a_sc;  v[10] = a_sh;  v[11] = a_al;  v[12] = q_sc;  v[13] = q_sh;  v[14] = q_al;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[i * 9 + k] = dw[i][k];
-        v[NB * 9 + i * 3 + 0] = a_sc[i];  v[NB * 9 + i * 3 + 1] = a_sh[i];  v[NB * 9 + i * 3 + 2] = a_al[i];
+    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);       // every lane ends with the wave's total
     }
-    v[NB * 12 + 0] = q_sc;  v[NB * 12 + 1] = q_sh;  v[NB * 12 + 2] = q_al;
+    if (lane < 9) {
+        float t = v[0];
 #pragma unroll
-    for (int k = 0; k < NRED; ++k) {
-        float t = v[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-        if ((tid & 63) == 0) red[tid >> 6][k] = t;
+        for (int k = 1; k < 9; ++k) t = lane == k ? v[k] : t;
+        atomicAdd(&g.g_merge_w[((size_t)c * NB + bi) * 9 + lane], t);
+    } else if (lane == 9) {
+        // frozen BatchNorm folded into (scale, shift) = (gamma*inv, beta - mean*gamma*inv): (d scale, d shift) -> (d gamma, d beta)
+        atomicAdd(&g.g_br_scale[ch], g.br_inv ? (v[9] - g.br_mean[ch] * v[10]) * g.br_inv[ch] : v[9]);
+        atomicAdd(&g.g_br_shift[ch], v[10]);
+        atomicAdd(&g.g_br_alpha[ch], v[11]);
+    } else if (lane == 10) {
+        redq[bi][0] = v[12];  redq[bi][1] = v[13];  redq[bi][2] = v[14];
     }
     __syncthreads();
-    auto tot = [&](int k) { return (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]); };
-    if (tid < NB * 9) {
-        atomicAdd(&g.g_merge_w[(size_t)c * NB * 9 + tid], tot(tid));
-    } else if (tid < NB * 10) {
-        const int i = tid - NB * 9, ch = i * g.P + c;
-        const float t_sc = tot(NB * 9 + i * 3), t_sh = tot(NB * 9 + i * 3 + 1);
-        // frozen BatchNorm folded into (scale, shift) = (gamma*inv, beta - mean*gamma*inv): (d scale, d shift) -> (d gamma, d beta)
-        atomicAdd(&g.g_br_scale[ch], g.br_inv ? (t_sc - g.br_mean[ch] * t_sh) * g.br_inv[ch] : t_sc);
-        atomicAdd(&g.g_br_shift[ch], t_sh);
-        atomicAdd(&g.g_br_alpha[ch], tot(NB * 9 + i * 3 + 2));
-    } else if (tid == NB * 10) {
-        const float t_sc = tot(NB * 12), t_sh = tot(NB * 12 + 1);
+    if (tid == 0) {
+        float t_sc = 0.f, t_sh = 0.f, t_al = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { t_sc += redq[i][0];  t_sh += redq[i][1];  t_al += redq[i][2]; }
         atomicAdd(&g.g_m_scale[c], g.m_inv ? (t_sc - g.m_mean[c] * t_sh) * g.m_inv[c] : t_sc);
         atomicAdd(&g.g_m_shift[c], t_sh);
-        if (mact && g.g_m_alpha) atomicAdd(&g.g_m_alpha[c], tot(NB * 12 + 2));
+        if (mact && g.g_m_alpha) atomicAdd(&g.g_m_alpha[c], t_al);
     }
 }
 
@@ -1016,14 +1028,14 @@ extern "C" int mspl_pyrpool_merge_bwd(const float* gy, const float* mraw, const 
     g.g_m_scale = g_m_scale; g.g_m_shift = g_m_shift; g.g_m_alpha = g_m_alpha;
     const int64_t blocks = (int64_t)N * P * g.tiles_y;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "pyrpool_merge_bwd: grid too large");
-    const dim3 grid((unsigned)blocks), blk(256);
+    const dim3 grid((unsigned)blocks);
     hipStream_t s = (hipStream_t)stream;
     switch (nb) {
-        case 1: hipLaunchKernelGGL(pyr_merge_bwd_kernel<1>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
-        case 2: hipLaunchKernelGGL(pyr_merge_bwd_kernel<2>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
-        case 3: hipLaunchKernelGGL(pyr_merge_bwd_kernel<3>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
-        case 4: hipLaunchKernelGGL(pyr_merge_bwd_kernel<4>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
-        default: hipLaunchKernelGGL(pyr_merge_bwd_kernel<5>, grid, blk, 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 1: hipLaunchKernelGGL(pyr_merge_bwd_kernel<1>, grid, dim3(64), 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 2: hipLaunchKernelGGL(pyr_merge_bwd_kernel<2>, grid, dim3(128), 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 3: hipLaunchKernelGGL(pyr_merge_bwd_kernel<3>, grid, dim3(192), 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        case 4: hipLaunchKernelGGL(pyr_merge_bwd_kernel<4>, grid, dim3(256), 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
+        default: hipLaunchKernelGGL(pyr_merge_bwd_kernel<5>, grid, dim3(320), 0, s, gy, mraw, zcat, merge_w, br_scale, br_shift, br_alpha, m_scale, m_shift, m_alpha, g, gt); break;
     }
     MSPL_CHECK_LAUNCH("pyrpool_merge_bwd");
     return MSPL_OK;
