@@ -191,7 +191,10 @@ def test_graphed_supervised_step_equals_eager():
     graphed = [float(gs(x, y)[0]) for _ in range(2)]
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4, atol=1e-6)
     for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
-        np.testing.assert_allclose(q.float().cpu().numpy(), p.float().cpu().numpy(), rtol=1e-4, atol=2e-4, err_msg=k)
+        # two runs of the same kernels: the float atomics of the channel sums land in a different order, and at 32 x 48 the level-4 / 5
+        # BatchNorms normalise over 4 and 2 values per channel, which amplifies that over the four steps (seen: 2.2e-4 relative on a
+        # running_var)
+        np.testing.assert_allclose(q.float().cpu().numpy(), p.float().cpu().numpy(), rtol=5e-4, atol=2e-4, err_msg=k)
     assert int(nets[1].state_dict()['base_net.level1.bn.num_batches_tracked']) == 4
 
 
