@@ -494,7 +494,7 @@ int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C, int32_t H
  * launches of mspl_bn_batch_stats_fold_fwd and the separate mspl_bn_batch_stats_bwd_coeffs launch: the workgroup that adds a
  * channel's last partial finishes the channel.  _fused_fwd: same outputs as _fold_fwd; num_batches_tracked (may be NULL): the module's
  * int64 counter, incremented by one (nn.BatchNorm2d does it per forward: an ATen launch per BatchNorm otherwise).  mspl_bn_train_prelu_bwd: the backward of
- * y = PReLU(z * scale + shift + residual) with (scale, shift) the batch-statistics fold of z: gres (may be NULL), gc = direct gradient
+ * y = PReLU(z * scale + shift + residual) with (scale, shift) the batch-statistics fold of z: gres (may be NULL), gc (may be NULL: see mspl_bn_train_prelu_bwd_apply) = direct gradient
  * of z through the affine map, ggamma / gbeta (accumulate != 0: added to), galpha (ACCUMULATED, caller zeroes or passes the parameter's
  * gradient), and the coefficients p, q (C floats each) of the statistics' path: dL/dz = p * z + q + gc (one mspl_pointwise_fwd). */
 /* merge_layer.0 (BatchNorm fold + PReLU over the concatenation), Shuffle and merge_layer.2's grouped 3x3 from KEPT branch values
@@ -515,6 +515,10 @@ int mspl_bn_train_prelu_bwd(const float* z, const float* residual, const float* 
                             const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
                             int32_t HW, float* gres, float* gc, void* ws_zeroed, int32_t accumulate, float* ggamma, float* gbeta,
                             float* galpha, float* p, float* q, void* stream);
+/* The residual-free node's second pass with the direct gradient recomputed instead of read back (mspl_bn_train_prelu_bwd then takes
+ * gc = NULL and only reads): gz = p * z + q + (z * scale + shift > 0 ? gy : alpha * gy) * scale; alpha may be NULL (no PReLU). */
+int mspl_bn_train_prelu_bwd_apply(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                  const float* p, const float* q, int32_t N, int32_t C, int32_t HW, float* gz, void* stream);
 /* Backward of the statistics' dependence on z, per channel: t = gscale - mean * gshift; ggamma = t * invstd; gbeta = gshift (NULL:
  * not wanted); p = -gamma * t * invstd^3 / M; q = -gshift * scale / M - p * mean  (then gz = p * z + q, one mspl_pointwise_fwd).
  * accumulate != 0: ggamma / gbeta are added to (the parameters' gradient buffers). */

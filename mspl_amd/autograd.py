@@ -653,12 +653,13 @@ class PyrBodyBNFn(torch.autograd.Function):
         direct2 = psinks[4] is not None and psinks[5] is not None
         out2 = torch.empty(4, P, dtype=torch.float32, device=dev)             # d gamma, d beta, p, q
         gal2 = dst(psinks[6], (P,)) if m_alpha is not None else None
-        gc2 = torch.empty_like(mraw)
         check(lib.mspl_bn_train_prelu_bwd(_p(mraw), None, _p(gy), _p(st2[2]), _p(st2[3]), _p(m_alpha), _p(g2), _p(st2[0]), _p(st2[1]),
-                                          N, P, h * w, None, _p(gc2), _p(ws2), 1 if direct2 else 0,
+                                          N, P, h * w, None, None, _p(ws2), 1 if direct2 else 0,
                                           _p(psinks[4] if direct2 else out2[0]), _p(psinks[5] if direct2 else out2[1]), _p(gal2),
                                           _p(out2[2]), _p(out2[3]), _stream()))
-        g_mraw = ops.pointwise(mraw, Epi(out2[2], out2[3], residual=gc2))      # p * z + q + gc
+        g_mraw = torch.empty_like(mraw)                                       # p * z + q + gc, gc recomputed from (z, gy)
+        check(lib.mspl_bn_train_prelu_bwd_apply(_p(mraw), _p(gy), _p(st2[2]), _p(st2[3]), _p(m_alpha), _p(out2[2]), _p(out2[3]), N, P,
+                                                h * w, _p(g_mraw), _stream()))
         # the merge convolution and merge_layer.0's direct path; raw (d scale, d shift) sums of merge_layer.0
         raw0 = torch.zeros(2, C0, device=dev, dtype=torch.float32)
         scratch2 = torch.zeros(2, P, device=dev, dtype=torch.float32)         # (merge_layer.2 is the identity here: sums not used)
@@ -1010,7 +1011,7 @@ class BNTrainPReLUFn(torch.autograd.Function):
     """y = PReLU(BatchNorm_train(z) + residual) with batch statistics (nn.BatchNorm2d in train(), the supervised loop), as ONE
     autograd node of FOUR launches: statistics + fold (the workgroup that adds a channel's last partial finishes the channel), the
     affine / PReLU kernel; backward: the affine backward whose last workgroup per channel turns the sums into (d gamma, d beta, p, q),
-    and ONE pointwise launch gz = p * z + q + gc.  `ws`: the BatchNorm's persistent workspace (zeroed once, handed back zeroed by both
+    and ONE launch gz = p * z + q + gc (without a residual gc is recomputed there from (z, gy), not stored and read back).  `ws`: the BatchNorm's persistent workspace (zeroed once, handed back zeroed by both
     kernels: no memset, no finalize launch, no coefficient launch, no zeros() per call -- eight launches before).  As two nodes
     (BNBatchStatsFn + AffinePReLUFn) autograd added the two full-size gradients of z with an ATen kernel per BatchNorm and accumulated
     d gamma / d beta with two more (320 `add_` launches, 1.85 ms of a 17.5 ms iteration)."""
@@ -1039,7 +1040,7 @@ class BNTrainPReLUFn(torch.autograd.Function):
         hw = z[0, 0].numel()
         s_g, s_b, s_a = ctx.sinks
         gres = torch.empty_like(z) if residual is not None else None
-        gc = torch.empty_like(z)
+        gc = torch.empty_like(z) if residual is not None else None       # no residual: the second pass recomputes it from (z, gy)
         gal = None
         if alpha is not None:
             gal = s_a if s_a is not None else torch.zeros(C, device=z.device)
@@ -1048,7 +1049,12 @@ class BNTrainPReLUFn(torch.autograd.Function):
         check(lib.mspl_bn_train_prelu_bwd(_p(z), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(gamma), _p(mean), _p(invstd),
                                           N, C, hw, _p(gres), _p(gc), _p(ws), 1 if direct else 0, _p(s_g if direct else out[0]),
                                           _p(s_b if direct else out[1]), _p(gal), _p(out[2]), _p(out[3]), _stream()))
-        gz = ops.pointwise(z, Epi(out[2], out[3], residual=gc))           # p * z + q + gc
+        if gc is not None:
+            gz = ops.pointwise(z, Epi(out[2], out[3], residual=gc))       # p * z + q + gc
+        else:
+            gz = torch.empty_like(z)
+            check(lib.mspl_bn_train_prelu_bwd_apply(_p(z), _p(gy), _p(scale), _p(shift), _p(alpha), _p(out[2]), _p(out[3]), N, C, hw,
+                                                    _p(gz), _stream()))
         return (gz, None if direct else out[0], None if direct else out[1],
                 None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None, None)
 

@@ -224,6 +224,37 @@ __global__ __launch_bounds__(256) void bn_stats_path_add_kernel(float* __restric
     *gp = gv;
 }
 
+// Second pass of the batch-statistics BatchNorm + PReLU backward without a residual: gz = p * z + q + gc with the direct gradient
+// gc = (u > 0 ? gy : alpha * gy) * scale, u = z * scale + shift, RECOMPUTED from (z, gy) instead of read back -- the first pass
+// (mspl_bn_train_prelu_bwd with gc = NULL) then only reads: five tensor passes per BatchNorm instead of six.  Same operations in the
+// same order as the two-kernel form (affine_prelu_bwd_kernel's gc, then mspl_pointwise_fwd's p * z + q + gc).
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_train_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ alpha, const float* __restrict__ p,
+                                                                 const float* __restrict__ q, int C, int L, float* __restrict__ gz) {
+    const long long plane = (long long)blockIdx.z * gridDim.y + blockIdx.y;      // n * C + c
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const int c = (int)(plane % C);
+    const float sc = scale[c], sh = shift[c], pc = p[c], qc = q[c];
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[c] : 1.f;
+    auto one = [&](float zv, float g) {
+        const float u = zv * sc + sh;
+        const float gzv = (!act || u > 0.f) ? g : al * g;
+        return fmaf(zv, pc, qc) + gzv * sc;
+    };
+    if (VEC) {
+        const size_t o = (size_t)plane * L + t;
+        const float4 zv = reinterpret_cast<const float4*>(z)[o], g = reinterpret_cast<const float4*>(gy)[o];
+        reinterpret_cast<float4*>(gz)[o] = make_float4(one(zv.x, g.x), one(zv.y, g.y), one(zv.z, g.z), one(zv.w, g.w));
+    } else {
+        const size_t o = (size_t)plane * L + t;
+        gz[o] = one(z[o], gy[o]);
+    }
+}
+
 // merge_layer.0 .. merge_layer.2's convolution from the KEPT branch values (the batch-statistics pyramid node: the branch values are
 // computed once, their statistics give merge_layer.0's fold, and this kernel finishes the forward without evaluating the branches a
 // second time):  out[n][c] = sum_i conv3x3( PReLU(zcat[n][i*P + c] * scale[i*P + c] + shift[i*P + c]), merge_w[c][i] ), zero padding
@@ -323,6 +354,22 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
                                             double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
     return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int mspl_bn_train_prelu_bwd_apply(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                            const float* p, const float* q, int32_t N, int32_t C, int32_t HW, float* gz, void* stream) {
+    MSPL_REQUIRE(z && gy && scale && shift && p && q && gz, MSPL_ERR_NULL_POINTER, "bn_train_prelu_bwd_apply: null pointer");
+    MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "bn_train_prelu_bwd_apply: bad shape N=%d C=%d HW=%d", N, C, HW);
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)gy) | ((uintptr_t)gz)) & 15) == 0;
+    const int L = vec ? HW / 4 : HW;
+    const int64_t planes = (int64_t)N * C;
+    MSPL_REQUIRE(planes <= 65535ll * 65535ll, MSPL_ERR_BAD_SHAPE, "bn_train_prelu_bwd_apply: too many planes");
+    const int gy_ = planes < 65535 ? (int)planes : 65535;
+    const dim3 grid((unsigned)ceil_div(L, 256), (unsigned)gy_, (unsigned)ceil_div64(planes, gy_));
+    if (vec) hipLaunchKernelGGL(bn_train_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, gy, scale, shift, alpha, p, q, C, L, gz);
+    else hipLaunchKernelGGL(bn_train_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, gy, scale, shift, alpha, p, q, C, L, gz);
+    MSPL_CHECK_LAUNCH("bn_train_prelu_bwd_apply");
+    return MSPL_OK;
 }
 
 extern "C" int mspl_pyrpool_merge_fwd(const float* zcat, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const float* br_scale,

@@ -1065,7 +1065,7 @@ extern "C" int mspl_bn_train_prelu_bwd(const float* z, const float* residual, co
                                        const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
                                        int32_t HW, float* gres, float* gc, void* ws_zeroed, int32_t accumulate, float* ggamma, float* gbeta,
                                        float* galpha, float* p, float* q, void* stream) {
-    MSPL_REQUIRE(scale && shift && gamma && mean && invstd && ws_zeroed && ggamma && gbeta && p && q && gc, MSPL_ERR_NULL_POINTER,
+    MSPL_REQUIRE(scale && shift && gamma && mean && invstd && ws_zeroed && ggamma && gbeta && p && q, MSPL_ERR_NULL_POINTER,
                  "bn_train_prelu_bwd: null pointer");
     MSPL_REQUIRE(((uintptr_t)ws_zeroed & 7) == 0, MSPL_ERR_BAD_SHAPE, "bn_train_prelu_bwd: workspace must be 8-byte aligned");
     // the backward's part of the BatchNorm's persistent workspace (mspl_bn_fused_workspace_bytes): behind the forward's 2C doubles + C counters
