@@ -195,6 +195,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
+_CONV_SKIP = os.environ.get('MSPL_CONV_SKIP', '1') != '0'      # EESP in train(): projection + skip connection as one autograd node
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
 _FUSED_DW_EXP = os.environ.get('MSPL_EESP_EXP', '1') != '0'   # inference: K2 + K3 of a stride-1 EESP block as one launch
 _FUSED_NEXT_PROJ = os.environ.get('MSPL_EESP_NEXT', '1') != '0'   # ... and the following block's proj_1x1 inside that launch
@@ -436,14 +437,19 @@ class EESP(nn.Module):
             return ag.EESPFn.apply(input, cfg, fold(pj.bn), fold(br.bn), fold(exp.bn), pj.conv.weight, pj.bn.weight, pj.bn.bias,
                                    pj.act.weight, ws[0], ws[1], ws[2], ws[3], br.bn.weight, br.bn.bias, br.act.weight,
                                    exp.conv.weight, exp.bn.weight, exp.bn.bias, None if strided_avg else self.module_act.weight)
-        o1 = self.proj_1x1(input)
+        has_res = self.stride == 1 and exp.conv.out_channels == input.shape[1] and not (self.stride == 2 and self.downAvg)
+        skip = input
+        if has_res and pj.bn.training and _CONV_SKIP and input.requires_grad:
+            # projection and skip connection on one autograd node: the projection's data gradient adds the skip gradient in its epilogue
+            z1, skip = ag.conv_skip(input, pj.conv.weight, pj.conv.groups)
+            o1 = _bn_act(z1, pj.bn, pj.act.weight)
+        else:
+            o1 = self.proj_1x1(input)
         cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
         cat = self.br_after_cat(cat)
-        exp = self.conv_1x1_exp
         if self.stride == 2 and self.downAvg:
             return _conv_bn_act(cat, exp.conv, exp.bn)
-        residual = input if (self.stride == 1 and exp.conv.out_channels == input.shape[1]) else None
-        return _conv_bn_act(cat, exp.conv, exp.bn, self.module_act.weight, residual=residual)
+        return _conv_bn_act(cat, exp.conv, exp.bn, self.module_act.weight, residual=skip if has_res else None)
 
     def _fused_dw_exp(self, shape):
         """True when K2 + K3 of this block run as one launch for an input of `shape` (inference path)."""

@@ -74,6 +74,20 @@ def test_eesp_dw_fn(dil, stride, shape):
     check_op(lambda a, w0, w1, w2, w3: ag.eesp_dw(a, [w0, w1, w2, w3], dil, stride), cpu, [x] + ws)
 
 
+@pytest.mark.parametrize('cfg', [(2, 64, 16, 4, 9, 12), (1, 128, 32, 4, 18, 30), (3, 32, 8, 1, 7, 5)])
+def test_conv_skip_fn(cfg):
+    """autograd.ConvSkipFn: projection + skip alias on one node (the data gradient adds the skip gradient in its epilogue) against torch."""
+    from mspl_amd import autograd as ag
+    N, ci, co, g, h, w = cfg
+    x, wt, m = rnd(N, ci, h, w, seed=1), rnd(co, ci // g, 1, 1, seed=2, scale=0.3), rnd(N, ci, h, w, seed=3)
+
+    def gpu(a, b, mm):
+        y, skip = ag.conv_skip(a, b, g)
+        return torch.cat([y, skip * mm], 1)
+
+    check_op(gpu, lambda a, b, mm: torch.cat([F.conv2d(a, b, None, 1, 0, 1, g), a * mm], 1), [x, wt, m])
+
+
 def test_affine_prelu_fn():
     from mspl_amd import autograd as ag
     c, pre, res = rnd(2, 6, 9, 11, seed=1), rnd(2, 6, 9, 11, seed=2), rnd(2, 6, 9, 11, seed=3)
