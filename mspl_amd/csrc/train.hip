@@ -514,6 +514,112 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     gx[idx] = acc;
 }
 
+// Tiled separable form of the same gather (x2 / x4 up-sampling: the decoder merges and the two heads, 9-10 launches per training
+// step).  bilinear^T = R_y^T . gy . R_x is separable: a workgroup owns TLH x 64 INPUT pixels of one plane, stages the output-gradient
+// rows / columns they can receive from in LDS, (A) contracts the columns -- H[r][j] = sum_k wx[j][k] * G[r][clo[j] + k], the column
+// weights evaluated ONCE per workgroup into an LDS table instead of once per thread and candidate -- and (B) contracts the rows of H
+// with the row-weight table.  Candidates, weights and the order of the additions are exactly bilinear_bwd_kernel's (zero-weight
+// candidates contribute fma(0, finite, acc) = acc), so the results are bit-identical; the per-thread form spent ~250-300 vector
+// instructions per input pixel on re-evaluating bilinear_src (146 us for the 72x120 -> 288x480 head at 16 x 13 planes: 0.8 TB/s).
+__device__ __forceinline__ int bb_lo(float s, int i) { return s > 0.f ? max(0, (int)ceilf((float)(i - 1) / s) - 1) : 0; }
+__device__ __forceinline__ int bb_hi(float s, int i, int O) { return s > 0.f ? min(O - 1, (int)floorf((float)(i + 1) / s) + 1) : O - 1; }
+
+template <int MAXC, int TLH>
+__global__ __launch_bounds__(256) void bilinear_bwd_tile_kernel(const float* __restrict__ gy, RsG g, int FH, int FWS, int tiles_x,
+                                                                float* __restrict__ gx) {
+    constexpr int TLW = 64;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* G = sm;                                      // [FH][FWS]: output-gradient tile, zero past the staged columns
+    float* Hh = G + FH * FWS;                           // [FH + MAXC][TLW]: column-contracted rows, zero past the staged rows
+    float* WX = Hh + (FH + MAXC) * TLW;                 // [MAXC][TLW] column weights of candidate k of input column j
+    float* WY = WX + MAXC * TLW;                        // [TLH][MAXC] row weights
+    int* CL = reinterpret_cast<int*>(WY + TLH * MAXC);  // [TLW] first candidate column of input column j, relative to the tile
+    int* RL = CL + TLW;                                 // [TLH] first candidate row of input row i, relative to the tile
+    const int t = blockIdx.z * gridDim.y + blockIdx.y;  // plane n*C + c
+    if (t >= g.N * g.C) return;
+    const int txi = blockIdx.x % tiles_x, tyi = blockIdx.x / tiles_x;
+    const int iy0 = tyi * TLH, ix0 = txi * TLW;
+    const int iyl = min(iy0 + TLH, g.Hi) - 1, ixl = min(ix0 + TLW, g.Wi) - 1;
+    const int RY0 = bb_lo(g.sh, iy0), RY1 = bb_hi(g.sh, iyl, g.Ho), CX0 = bb_lo(g.sw, ix0), CX1 = bb_hi(g.sw, ixl, g.Wo);
+    const int nrows = min(RY1 - RY0 + 1, FH), ncols = min(CX1 - CX0 + 1, FWS - MAXC);      // (the host sized FH / FWS from the same formulas)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* gp = gy + (size_t)t * g.Ho * g.Wo;
+    // ---- stage the gradient tile: a wave per row, lanes over the columns, two rows' loads in flight
+    for (int r = wave; r < nrows; r += 8) {
+        const float* ra = gp + (size_t)(RY0 + r) * g.Wo + CX0;
+        const bool hb = r + 4 < nrows;
+        const float* rb = gp + (size_t)(RY0 + (hb ? r + 4 : r)) * g.Wo + CX0;
+        for (int c0 = 0; c0 < FWS; c0 += 128) {
+            const int ca = c0 + lane, cb = c0 + 64 + lane;
+            const float a0 = ca < ncols ? ra[ca] : 0.f, a1 = cb < ncols ? ra[cb] : 0.f;
+            const float b0 = (hb && ca < ncols) ? rb[ca] : 0.f, b1 = (hb && cb < ncols) ? rb[cb] : 0.f;
+            if (ca < FWS) { G[r * FWS + ca] = a0;  if (hb) G[(r + 4) * FWS + ca] = b0; }
+            if (cb < FWS) { G[r * FWS + cb] = a1;  if (hb) G[(r + 4) * FWS + cb] = b1; }
+        }
+    }
+    // rows of H past the staged ones: read (with zero weights) by phase B
+    for (int i = tid; i < MAXC * TLW; i += 256) Hh[nrows * TLW + i] = 0.f;
+    // ---- weight tables
+    for (int task = tid; task < MAXC * TLW; task += 256) {
+        const int k = task / TLW, j = task - k * TLW, ix = ix0 + j;
+        float w = 0.f;
+        int lo = CX0;
+        if (ix <= ixl) {
+            lo = bb_lo(g.sw, ix);
+            const int ox = lo + k;
+            if (ox <= bb_hi(g.sw, ix, g.Wo)) {
+                int x0, x1;  float wx0, wx1;
+                bilinear_src(g.sw, ox, g.Wi, x0, x1, wx0, wx1);
+                w = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+            }
+        }
+        WX[task] = w;
+        if (k == 0) CL[j] = lo - CX0;
+    }
+    for (int task = tid; task < TLH * MAXC; task += 256) {
+        const int i = task / MAXC, k = task - i * MAXC, iy = iy0 + i;
+        float w = 0.f;
+        int lo = RY0;
+        if (iy <= iyl) {
+            lo = bb_lo(g.sh, iy);
+            const int oy = lo + k;
+            if (oy <= bb_hi(g.sh, iy, g.Ho)) {
+                int y0, y1;  float wy0, wy1;
+                bilinear_src(g.sh, oy, g.Hi, y0, y1, wy0, wy1);
+                w = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            }
+        }
+        WY[task] = w;
+        if (k == 0) RL[i] = lo - RY0;
+    }
+    __syncthreads();
+    // ---- (A) contract the columns: thread = input column j, rows wave, wave + 4, ...
+    {
+        float wx[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) wx[k] = WX[k * TLW + lane];
+        const float* gcol = G + CL[lane];
+        for (int r = wave; r < nrows; r += 4) {
+            const float* row = gcol + r * FWS;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) acc = fmaf(wx[k], row[k], acc);
+            Hh[r * TLW + lane] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- (B) contract the rows and store
+    for (int i = wave; i < TLH; i += 4) {
+        const int iy = iy0 + i, ix = ix0 + lane;
+        if (iy > iyl || ix > ixl) continue;
+        const float* hcol = Hh + RL[i] * TLW + lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) acc = fmaf(WY[i * MAXC + k], hcol[k * TLW], acc);
+        gx[(size_t)t * g.Hi * g.Wi + (size_t)iy * g.Wi + ix] = acc;
+    }
+}
+
 // Large up-sampling ratios (the pyramid's 0.1 branch: 7x12 -> 64x120, 24x24 candidate outputs per input pixel, and only a
 // few hundred input pixels per plane): one WAVE per input pixel, lanes over the candidate columns, rows walked together.
 __global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const float* __restrict__ gy, RsG g, float* __restrict__ gx, int64_t total_in) {
@@ -1139,6 +1245,36 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
         return MSPL_OK;
     }
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
+    static const int tile_form = getenv("MSPL_BILINEAR_BWD_TILE") ? atoi(getenv("MSPL_BILINEAR_BWD_TILE")) : 1;
+    if (tile_form && g.sh > 0.f && g.sw > 0.f) {
+        // candidate windows (rows and columns) of at most 8 (x2) or 12 (x4): the tiled separable form
+        const float cw = 2.0f / g.sw + 3.0f, rw = 2.0f / g.sh + 3.0f;
+        const int maxc = (cw <= 8.0f && rw <= 8.0f) ? 8 : ((cw <= 12.0f && rw <= 12.0f) ? 12 : 0);
+        if (maxc) {
+            const int TLH = maxc == 8 ? 8 : 4, TLW = 64;
+            const int tiles_x = ceil_div(Wi, TLW), tiles_y = ceil_div(Hi, TLH);
+            auto lo = [](float sc, int i) { const int v = (int)ceilf((float)(i - 1) / sc) - 1; return v > 0 ? v : 0; };
+            auto hi = [](float sc, int i, int O) { const int v = (int)floorf((float)(i + 1) / sc) + 1; return v < O - 1 ? v : O - 1; };
+            int FH = 1, FW = 1;
+            for (int ty = 0; ty < tiles_y; ++ty) {
+                const int i0 = ty * TLH, il = (i0 + TLH < Hi ? i0 + TLH : Hi) - 1;
+                FH = std::max(FH, hi(g.sh, il, Ho) - lo(g.sh, i0) + 1);
+            }
+            for (int tx = 0; tx < tiles_x; ++tx) {
+                const int i0 = tx * TLW, il = (i0 + TLW < Wi ? i0 + TLW : Wi) - 1;
+                FW = std::max(FW, hi(g.sw, il, Wo) - lo(g.sw, i0) + 1);
+            }
+            const int FWS = ((FW + maxc + 3) & ~3) | 4;            // row stride: staged columns + the candidates' over-read, not a multiple of 8 floats
+            const size_t lds = ((size_t)FH * FWS + (size_t)(FH + maxc) * TLW + (size_t)maxc * TLW + (size_t)TLH * maxc + TLW + TLH) * sizeof(float);
+            if (lds <= 64 * 1024 && (int64_t)tiles_x * tiles_y < (1ll << 31)) {
+                const dim3 tgrid((unsigned)(tiles_x * tiles_y), (unsigned)gyd, (unsigned)ceil_div(planes, gyd));
+                if (maxc == 8) hipLaunchKernelGGL((bilinear_bwd_tile_kernel<8, 8>), tgrid, dim3(256), lds, (hipStream_t)stream, gy, g, FH, FWS, tiles_x, gx);
+                else hipLaunchKernelGGL((bilinear_bwd_tile_kernel<12, 4>), tgrid, dim3(256), lds, (hipStream_t)stream, gy, g, FH, FWS, tiles_x, gx);
+                MSPL_CHECK_LAUNCH("bilinear_bwd(tiled)");
+                return MSPL_OK;
+            }
+        }
+    }
     const dim3 grid((unsigned)ceil_div(Hi * Wi, 256), (unsigned)gyd, (unsigned)ceil_div(planes, gyd));
     if (g.sw > 0.f && 2.0f / g.sw + 3.0f <= 8.0f)          // x2 up-sampling (the decoder, the heads): at most 7 candidate columns
         hipLaunchKernelGGL(bilinear_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, gy, g, gx, total);

@@ -171,6 +171,10 @@ def test_resample_fns():
     y = rnd(1, 2, 5, 6, seed=2)
     check_op(lambda a: ag.bilinear(a, (64, 120)), lambda a: F.interpolate(a, (64, 120), mode='bilinear', align_corners=True), [y])
     check_op(lambda a: ag.bilinear(a, (5, 6)), lambda a: F.interpolate(a, (5, 6), mode='bilinear', align_corners=True), [y])
+    # tiled separable backward (x2 / x4 and in between): several 64-column tiles, ragged tiles, a non-integer ratio, down-scaling rows
+    for shp, size in (((2, 3, 20, 150), (40, 300)), ((1, 2, 13, 70), (52, 280)), ((1, 2, 17, 33), (29, 57)), ((2, 2, 9, 130), (36, 260)),
+                      ((1, 3, 24, 96), (48, 191)), ((1, 2, 30, 40), (45, 100))):
+        check_op(lambda a: ag.bilinear(a, size), lambda a: F.interpolate(a, size, mode='bilinear', align_corners=True), [rnd(*shp, seed=4)])
     # rows form of the wide backward: more output columns than threads, more input columns than one candidate window
     z = rnd(2, 3, 13, 24, seed=3)
     check_op(lambda a: ag.bilinear(a, (128, 300)), lambda a: F.interpolate(a, (128, 300), mode='bilinear', align_corners=True), [z])
