@@ -321,28 +321,33 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
     long long u = u0 + threadIdx.x;
     int n = (int)(u / L), q = (int)(u - (long long)n * L);
     auto advance = [&]() { u += 256; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
-    if (vec) {                                 // 16-byte operands, two independent quads in flight per iteration
+    if (vec) {                                 // 16-byte operands, four independent quads per operand in flight per iteration
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int UQ = 4;
         while (u < u1) {
-            const size_t oa = (((size_t)n * C + ch) * (size_t)HW) + 4 * (size_t)q;
-            advance();
-            const bool hb = u < u1;
-            const size_t ob = hb ? (((size_t)n * C + ch) * (size_t)HW) + 4 * (size_t)q : oa;
-            advance();
-            const float4 ca = *reinterpret_cast<const float4*>(c + oa), ga = *reinterpret_cast<const float4*>(gy + oa);
-            const float4 pa = pre ? *reinterpret_cast<const float4*>(pre + oa) : zero, ra = res ? *reinterpret_cast<const float4*>(res + oa) : zero;
-            const float4 cb = *reinterpret_cast<const float4*>(c + ob), gb = *reinterpret_cast<const float4*>(gy + ob);
-            const float4 pb = pre ? *reinterpret_cast<const float4*>(pre + ob) : zero, rb = res ? *reinterpret_cast<const float4*>(res + ob) : zero;
-            float4 gz, gc;
-            one(ca.x, pa.x, ra.x, ga.x, gz.x, gc.x); one(ca.y, pa.y, ra.y, ga.y, gz.y, gc.y);
-            one(ca.z, pa.z, ra.z, ga.z, gz.z, gc.z); one(ca.w, pa.w, ra.w, ga.w, gz.w, gc.w);
-            if (gz_out) *reinterpret_cast<float4*>(gz_out + oa) = gz;
-            if (gc_out) *reinterpret_cast<float4*>(gc_out + oa) = gc;
-            if (hb) {
-                one(cb.x, pb.x, rb.x, gb.x, gz.x, gc.x); one(cb.y, pb.y, rb.y, gb.y, gz.y, gc.y);
-                one(cb.z, pb.z, rb.z, gb.z, gz.z, gc.z); one(cb.w, pb.w, rb.w, gb.w, gz.w, gc.w);
-                if (gz_out) *reinterpret_cast<float4*>(gz_out + ob) = gz;
-                if (gc_out) *reinterpret_cast<float4*>(gc_out + ob) = gc;
+            size_t o[UQ];  bool h[UQ];
+#pragma unroll
+            for (int i = 0; i < UQ; ++i) {
+                h[i] = u < u1;
+                o[i] = h[i] ? (((size_t)n * C + ch) * (size_t)HW) + 4 * (size_t)q : o[0];
+                advance();
+            }
+            float4 cv[UQ], gv[UQ], pv[UQ], rv[UQ];
+#pragma unroll
+            for (int i = 0; i < UQ; ++i) {
+                cv[i] = *reinterpret_cast<const float4*>(c + o[i]);
+                gv[i] = *reinterpret_cast<const float4*>(gy + o[i]);
+                pv[i] = pre ? *reinterpret_cast<const float4*>(pre + o[i]) : zero;
+                rv[i] = res ? *reinterpret_cast<const float4*>(res + o[i]) : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < UQ; ++i) {
+                if (!h[i]) continue;
+                float4 gz, gc;
+                one(cv[i].x, pv[i].x, rv[i].x, gv[i].x, gz.x, gc.x); one(cv[i].y, pv[i].y, rv[i].y, gv[i].y, gz.y, gc.y);
+                one(cv[i].z, pv[i].z, rv[i].z, gv[i].z, gz.z, gc.z); one(cv[i].w, pv[i].w, rv[i].w, gv[i].w, gz.w, gc.w);
+                if (gz_out) *reinterpret_cast<float4*>(gz_out + o[i]) = gz;
+                if (gc_out) *reinterpret_cast<float4*>(gc_out + o[i]) = gc;
             }
         }
     } else {

@@ -175,8 +175,8 @@ def test_graphed_supervised_step_equals_eager():
     from mspl_amd import losses, models, supervised
     c = SUPERVISED_CASE
     a = argparse.Namespace(s=c['s'], channels=3, num_classes=1000)
-    x = synth_input((2, 3, 32, 48), 28).cuda()
-    y = synth_labels((2, 32, 48), c['classes'], 28).cuda()
+    x = synth_input((2, 3, 64, 96), 28).cuda()
+    y = synth_labels((2, 64, 96), c['classes'], 28).cuda()
     crit = losses.SegmentationLoss(n_classes=c['classes'], device='cuda', ignore_idx=c['ignore_idx'])
     nets = []
     for _ in range(2):
@@ -191,10 +191,12 @@ def test_graphed_supervised_step_equals_eager():
     graphed = [float(gs(x, y)[0]) for _ in range(2)]
     np.testing.assert_allclose(graphed, eager[2:], rtol=5e-4, atol=1e-6)
     for (k, p), (_, q) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
-        # two runs of the same kernels: the float atomics of the channel sums land in a different order, and at 32 x 48 the level-4 / 5
-        # BatchNorms normalise over 4 and 2 values per channel, which amplifies that over the four steps (seen: 2.2e-4 relative on a
-        # running_var)
-        np.testing.assert_allclose(q.float().cpu().numpy(), p.float().cpu().numpy(), rtol=5e-4, atol=2e-4, err_msg=k)
+        # two runs of the same kernels: the float atomics of the weight-gradient / channel sums land in a different order, and the
+        # coarsest BatchNorms normalise over a handful of values per channel (16 and 4 at 64 x 96), which amplifies that over the four
+        # steps (seen at 32 x 48, 4 and 2 values: 1.1e-3 relative on a running_var).  The outcome is bimodal: a 1e-7 difference can flip
+        # a discrete event (a PReLU sign near zero) in step 3, after which the two runs sit 2e-5 apart in the loss and up to 4e-4 in
+        # single weights (tools/sup_graph_vs_eager.py, tools/sup_determinism4.py: eager vs eager shows the same two outcomes)
+        np.testing.assert_allclose(q.float().cpu().numpy(), p.float().cpu().numpy(), rtol=2e-3, atol=1e-3, err_msg=k)
     assert int(nets[1].state_dict()['base_net.level1.bn.num_batches_tracked']) == 4
 
 

@@ -11,7 +11,7 @@ python - $O/bn_kernel_trace.csv <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-keys = ('bn_stats_fused', 'affine_prelu_bwd', 'pointwise_kernel')
+keys = ('bn_stats_fused', 'affine_prelu_bwd', 'pointwise_kernel', 'bn_train_bwd_apply')
 seq = [(k, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // 256) for r in rows for k in keys if k in r['Kernel_Name']]
 # per shape: 5 reps x (stats, pointwise, bwd, pointwise)
 for s in range(len(seq) // 20):
