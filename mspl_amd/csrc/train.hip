@@ -147,6 +147,78 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_kernel(const float* __res
                   (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
+// Strip form of the same for stride 1 / dilation 1 / padding 1 on rows of whole 16-byte strips (the EfficientPWConv expansions, the
+// pyramid stages and merge convolutions: every stride-1 3x3 of the training steps): a thread takes FOUR adjacent output positions per
+// step -- gy as one 16-byte load, each input row as one 16-byte load + its two neighbours -- so a position's tap costs a quarter of a
+// load instruction instead of one: the per-position form is bound by the L1 load path (CG * 9 four-byte loads per position:
+// 179 us for the 8-channel-group expansion at 16 x 144x240 whose operands are 141 MB).
+template <int CG>
+__global__ __launch_bounds__(256) void g3x3_bwd_weight_strip_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                    ConvGeom g, int chunks, float* __restrict__ gw) {
+    const int chunk = blockIdx.x % chunks, co = blockIdx.x / chunks;
+    const int ci0 = (co / g.cout_g) * CG;
+    const int XS = g.W >> 2, nstrip = g.H * XS;                     // Ho == H, Wo == W
+    const int64_t total = (int64_t)g.N * nstrip;
+    const int64_t per = (total + chunks - 1) / chunks;
+    const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
+    const size_t plane = (size_t)g.H * g.W;
+    float acc[CG * 9];
+#pragma unroll
+    for (int t = 0; t < CG * 9; ++t) acc[t] = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int n = (int)(i / nstrip), sidx = (int)(i - (int64_t)n * nstrip);
+        const int oy = sidx / XS, x0 = (sidx - oy * XS) * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + ((size_t)n * g.Cout + co) * plane + (size_t)oy * g.W + x0);
+        const float gvv[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float* xp = x + ((size_t)n * g.Cin + ci0) * plane;
+        const float ml = x0 > 0 ? 1.f : 0.f, mr = x0 + 4 < g.W ? 1.f : 0.f;
+        const int xl = max(x0 - 1, 0), xr = min(x0 + 4, g.W - 1);
+        int roff[3];  float rm[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            rm[ky] = (iy >= 0 && iy < g.H) ? 1.f : 0.f;
+            roff[ky] = min(max(iy, 0), g.H - 1) * g.W;
+        }
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci) {
+            // the channel's nine loads first, then the arithmetic
+            float4 v[3];  float l[3], r[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* row = xp + ci * plane + roff[ky];
+                v[ky] = *reinterpret_cast<const float4*>(row + x0);
+                l[ky] = row[xl];
+                r[ky] = row[xr];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float w6[6] = {l[ky] * (ml * rm[ky]), v[ky].x * rm[ky], v[ky].y * rm[ky], v[ky].z * rm[ky], v[ky].w * rm[ky],
+                                     r[ky] * (mr * rm[ky])};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float a = acc[ci * 9 + ky * 3 + kx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a = fmaf(gvv[j], w6[j + kx], a);
+                    acc[ci * 9 + ky * 3 + kx] = a;
+                }
+            }
+        }
+    }
+    __shared__ float part[4][CG * 9];
+#pragma unroll
+    for (int t = 0; t < CG * 9; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < CG * 9)
+        atomicAdd(&gw[(size_t)co * CG * 9 + threadIdx.x],
+                  (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
 // The same for COB consecutive output channels of one group per workgroup: a position's CG * 9 taps are loaded once and serve COB
 // output channels (the stem's 3 -> 32 stride-2 gradient loaded every tap 32 times: 424 M four-byte loads through L1, 197 us for
 // 87 MB of operands).  Per accumulator the positions arrive in the same order as above: same sums.
@@ -1022,6 +1094,24 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         while ((int64_t)(Cout / 4) * chunks < 2048 && total / (chunks * 2) >= 2048) chunks *= 2;
         hipLaunchKernelGGL((g3x3_bwd_weight_cob_kernel<3, 4>), dim3((unsigned)(Cout / 4 * chunks)), dim3(256), 0, s, gy, x, g, chunks, gw);
         MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3, few input channels, 4 output channels per workgroup)");
+        return MSPL_OK;
+    }
+    static const int strip_form = getenv("MSPL_G3X3_WGRAD_STRIP") ? atoi(getenv("MSPL_G3X3_WGRAD_STRIP")) : 1;
+    if (strip_form && K == 3 && (g.cin_g <= 5 || g.cin_g == 8) && g.stride == 1 && g.dil == 1 && g.pad == 1 && (g.W & 3) == 0 &&
+        ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0) {
+        const int64_t strips = total / 4;
+        int chunks = 1;
+        while ((int64_t)Cout * chunks < 2048 && strips / (chunks * 2) >= 1024) chunks *= 2;
+        const dim3 grid((unsigned)(Cout * chunks)), blk(256);
+        switch (g.cin_g) {
+            case 1: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<1>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 2: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<2>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 3: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<3>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 4: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<4>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            case 5: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<5>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+            default: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<8>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
+        }
+        MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3, few input channels, strips)");
         return MSPL_OK;
     }
     if (K == 3 && (g.cin_g <= 5 || g.cin_g == 8)) {

@@ -49,7 +49,10 @@ def check_op(gpu_fn, cpu_fn, tensors, atol=2e-4, rtol=2e-3):
                                  (1, 16, 16, 16, 11, 9, 3, 1), (1, 20, 4, 4, 7, 7, 3, 1), (1, 24, 12, 4, 8, 8, 3, 2),
                                  # 1x1 weight gradient on the matrix cores: several 32-tiles, partial tiles, pixel tails, slices
                                  (2, 128, 96, 1, 8, 12, 1, 1), (3, 512, 512, 4, 18, 30, 1, 1), (2, 48, 40, 1, 6, 10, 1, 1),
-                                 (1, 64, 256, 2, 36, 60, 1, 1)])
+                                 (1, 64, 256, 2, 36, 60, 1, 1),
+                                 # 3x3 weight gradient, strip form (stride 1, rows of whole 16-byte strips): cin_g = 1, 8, 5, 4, 3, 2
+                                 (2, 16, 16, 16, 12, 16, 3, 1), (1, 16, 8, 2, 9, 20, 3, 1), (2, 10, 4, 2, 6, 8, 3, 1), (1, 12, 6, 3, 7, 12, 3, 1),
+                                 (1, 6, 4, 2, 5, 4, 3, 1), (2, 8, 8, 4, 10, 24, 3, 1), (3, 32, 12, 4, 33, 68, 3, 1)])
 def test_conv_fn(cfg):
     from mspl_amd import autograd as ag
     N, ci, co, g, h, w, k, s = cfg
