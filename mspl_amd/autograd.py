@@ -807,6 +807,36 @@ class BilinearFn(torch.autograd.Function):
         return gx, None
 
 
+class TwoHeadSumFn(torch.autograd.Function):
+    """up(main) + 0.5 * up(aux) at `size` (`outputs[0] + 0.5 * outputs[1]` of train_seg_ue, utilities/train_eval_seg.py:187, with the two
+    final bilinear up-samplings of espdnet_ue.py:301-302) as one node of two launches: the second up-sampling applies the 0.5 and adds
+    the first in its epilogue (same roundings as the three ATen / bilinear launches: the 0.5 is exact).  Backward: the two transposed
+    interpolations of the SAME gradient and the 0.5 on the small aux-sized result (exact, commutes with the sums)."""
+
+    @staticmethod
+    def forward(ctx, main, aux, size):
+        main, aux = _c(main), _c(aux)
+        ctx.shapes = (main.shape, aux.shape)
+        out = ops.bilinear(main, size)
+        half = _const_vec(0.5, aux.shape[1], aux.device)
+        return ops.bilinear(aux, size, Epi(scale=half, residual=out), out=(out, 0))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs = []
+        for shp in ctx.shapes:
+            gx = torch.empty(shp, device=g.device, dtype=torch.float32)
+            check(lib.mspl_bilinear_bwd(_p(g), shp[0], shp[1], shp[2], shp[3], g.shape[2], g.shape[3], _p(gx), _stream()))
+            outs.append(gx)
+        outs[1].mul_(0.5)
+        return outs[0], outs[1], None
+
+
+def two_head_sum(main, aux, size):
+    return TwoHeadSumFn.apply(main, aux, tuple(int(v) for v in size))
+
+
 class AdaptivePoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, size):

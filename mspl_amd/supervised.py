@@ -14,6 +14,8 @@ Batch-statistics BatchNorm runs through mspl_amd.autograd.BNBatchStatsFn (statis
 kernels); `FlatSGD` keeps parameters, gradients and momentum buffers of all groups in three flat fp32 buffers laid out group
 after group, so a step is one kernel per group and the multi-GPU exchange one all-reduce.
 """
+import os
+
 import torch
 
 from . import autograd as ag
@@ -97,6 +99,23 @@ def flood(loss, b=FLOOD_LEVEL):
     return (loss - b).abs() + b
 
 
+_TWO_HEAD_SUM = os.environ.get('MSPL_TWO_HEAD_SUM', '1') != '0'
+
+
+def two_head_outputs(model, inputs, depth=None):
+    """`outputs[0] + 0.5 * outputs[1]` of the two-head model (train_eval_seg.py:185-187): through the low-resolution heads and
+    autograd.TwoHeadSumFn when the model offers them (two launches instead of two up-samplings + a multiply + an add on full-size
+    logits), the reference's three steps otherwise."""
+    if _TWO_HEAD_SUM and hasattr(model, 'forward_lowres') and getattr(model, 'aux_layer', -1) >= 0:
+        main, aux = model.forward_lowres(inputs, depth) if depth is not None else model.forward_lowres(inputs)
+        if aux is not None and main.shape[1] == aux.shape[1]:
+            return ag.two_head_sum(main, aux, inputs.shape[2:])
+        out = (ag.bilinear(main, tuple(inputs.shape[2:])), ag.bilinear(aux, tuple(inputs.shape[2:])))
+    else:
+        out = model(inputs, depth) if depth is not None else model(inputs)
+    return out[0] + 0.5 * out[1]
+
+
 def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=None, add_criterion=None, weight=1.0,
                       lr=0.009, lr_mult=10.0, momentum=0.9, weight_decay=4e-5, b=FLOOD_LEVEL):
     """One iteration of train_seg_ue (utilities/train_eval_seg.py:179-225) for a two-head model in train() mode.
@@ -107,8 +126,7 @@ def train_seg_ue_step(model, inputs, target, criterion, optimizer=None, depth=No
     tr = getattr(optimizer, 'transposer', None)
     with torch.enable_grad(), ag.grad_sinks(), (tr.active() if tr is not None else ag.collect_conv_weights()) as got:
         layers.prefold_frozen_bn(model)
-        out = model(inputs, depth) if depth is not None else model(inputs)
-        outputs = out[0] + 0.5 * out[1]
+        outputs = two_head_outputs(model, inputs, depth)
         loss = criterion(outputs, target).mean()
         if add_criterion is not None:
             loss = loss + add_criterion(inputs, outputs) * weight
@@ -143,8 +161,7 @@ class GraphedSupervisedStep:
             self.optimizer.zero_grad()
             with torch.enable_grad(), ag.grad_sinks(), self.optimizer.transposer.active():
                 layers.prefold_frozen_bn(model)
-                out = model(self.inputs, self.depth) if self.depth is not None else model(self.inputs)
-                self.outputs = out[0] + 0.5 * out[1]
+                self.outputs = two_head_outputs(model, self.inputs, self.depth)
                 self.loss = flood(criterion(self.outputs, self.target).mean(), b)
                 self.loss.backward()
         self._finish()                                  # the capture did not execute: run the iteration it recorded

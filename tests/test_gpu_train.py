@@ -183,6 +183,18 @@ def test_resample_fns():
     check_op(lambda a: ag.bilinear(a, (128, 300)), lambda a: F.interpolate(a, (128, 300), mode='bilinear', align_corners=True), [z])
 
 
+def test_two_head_sum_fn():
+    """autograd.TwoHeadSumFn = bilinear(main) + 0.5 * bilinear(aux) of the supervised loop: forward bit-identical to the three-step form,
+    gradients against torch."""
+    from mspl_amd import autograd as ag
+    main, aux = rnd(2, 5, 16, 24, seed=1), rnd(2, 5, 8, 12, seed=2)
+    size = (32, 48)
+    up = lambda t: F.interpolate(t, size, mode='bilinear', align_corners=True)
+    check_op(lambda a, b: ag.two_head_sum(a, b, size), lambda a, b: up(a) + 0.5 * up(b), [main, aux])
+    m, a = main.to(DEV), aux.to(DEV)
+    assert torch.equal(ag.two_head_sum(m, a, size), ag.bilinear(m, size) + 0.5 * ag.bilinear(a, size))
+
+
 def test_gate_fns():
     from mspl_amd import autograd as ag
     x, w = rnd(2, 8, 7, 9, seed=1), rnd(6, 8, 1, 1, seed=2)
