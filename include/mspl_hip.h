@@ -515,6 +515,18 @@ int mspl_bn_train_prelu_bwd(const float* z, const float* residual, const float* 
                             const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
                             int32_t HW, float* gres, float* gc, void* ws_zeroed, int32_t accumulate, float* ggamma, float* gbeta,
                             float* galpha, float* p, float* q, void* stream);
+/* Small planes (mspl_bn_train_small_fits: N * HW <= 40 960 values per channel -- levels 3-5 of the path): the whole node per channel in
+ * one workgroup and ONE launch each way, no workspace.  _fwd: y = PReLU(BatchNorm_train(z) + residual) + the statistics outputs of
+ * mspl_bn_batch_stats_fused_fwd (residual / alpha / running_* / num_batches_tracked may be NULL).  _bwd: gz (dL/dz through both the
+ * affine map and the statistics), gres (NULL without a residual), d gamma / d beta (accumulate != 0: added to), galpha (ACCUMULATED). */
+int mspl_bn_train_small_fits(int32_t N, int32_t C, int32_t HW);
+int mspl_bn_train_small_fwd(const float* z, const float* residual, const float* gamma, const float* beta, const float* alpha,
+                            int32_t N, int32_t C, int32_t HW, float eps, float momentum, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift, float* y, void* stream);
+int mspl_bn_train_small_bwd(const float* z, const float* residual, const float* gy, const float* scale, const float* shift,
+                            const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
+                            int32_t HW, int32_t accumulate, float* gz, float* gres, float* ggamma, float* gbeta, float* galpha,
+                            void* stream);
 /* The residual-free node's second pass with the direct gradient recomputed instead of read back (mspl_bn_train_prelu_bwd then takes
  * gc = NULL and only reads): gz = p * z + q + (z * scale + shift > 0 ? gy : alpha * gy) * scale; alpha may be NULL (no PReLU). */
 int mspl_bn_train_prelu_bwd_apply(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,

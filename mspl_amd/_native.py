@@ -83,6 +83,9 @@ SIGNATURES = {
     'mspl_conv_bwd_data': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_conv_bwd_weight': [c_f32p, c_f32p] + [c_i32] * 10 + [c_f32p, ctypes.c_void_p],
     'mspl_affine_prelu_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p] * 5 + [ctypes.c_void_p],
+    'mspl_bn_train_small_fits': [c_i32] * 3,
+    'mspl_bn_train_small_fwd': [c_f32p] * 5 + [c_i32] * 3 + [ctypes.c_float] * 2 + [c_f32p] * 2 + [ctypes.c_void_p] + [c_f32p] * 5 + [ctypes.c_void_p],
+    'mspl_bn_train_small_bwd': [c_f32p] * 9 + [c_i32] * 4 + [c_f32p] * 5 + [ctypes.c_void_p],
     'mspl_bn_train_prelu_bwd_apply': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p, ctypes.c_void_p],
     'mspl_pyrpool_merge_fwd': [c_f32p] + [c_i32] * 5 + [c_f32p] * 5 + [ctypes.c_void_p],
     'mspl_bn_stats_path_add': [c_f32p] * 4 + [c_i32] * 4 + [ctypes.c_void_p],

@@ -1093,9 +1093,17 @@ class BNTrainPReLUFn(torch.autograd.Function):
         hw = z[0, 0].numel()
         st = torch.empty(4, C, dtype=torch.float32, device=z.device)       # mean, invstd, scale, shift
         gamma_c, beta_c = _c(gamma), _c(beta)
-        check(lib.mspl_bn_batch_stats_fused_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma_c),
-                                                _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(nbt), _stream()))
-        y = ops.pointwise(z, Epi(st[2], st[3], alpha, residual=residual))
+        ctx.small = _SMALL_BN and bool(lib.mspl_bn_train_small_fits(N, C, hw))
+        if ctx.small:
+            # small planes: the channel's whole node in one workgroup, one launch (statistics + fold + apply)
+            y = torch.empty_like(z)
+            check(lib.mspl_bn_train_small_fwd(_p(z), _p(residual), _p(gamma_c), _p(beta_c), _p(None if alpha is None else _c(alpha)), N, C, hw,
+                                              eps, momentum, _p(running_mean), _p(running_var), _p(nbt), _p(st[0]), _p(st[1]), _p(st[2]),
+                                              _p(st[3]), _p(y), _stream()))
+        else:
+            check(lib.mspl_bn_batch_stats_fused_fwd(_p(z), N, C, hw, eps, momentum, _p(running_mean), _p(running_var), _p(gamma_c),
+                                                    _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(nbt), _stream()))
+            y = ops.pointwise(z, Epi(st[2], st[3], alpha, residual=residual))
         ctx.save_for_backward(z, gamma_c, alpha, residual, st, ws)
         ctx.sinks = (_sink(gamma), _sink(beta), _sink(alpha))
         return y
@@ -1109,6 +1117,18 @@ class BNTrainPReLUFn(torch.autograd.Function):
         hw = z[0, 0].numel()
         s_g, s_b, s_a = ctx.sinks
         gres = torch.empty_like(z) if residual is not None else None
+        if ctx.small:
+            gal = None
+            if alpha is not None:
+                gal = s_a if s_a is not None else torch.zeros(C, device=z.device)
+            direct = s_g is not None and s_b is not None
+            out = torch.empty(2, C, dtype=torch.float32, device=z.device)
+            gz = torch.empty_like(z)
+            check(lib.mspl_bn_train_small_bwd(_p(z), _p(residual), _p(gy), _p(scale), _p(shift), _p(alpha), _p(gamma), _p(mean), _p(invstd),
+                                              N, C, hw, 1 if direct else 0, _p(gz), _p(gres), _p(s_g if direct else out[0]),
+                                              _p(s_b if direct else out[1]), _p(gal), _stream()))
+            return (gz, None if direct else out[0], None if direct else out[1],
+                    None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None, None)
         gc = torch.empty_like(z) if residual is not None else None       # no residual: the second pass recomputes it from (z, gy)
         gal = None
         if alpha is not None:
@@ -1126,6 +1146,9 @@ class BNTrainPReLUFn(torch.autograd.Function):
                                                     _p(gz), _stream()))
         return (gz, None if direct else out[0], None if direct else out[1],
                 None if (alpha is None or s_a is not None) else gal, gres, None, None, None, None, None, None)
+
+
+_SMALL_BN = os.environ.get('MSPL_BN_SMALL', '1') != '0'       # small planes: one launch per BatchNorm node and direction
 
 
 def _bn_workspace(bn, device):

@@ -224,6 +224,225 @@ __global__ __launch_bounds__(256) void bn_stats_path_add_kernel(float* __restric
     *gp = gv;
 }
 
+// ---- small planes (levels 3-5: N * HW <= ~40 k values per channel): the whole BatchNorm + PReLU node of a channel in ONE workgroup and
+// ONE launch each way.  Forward: shifted sums of the channel (fp32 per thread, double across the workgroup), mean / invstd / fold /
+// running statistics, then the apply pass over the same values (L2 hits); backward: the three channel sums, (d gamma, d beta, p, q),
+// then gz = p * z + q + direct gradient.  No atomics, no workspace, no second launch: at these sizes the two-launch forms are four
+// launch latencies for ~2 us of data movement each (45 of the supervised iteration's 70 BatchNorms).
+__device__ __forceinline__ double bn_block_sum(double v, double* part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();                                   // part may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void bn_train_small_fwd_kernel(const float* __restrict__ z, const float* __restrict__ res,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ alpha, int N, int C, int HW, float eps,
+                                                                 float momentum, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, long long* __restrict__ nbt,
+                                                                 float* __restrict__ mean, float* __restrict__ invstd,
+                                                                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ y) {
+    __shared__ double part[16];
+    __shared__ float fold[2];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const bool vec = (HW & 3) == 0;
+    const int L = vec ? (HW >> 2) : HW, total = N * L;
+    const int NT = blockDim.x;                  // 1024, or 256 for the smallest channels
+    const int step_n = NT / L, step_q = NT - step_n * L;
+    const float k = z[(size_t)c * HW];
+    float s1 = 0.f, s2 = 0.f;
+    {
+        int u = tid, n = u / L, q = u - n * L;
+        auto advance = [&]() { u += NT; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
+        if (vec) {
+            auto acc4 = [&](const float4& v) {
+                const float a = v.x - k, b = v.y - k, cc = v.z - k, d = v.w - k;
+                s1 += (a + b) + (cc + d);
+                s2 += (a * a + b * b) + (cc * cc + d * d);
+            };
+            while (u + 3 * NT < total) {
+                const float4* p0 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+                const float4* p1 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+                const float4* p2 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+                const float4* p3 = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW) + q;  advance();
+                const float4 v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+                acc4(v0); acc4(v1); acc4(v2); acc4(v3);
+            }
+            while (u < total) {
+                const float4 v = reinterpret_cast<const float4*>(z + ((size_t)n * C + c) * (size_t)HW)[q];
+                advance();
+                acc4(v);
+            }
+        } else {
+            while (u < total) {
+                const float a = z[((size_t)n * C + c) * (size_t)HW + q] - k;
+                advance();
+                s1 += a;
+                s2 += a * a;
+            }
+        }
+    }
+    const double t1 = bn_block_sum((double)s1, part), t2 = bn_block_sum((double)s2, part);
+    if (tid == 0) {
+        const double M = (double)N * (double)HW;
+        const double e1 = t1 / M, e2 = t2 / M;
+        const double mu = (double)k + e1;
+        double var = e2 - e1 * e1;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = mf;
+        invstd[c] = isf;
+        const float sc = gamma[c] * isf, sh = beta[c] + (-mf) * sc;
+        scale[c] = sc;
+        shift[c] = sh;
+        fold[0] = sc;  fold[1] = sh;
+        if (running_mean) {
+            const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+    __syncthreads();
+    const float sc = fold[0], sh = fold[1];
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[c] : 1.f;
+    auto one = [&](float zv, float rv) {
+        float v = fmaf(zv, sc, sh);
+        v += rv;
+        return (!act || v > 0.f) ? v : al * v;
+    };
+    int u = tid, n = u / L, q = u - n * L;
+    auto advance = [&]() { u += NT; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
+    if (vec) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (u < total) {
+            const size_t oa = ((size_t)n * C + c) * (size_t)HW + 4 * (size_t)q;
+            advance();
+            const bool hb = u < total;
+            const size_t ob = hb ? ((size_t)n * C + c) * (size_t)HW + 4 * (size_t)q : oa;
+            advance();
+            const float4 za = *reinterpret_cast<const float4*>(z + oa), zb = *reinterpret_cast<const float4*>(z + ob);
+            const float4 ra = res ? *reinterpret_cast<const float4*>(res + oa) : zero, rb = res ? *reinterpret_cast<const float4*>(res + ob) : zero;
+            *reinterpret_cast<float4*>(y + oa) = make_float4(one(za.x, ra.x), one(za.y, ra.y), one(za.z, ra.z), one(za.w, ra.w));
+            if (hb) *reinterpret_cast<float4*>(y + ob) = make_float4(one(zb.x, rb.x), one(zb.y, rb.y), one(zb.z, rb.z), one(zb.w, rb.w));
+        }
+    } else {
+        while (u < total) {
+            const size_t o = ((size_t)n * C + c) * (size_t)HW + q;
+            advance();
+            y[o] = one(z[o], res ? res[o] : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_train_small_bwd_kernel(const float* __restrict__ z, const float* __restrict__ res,
+                                                                 const float* __restrict__ gy, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, int N, int C, int HW, float inv_m,
+                                                                 int accumulate, float* __restrict__ gz, float* __restrict__ gres,
+                                                                 float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                                 float* __restrict__ galpha) {
+    __shared__ float part[3][16];
+    __shared__ float coef[2];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const bool vec = (HW & 3) == 0;
+    const int L = vec ? (HW >> 2) : HW, total = N * L;
+    const int NT = blockDim.x;                  // 1024, or 256 for the smallest channels
+    const int step_n = NT / L, step_q = NT - step_n * L;
+    const float sc = scale[c], sh = shift[c];
+    const bool act = alpha != nullptr;
+    const float al = act ? alpha[c] : 1.f;
+    float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
+    auto direct = [&](float zv, float rv, float g) {           // gradient of the pre-activation, as affine_prelu_bwd_kernel
+        const float u = zv * sc + sh + rv;
+        return (!act || u > 0.f) ? g : al * g;
+    };
+    auto sums = [&](float zv, float rv, float g) {
+        const float u = zv * sc + sh + rv;
+        const float gzv = (!act || u > 0.f) ? g : al * g;
+        if (act && u <= 0.f) s_alpha += g * u;
+        s_scale += gzv * zv;
+        s_shift += gzv;
+    };
+    {
+        int u = tid, n = u / L, q = u - n * L;
+        auto advance = [&]() { u += NT; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
+        if (vec) {
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            while (u < total) {
+                const size_t oa = ((size_t)n * C + c) * (size_t)HW + 4 * (size_t)q;
+                advance();
+                const bool hb = u < total;
+                const size_t ob = hb ? ((size_t)n * C + c) * (size_t)HW + 4 * (size_t)q : oa;
+                advance();
+                const float4 za = *reinterpret_cast<const float4*>(z + oa), ga = *reinterpret_cast<const float4*>(gy + oa);
+                const float4 zb = *reinterpret_cast<const float4*>(z + ob), gb = *reinterpret_cast<const float4*>(gy + ob);
+                const float4 ra = res ? *reinterpret_cast<const float4*>(res + oa) : zero, rb = res ? *reinterpret_cast<const float4*>(res + ob) : zero;
+                sums(za.x, ra.x, ga.x); sums(za.y, ra.y, ga.y); sums(za.z, ra.z, ga.z); sums(za.w, ra.w, ga.w);
+                if (hb) { sums(zb.x, rb.x, gb.x); sums(zb.y, rb.y, gb.y); sums(zb.z, rb.z, gb.z); sums(zb.w, rb.w, gb.w); }
+            }
+        } else {
+            while (u < total) {
+                const size_t o = ((size_t)n * C + c) * (size_t)HW + q;
+                advance();
+                sums(z[o], res ? res[o] : 0.f, gy[o]);
+            }
+        }
+    }
+    float v[3] = {s_scale, s_shift, s_alpha};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o, 64);
+        if ((tid & 63) == 0) part[i][tid >> 6] = v[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float dsc = 0.f, dsh = 0.f, dal = 0.f;
+        for (int w = 0; w < (NT >> 6); ++w) { dsc += part[0][w];  dsh += part[1][w];  dal += part[2][w]; }
+        const float is = invstd[c], mu = mean[c];
+        const float t = dsc + (-mu) * dsh;
+        ggamma[c] = accumulate ? ggamma[c] + t * is : t * is;
+        gbeta[c] = accumulate ? gbeta[c] + dsh : dsh;
+        if (galpha && act) galpha[c] += dal;
+        const float p = ((gamma[c] * t) * (is * is * is)) * (-inv_m);
+        coef[0] = p;
+        coef[1] = (dsh * sc) * (-inv_m) - p * mu;
+    }
+    __syncthreads();
+    const float pc = coef[0], qc = coef[1];
+    int u = tid, n = u / L, q = u - n * L;
+    auto advance = [&]() { u += NT; q += step_q; n += step_n; if (q >= L) { q -= L; ++n; } };
+    if (vec) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (u < total) {
+            const size_t oa = ((size_t)n * C + c) * (size_t)HW + 4 * (size_t)q;
+            advance();
+            const float4 za = *reinterpret_cast<const float4*>(z + oa), ga = *reinterpret_cast<const float4*>(gy + oa);
+            const float4 ra = res ? *reinterpret_cast<const float4*>(res + oa) : zero;
+            const float4 d = make_float4(direct(za.x, ra.x, ga.x), direct(za.y, ra.y, ga.y), direct(za.z, ra.z, ga.z), direct(za.w, ra.w, ga.w));
+            if (gres) *reinterpret_cast<float4*>(gres + oa) = d;
+            *reinterpret_cast<float4*>(gz + oa) = make_float4(fmaf(za.x, pc, qc) + d.x * sc, fmaf(za.y, pc, qc) + d.y * sc,
+                                                              fmaf(za.z, pc, qc) + d.z * sc, fmaf(za.w, pc, qc) + d.w * sc);
+        }
+    } else {
+        while (u < total) {
+            const size_t o = ((size_t)n * C + c) * (size_t)HW + q;
+            advance();
+            const float d = direct(z[o], res ? res[o] : 0.f, gy[o]);
+            if (gres) gres[o] = d;
+            gz[o] = fmaf(z[o], pc, qc) + d * sc;
+        }
+    }
+}
+
 // Second pass of the batch-statistics BatchNorm + PReLU backward without a residual: gz = p * z + q + gc with the direct gradient
 // gc = (u > 0 ? gy : alpha * gy) * scale, u = z * scale + shift, RECOMPUTED from (z, gy) instead of read back -- the first pass
 // (mspl_bn_train_prelu_bwd with gc = NULL) then only reads: five tensor passes per BatchNorm instead of six.  Same operations in the
@@ -354,6 +573,45 @@ extern "C" int mspl_bn_batch_stats_fold_fwd(const float* z, int32_t N, int32_t C
                                             double* ws, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MSPL_REQUIRE(gamma && beta && scale && shift, MSPL_ERR_NULL_POINTER, "bn_batch_stats_fold: null pointer");
     return bn_batch_stats_impl(z, N, C, HW, eps, momentum, running_mean, running_var, gamma, beta, ws, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int mspl_bn_train_small_fits(int32_t N, int32_t C, int32_t HW) {
+    return N > 0 && C > 0 && HW > 0 && (int64_t)N * HW <= 40960 && C <= 65535;
+}
+
+extern "C" int mspl_bn_train_small_fwd(const float* z, const float* residual, const float* gamma, const float* beta, const float* alpha,
+                                       int32_t N, int32_t C, int32_t HW, float eps, float momentum, float* running_mean,
+                                       float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale,
+                                       float* shift, float* y, void* stream) {
+    MSPL_REQUIRE(z && gamma && beta && mean && invstd && scale && shift && y, MSPL_ERR_NULL_POINTER, "bn_train_small_fwd: null pointer");
+    MSPL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), MSPL_ERR_NULL_POINTER,
+                 "bn_train_small_fwd: running_mean and running_var go together");
+    MSPL_REQUIRE(mspl_bn_train_small_fits(N, C, HW), MSPL_ERR_UNSUPPORTED, "bn_train_small_fwd: N=%d C=%d HW=%d is not a small-plane shape", N, C, HW);
+    MSPL_REQUIRE((HW & 3) != 0 || ((((uintptr_t)z) | ((uintptr_t)residual) | ((uintptr_t)y)) & 15) == 0, MSPL_ERR_BAD_SHAPE,
+                 "bn_train_small_fwd: operands must be 16-byte aligned");
+    const int nt_f = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(bn_train_small_fwd_kernel, dim3((unsigned)C), dim3(nt_f), 0, (hipStream_t)stream, z, residual, gamma, beta, alpha, N, C,
+                       HW, eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale,
+                       shift, y);
+    MSPL_CHECK_LAUNCH("bn_train_small_fwd");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_bn_train_small_bwd(const float* z, const float* residual, const float* gy, const float* scale, const float* shift,
+                                       const float* alpha, const float* gamma, const float* mean, const float* invstd, int32_t N, int32_t C,
+                                       int32_t HW, int32_t accumulate, float* gz, float* gres, float* ggamma, float* gbeta, float* galpha,
+                                       void* stream) {
+    MSPL_REQUIRE(z && gy && scale && shift && gamma && mean && invstd && gz && ggamma && gbeta, MSPL_ERR_NULL_POINTER,
+                 "bn_train_small_bwd: null pointer");
+    MSPL_REQUIRE((gres == nullptr) || residual, MSPL_ERR_NULL_POINTER, "bn_train_small_bwd: gres without residual");
+    MSPL_REQUIRE(mspl_bn_train_small_fits(N, C, HW), MSPL_ERR_UNSUPPORTED, "bn_train_small_bwd: N=%d C=%d HW=%d is not a small-plane shape", N, C, HW);
+    MSPL_REQUIRE((HW & 3) != 0 || ((((uintptr_t)z) | ((uintptr_t)residual) | ((uintptr_t)gy) | ((uintptr_t)gz) | ((uintptr_t)gres)) & 15) == 0,
+                 MSPL_ERR_BAD_SHAPE, "bn_train_small_bwd: operands must be 16-byte aligned");
+    const int nt_b = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(bn_train_small_bwd_kernel, dim3((unsigned)C), dim3(nt_b), 0, (hipStream_t)stream, z, residual, gy, scale, shift, alpha,
+                       gamma, mean, invstd, N, C, HW, (float)(1.0 / ((double)N * (double)HW)), accumulate, gz, gres, ggamma, gbeta, galpha);
+    MSPL_CHECK_LAUNCH("bn_train_small_bwd");
+    return MSPL_OK;
 }
 
 extern "C" int mspl_bn_train_prelu_bwd_apply(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,

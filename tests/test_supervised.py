@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import train as otrain
 from tests.cases import LR_CASES, SUPERVISED_CASE
@@ -87,6 +88,47 @@ def test_bn_batch_stats_kernel():
         torch.testing.assert_close(bn.running_mean, f(ref.running_mean), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(bn.running_var, f(ref.running_var), rtol=1e-5, atol=1e-6)
         assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shp,mean_off,with_res', [((16, 24, 18, 30), 0.5, True), ((2, 7, 5, 9), 3.0, False), ((16, 8, 36, 60), -2.0, True),
+                                                   ((4, 32, 64, 120), 1.0, True), ((3, 5, 9, 15), 0.0, True), ((16, 16, 72, 120), 0.3, False)])
+def test_bn_train_prelu_node(shp, mean_off, with_res):
+    """autograd.bn_train_prelu (PReLU(BatchNorm_train(z) + residual), the supervised loop's node) against torch in fp64: the one-launch
+    small-plane form (N * HW <= 40 960: the first, second, third and fifth shapes) and the two-launch form, with and without residual."""
+    from mspl_amd import autograd as ag
+    g = torch.Generator().manual_seed(6)
+    C = shp[1]
+    z = (torch.randn(shp, generator=g) * 1.3 + mean_off).cuda().requires_grad_()
+    res = torch.randn(shp, generator=g).cuda().requires_grad_() if with_res else None
+    al = (torch.rand(C, generator=g) * 0.3).cuda().requires_grad_()
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    ref = torch.nn.BatchNorm2d(C).cuda().double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        ref.load_state_dict(bn.state_dict())
+    gy = torch.randn(shp, generator=g).cuda()
+    with torch.enable_grad():
+        y = ag.bn_train_prelu(z, bn, al, res)
+        y.backward(gy)
+    z2 = z.detach().double().requires_grad_()
+    r2 = res.detach().double().requires_grad_() if with_res else None
+    a2 = al.detach().double().requires_grad_()
+    u = ref(z2) + (r2 if with_res else 0.0)
+    y2 = F.prelu(u, a2)
+    y2.backward(gy.double())
+    f = lambda t: t.float()
+    torch.testing.assert_close(y, f(y2), rtol=2e-5, atol=2e-5 * (1 + abs(mean_off)))
+    torch.testing.assert_close(z.grad, f(z2.grad), rtol=2e-4, atol=5e-5)
+    if with_res:
+        torch.testing.assert_close(res.grad, f(r2.grad), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(al.grad, f(a2.grad), rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(bn.weight.grad, f(ref.weight.grad), rtol=1e-4, atol=2e-3 + 2e-4 * abs(mean_off))
+    torch.testing.assert_close(bn.bias.grad, f(ref.bias.grad), rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(bn.running_mean, f(ref.running_mean), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, f(ref.running_var), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
 
 
 @pytest.mark.gpu
