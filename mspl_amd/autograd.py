@@ -700,8 +700,9 @@ class PyrBodyBNFn(torch.autograd.Function):
         check(lib.mspl_bn_train_prelu_bwd_apply(_p(mraw), _p(gy), _p(st2[2]), _p(st2[3]), _p(m_alpha), _p(out2[2]), _p(out2[3]), N, P,
                                                 h * w, _p(g_mraw), _stream()))
         # the merge convolution and merge_layer.0's direct path; raw (d scale, d shift) sums of merge_layer.0
-        raw0 = torch.zeros(2, C0, device=dev, dtype=torch.float32)
-        scratch2 = torch.zeros(2, P, device=dev, dtype=torch.float32)         # (merge_layer.2 is the identity here: sums not used)
+        zbuf = torch.zeros(2 * C0 + 2 * P, device=dev, dtype=torch.float32)   # one fill for both accumulators
+        raw0 = zbuf[:2 * C0].view(2, C0)
+        scratch2 = zbuf[2 * C0:].view(2, P)                                   # (merge_layer.2 is the identity here: sums not used)
         g_br_alpha = dst(psinks[2], (C0,))
         g_merge_w = dst(psinks[3], tuple(merge_w.shape))
         gt = torch.empty((nb, N, P, h, w), device=dev, dtype=torch.float32)
