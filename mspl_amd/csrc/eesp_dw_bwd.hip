@@ -5,6 +5,8 @@
 //   gx[n,c,iy,ix]   = sum_k sum_{ky,kx} w_k[c,ky,kx] * G_k[n,c,(iy + d_k - ky*d_k)/s, (ix + d_k - kx*d_k)/s]     (exact divisions only)
 //   gw_k[c,ky,kx]  += sum_{n,oy,ox}     G_k[n,c,oy,ox] * x[n,c, oy*s - d_k + ky*d_k, ox*s - d_k + kx*d_k]
 // Streaming, HBM/L2-bound: per input pixel 36 gathered reads that hit L1/L2 (each G element is used 9 times) and one write.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mspl {
@@ -49,6 +51,61 @@ __global__ __launch_bounds__(256) void eesp_dw_bwd_data_kernel(const float* __re
         }
     }
     gx[(size_t)plane * g.H * g.W + p] = acc;
+}
+
+// Stride 2 on even planes (the three DownSampler EESPs: the largest launches of this file): a thread owns a 2 x 2 quad of INPUT pixels.
+// Which taps reach an input pixel is then a matter of parity, known per quad position: with an odd dilation the even/even pixel takes
+// the centre tap only, even/odd and odd/even two taps, odd/odd four; with an even dilation all nine taps land on the even/even pixel.
+// 36 loads per quad instead of 36 masked loads per pixel (three quarters of them multiplied by zero), same taps in the same order
+// per pixel: bit-identical to eesp_dw_bwd_data_kernel.
+__global__ __launch_bounds__(256) void eesp_dw_bwd_data_s2_kernel(const float* __restrict__ gs, const float* __restrict__ w4, DwBwdG g,
+                                                                  float* __restrict__ gx) {
+    const int QW = g.W >> 1, QH = g.H >> 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= QH * QW) return;
+    const int plane = blockIdx.y;                         // img * n + c
+    const int c = plane % g.n;
+    const int qy = t / QW, qx = t - qy * QW;
+    const size_t opl = (size_t)g.Ho * g.Wo;
+    const size_t branch = (size_t)g.N * g.n * opl;
+    const float* gp = gs + (size_t)plane * opl;
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;     // input pixels (2qy, 2qx), (2qy, 2qx+1), (2qy+1, 2qx), (2qy+1, 2qx+1)
+    auto G = [&](const float* gk, int oy, int ox, float& m) {
+        m = (oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo) ? 1.f : 0.f;
+        return gk[(size_t)min(max(oy, 0), g.Ho - 1) * g.Wo + min(max(ox, 0), g.Wo - 1)];
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = g.dil[k];
+        const float* wk = w4 + ((size_t)k * g.n + c) * 9;
+        const float* gk = gp + (size_t)k * branch;
+        if (d & 1) {                                      // uniform
+            const int hp = (1 + d) >> 1, hm = (1 - d) / 2;        // output offsets of taps 0 and 2 for an odd input coordinate
+            float m[9];
+            const float v11 = G(gk, qy, qx, m[0]);
+            const float v10 = G(gk, qy, qx + hp, m[1]), v12 = G(gk, qy, qx + hm, m[2]);
+            const float v01 = G(gk, qy + hp, qx, m[3]), v21 = G(gk, qy + hm, qx, m[4]);
+            const float v00 = G(gk, qy + hp, qx + hp, m[5]), v02 = G(gk, qy + hp, qx + hm, m[6]);
+            const float v20 = G(gk, qy + hm, qx + hp, m[7]), v22 = G(gk, qy + hm, qx + hm, m[8]);
+            a00 = fmaf(wk[4] * m[0], v11, a00);
+            a01 = fmaf(wk[3] * m[1], v10, a01);  a01 = fmaf(wk[5] * m[2], v12, a01);
+            a10 = fmaf(wk[1] * m[3], v01, a10);  a10 = fmaf(wk[7] * m[4], v21, a10);
+            a11 = fmaf(wk[0] * m[5], v00, a11);  a11 = fmaf(wk[2] * m[6], v02, a11);
+            a11 = fmaf(wk[6] * m[7], v20, a11);  a11 = fmaf(wk[8] * m[8], v22, a11);
+        } else {
+            const int h = d >> 1;
+            float v[9], m[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = G(gk, qy + h * (1 - ky), qx + h * (1 - kx), m[ky * 3 + kx]);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a00 = fmaf(wk[i] * m[i], v[i], a00);
+        }
+    }
+    float* o = gx + (size_t)plane * g.H * g.W + (size_t)(2 * qy) * g.W + 2 * qx;
+    *reinterpret_cast<float2*>(o) = make_float2(a00, a01);
+    *reinterpret_cast<float2*>(o + g.W) = make_float2(a10, a11);
 }
 
 struct GwPtrs { float* p[4]; };
@@ -134,7 +191,12 @@ extern "C" int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4
     hipStream_t s = (hipStream_t)stream;
     if (gx) {
         MSPL_REQUIRE((int64_t)N * n <= 65535, MSPL_ERR_BAD_SHAPE, "eesp_dw_bwd: too many planes (%lld)", (long long)N * n);
-        hipLaunchKernelGGL(eesp_dw_bwd_data_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)(N * n)), dim3(256), 0, s, gs, w4, g, gx);
+        static const int s2_form = getenv("MSPL_DW_BWD_S2") ? atoi(getenv("MSPL_DW_BWD_S2")) : 1;
+        if (s2_form && stride == 2 && (H & 1) == 0 && (W & 1) == 0 && (((uintptr_t)gx) & 7) == 0)
+            hipLaunchKernelGGL(eesp_dw_bwd_data_s2_kernel, dim3((unsigned)ceil_div((H / 2) * (W / 2), 256), (unsigned)(N * n)), dim3(256), 0, s, gs,
+                               w4, g, gx);
+        else
+            hipLaunchKernelGGL(eesp_dw_bwd_data_kernel, dim3((unsigned)ceil_div(H * W, 256), (unsigned)(N * n)), dim3(256), 0, s, gs, w4, g, gx);
         MSPL_CHECK_LAUNCH("eesp_dw_bwd(data)");
     }
     if (gw) {

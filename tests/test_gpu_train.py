@@ -61,7 +61,8 @@ def test_conv_fn(cfg):
 
 
 @pytest.mark.parametrize('dil,stride,shape', [([1, 2, 3, 4], 1, (2, 8, 12, 20)), ([1, 1, 2, 3], 1, (1, 16, 9, 15)),
-                                              ([1, 2, 3, 4], 2, (2, 4, 16, 24)), ([1, 2, 3, 4], 2, (1, 8, 15, 21))])
+                                              ([1, 2, 3, 4], 2, (2, 4, 16, 24)), ([1, 2, 3, 4], 2, (1, 8, 15, 21)),
+                                              ([1, 1, 2, 3], 2, (2, 6, 10, 36)), ([1, 1, 1, 2], 2, (1, 3, 6, 4))])
 def test_eesp_dw_fn(dil, stride, shape):
     from mspl_amd import autograd as ag
     N, n, h, w = shape
