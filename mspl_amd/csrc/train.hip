@@ -155,7 +155,13 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_kernel(const float* __res
 template <int CG>
 __global__ __launch_bounds__(256) void g3x3_bwd_weight_strip_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                     ConvGeom g, int chunks, float* __restrict__ gw) {
-    const int chunk = blockIdx.x % chunks, co = blockIdx.x / chunks;
+    // The cout_g output channels of a group read the SAME input chunk: their workgroups are issued back to back on ONE XCD (workgroup b
+    // goes to XCD b % 8), so the chunk is fetched into that XCD's L2 once instead of cout_g times through the Infinity Cache (137 us for
+    // the 8-channel-group expansion: 4.6 TB/s of re-reads).
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int cog = qq % g.cout_g, pair = (qq / g.cout_g) * 8 + xcd;          // pair = (group, chunk)
+    if (pair >= g.G * chunks) return;
+    const int chunk = pair % chunks, co = (pair / chunks) * g.cout_g + cog;
     const int ci0 = (co / g.cout_g) * CG;
     const int XS = g.W >> 2, nstrip = g.H * XS;                     // Ho == H, Wo == W
     const int64_t total = (int64_t)g.N * nstrip;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_strip_kernel(const float*
 // output channels (the stem's 3 -> 32 stride-2 gradient loaded every tap 32 times: 424 M four-byte loads through L1, 197 us for
 // 87 MB of operands).  Per accumulator the positions arrive in the same order as above: same sums.
 template <int CG, int COB>
-__global__ __launch_bounds__(256) void g3x3_bwd_weight_cob_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void g3x3_bwd_weight_cob_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                   ConvGeom g, int chunks, float* __restrict__ gw) {
     const int chunk = blockIdx.x % chunks, co0 = (blockIdx.x / chunks) * COB;
     const int ci0 = (co0 / g.cout_g) * CG;
@@ -273,6 +279,86 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_cob_kernel(const float* _
         for (int c = 0; c < COB; ++c)
 #pragma unroll
             for (int t = 0; t < CG * 9; ++t) acc[c][t] = fmaf(gv[c], xv[t], acc[c][t]);
+    }
+    __shared__ float part[4][COB * CG * 9];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int t = 0; t < CG * 9; ++t) {
+            float v = acc[c][t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c * CG * 9 + t] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < COB * CG * 9)
+        atomicAdd(&gw[(size_t)co0 * CG * 9 + threadIdx.x],
+                  (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// Stride 2 / padding 1 on rows of whole 32-byte blocks (the stem, 3 -> 32 at 288x480): four adjacent output positions per thread.
+// Their 3x3 windows cover input columns 2*ox0 - 1 .. 2*ox0 + 7 of each input row: two aligned 16-byte loads and the left neighbour
+// instead of twelve 4-byte loads at a stride of two floats; COB output channels share them.  (The per-position form ran at two, then
+// three waves per SIMD with one exposed load round trip per position: 166 -> 135 us for 96 MB of operands.)
+template <int CG, int COB>
+__global__ __launch_bounds__(256, 3) void g3x3_bwd_weight_s2_strip_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                          ConvGeom g, int chunks, float* __restrict__ gw) {
+    const int cgb = g.cout_g / COB;                               // workgroups per (group, chunk) pair: issued back to back on one XCD
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int cog = qq % cgb, pair = (qq / cgb) * 8 + xcd;
+    if (pair >= g.G * chunks) return;
+    const int chunk = pair % chunks, co0 = (pair / chunks) * g.cout_g + cog * COB;
+    const int ci0 = (co0 / g.cout_g) * CG;
+    const int XS = g.Wo >> 2, nstrip = g.Ho * XS;
+    const int64_t total = (int64_t)g.N * nstrip;
+    const int64_t per = (total + chunks - 1) / chunks;
+    const int64_t i0 = chunk * per, i1 = min(total, i0 + per);
+    const size_t plane = (size_t)g.H * g.W, oplane = (size_t)g.Ho * g.Wo;
+    float acc[COB][CG * 9];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int t = 0; t < CG * 9; ++t) acc[c][t] = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int n = (int)(i / nstrip), sidx = (int)(i - (int64_t)n * nstrip);
+        const int oy = sidx / XS, ox0 = (sidx - oy * XS) * 4;
+        float gv[COB][4];
+#pragma unroll
+        for (int c = 0; c < COB; ++c) {
+            const float4 t4 = *reinterpret_cast<const float4*>(gy + ((size_t)n * g.Cout + co0 + c) * oplane + (size_t)oy * g.Wo + ox0);
+            gv[c][0] = t4.x; gv[c][1] = t4.y; gv[c][2] = t4.z; gv[c][3] = t4.w;
+        }
+        const float* xp = x + ((size_t)n * g.Cin + ci0) * plane + 2 * ox0;
+        const float ml = ox0 > 0 ? 1.f : 0.f;
+        const int lo = ox0 > 0 ? -1 : 0;
+#pragma unroll
+        for (int ci = 0; ci < CG; ++ci) {
+            float4 a[3], b[3];  float l[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy - 1 + ky;                                  // <= H - 1 (H even); -1 at the top
+                const float* row = xp + ci * plane + (size_t)max(iy, 0) * g.W;
+                a[ky] = *reinterpret_cast<const float4*>(row);
+                b[ky] = *reinterpret_cast<const float4*>(row + 4);
+                l[ky] = row[lo];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float rm = (2 * oy - 1 + ky >= 0) ? 1.f : 0.f;
+                const float w9[9] = {l[ky] * (ml * rm), a[ky].x * rm, a[ky].y * rm, a[ky].z * rm, a[ky].w * rm,
+                                     b[ky].x * rm, b[ky].y * rm, b[ky].z * rm, b[ky].w * rm};
+#pragma unroll
+                for (int c = 0; c < COB; ++c)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float v = acc[c][ci * 9 + ky * 3 + kx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v = fmaf(gv[c][j], w9[2 * j + kx], v);
+                        acc[c][ci * 9 + ky * 3 + kx] = v;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // one channel's nine loads in flight at a time (all 27 hoisted: 70+ spilled VGPRs)
+        }
     }
     __shared__ float part[4][COB * CG * 9];
 #pragma unroll
@@ -1089,6 +1175,17 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
         return MSPL_OK;
     }
+    static const int s2_strip = getenv("MSPL_G3X3_WGRAD_S2STRIP") ? atoi(getenv("MSPL_G3X3_WGRAD_S2STRIP")) : 1;
+    if (s2_strip && K == 3 && g.cin_g == 3 && g.cout_g % 4 == 0 && Cout >= 16 && g.stride == 2 && g.dil == 1 && g.pad == 1 && (g.W & 7) == 0 &&
+        (g.H & 1) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0) {
+        const int64_t strips = total / 4;
+        int chunks = 1;
+        while ((int64_t)(Cout / 2) * chunks < 2048 && strips / (chunks * 2) >= 512) chunks *= 2;
+        const int64_t pairs8 = ((int64_t)g.G * chunks + 7) & ~7ll;
+        hipLaunchKernelGGL((g3x3_bwd_weight_s2_strip_kernel<3, 2>), dim3((unsigned)(pairs8 * (g.cout_g / 2))), dim3(256), 0, s, gy, x, g, chunks, gw);
+        MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3 stride 2, few input channels, strips)");
+        return MSPL_OK;
+    }
     if (K == 3 && g.cin_g == 3 && g.cout_g % 4 == 0 && Cout >= 16) {       // the stem: four output channels per workgroup share the taps
         int chunks = 1;
         while ((int64_t)(Cout / 4) * chunks < 2048 && total / (chunks * 2) >= 2048) chunks *= 2;
@@ -1102,7 +1199,8 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         const int64_t strips = total / 4;
         int chunks = 1;
         while ((int64_t)Cout * chunks < 2048 && strips / (chunks * 2) >= 1024) chunks *= 2;
-        const dim3 grid((unsigned)(Cout * chunks)), blk(256);
+        const int64_t pairs8 = ((int64_t)g.G * chunks + 7) & ~7ll;                 // (group, chunk) pairs, padded to whole rounds of the 8 XCDs
+        const dim3 grid((unsigned)(pairs8 * g.cout_g)), blk(256);
         switch (g.cin_g) {
             case 1: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<1>, grid, blk, 0, s, gy, x, g, chunks, gw); break;
             case 2: hipLaunchKernelGGL(g3x3_bwd_weight_strip_kernel<2>, grid, blk, 0, s, gy, x, g, chunks, gw); break;

@@ -52,7 +52,9 @@ def check_op(gpu_fn, cpu_fn, tensors, atol=2e-4, rtol=2e-3):
                                  (1, 64, 256, 2, 36, 60, 1, 1),
                                  # 3x3 weight gradient, strip form (stride 1, rows of whole 16-byte strips): cin_g = 1, 8, 5, 4, 3, 2
                                  (2, 16, 16, 16, 12, 16, 3, 1), (1, 16, 8, 2, 9, 20, 3, 1), (2, 10, 4, 2, 6, 8, 3, 1), (1, 12, 6, 3, 7, 12, 3, 1),
-                                 (1, 6, 4, 2, 5, 4, 3, 1), (2, 8, 8, 4, 10, 24, 3, 1), (3, 32, 12, 4, 33, 68, 3, 1)])
+                                 (1, 6, 4, 2, 5, 4, 3, 1), (2, 8, 8, 4, 10, 24, 3, 1), (3, 32, 12, 4, 33, 68, 3, 1),
+                                 # the stem's form: stride 2, three input channels, rows of whole 32-byte blocks
+                                 (2, 3, 16, 1, 12, 16, 3, 2), (1, 3, 32, 1, 30, 40, 3, 2)])
 def test_conv_fn(cfg):
     from mspl_amd import autograd as ag
     N, ci, co, g, h, w, k, s = cfg
