@@ -320,7 +320,7 @@ def train_step_time(step, x, y, dev, iters=10, world=1, repeats=3):
     return {'value': round(BATCH * world / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters, 'repeats': repeats,
             'ms_per_step_min_max': [round(min(samples) * 1e3, 3), round(max(samples) * 1e3, 3)],
             'n_gpus': world, 'global_batch': BATCH * world,
-            'micro_batch_lanes': step.lanes,
+            'micro_batch_lanes': step.lanes, 'lane_overlap': getattr(step, 'lane_overlap', None),
             'workload': 'uest train step, ESPDNet-UE s=2.0 C=5, bs=16/GPU x 3 x 256 x 480 fp32, hipGraph replay (%d concurrent micro-batch graphs) + ' % step.lanes +
                         ('one flat-bucket gradient all-reduce (%d floats, RCCL) + ' % step.optimizer.flat_g.numel() if world > 1 else '') +
                         'Adam kernel',
