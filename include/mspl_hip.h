@@ -577,6 +577,13 @@ int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const f
                         const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
                         float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream);
 
+/* The same launch for br_after_cat in train() (batch statistics, the supervised loop): (scale, shift) = the batch fold, stat_p / stat_q
+ * (4n each) = the statistics-path coefficients of mspl_bn_train_prelu_bwd (which has already produced d gamma / d beta / d alpha): the
+ * suffix sum runs over gz = p * z + q + direct gradient; gx = dL/dx of K2's input, gw accumulated as above. */
+int mspl_eesp_bwd_fused_bnstat(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
+                               const float* scale, const float* shift, const float* alpha, const float* stat_p, const float* stat_q,
+                               int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw, void* stream);
+
 /* out = srcs[0] + ... + srcs[n-1] (1 <= n <= 8 equally shaped fp32 tensors of `count` elements, count % 4 == 0, 16-byte aligned; srcs
  * is a HOST array of device pointers): the gradient of a tensor with several consumers in one launch (autograd.FanOutFn). */
 int mspl_sum_n(const float* const* srcs, int32_t n, int64_t count, float* out, void* stream);

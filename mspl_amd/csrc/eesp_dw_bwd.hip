@@ -245,13 +245,19 @@ struct FbProj {
     float *gscale, *gshift, *galpha;                 // n each, accumulated
 };
 
+// Batch-statistics BatchNorm (the supervised loop): the statistics path of br_after_cat, gz += p * z + q per channel (the coefficients
+// come from mspl_bn_train_prelu_bwd's sums), joins the direct gradient before the suffix sum.  p null: frozen statistics, nothing added.
+struct FbStat {
+    const float *p, *q;                              // 4n each, or null
+};
+
 __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __restrict__ z, const float* __restrict__ gy,
                                                              const float* __restrict__ x, const float* __restrict__ w4,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ alpha, const float* __restrict__ bn_mean,
                                                              const float* __restrict__ bn_inv, FbGeom g, float* __restrict__ gx,
                                                              GwPtrs gw, float* __restrict__ gscale, float* __restrict__ gshift,
-                                                             float* __restrict__ galpha, FbProj pj) {
+                                                             float* __restrict__ galpha, FbProj pj, FbStat st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[4][15];
     int b = blockIdx.x;
@@ -273,6 +279,12 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
     for (int k = 0; k < 4; ++k) {
         const int ch = k * g.n + j;
         sc[k] = scale ? scale[ch] : 1.f;  sh[k] = shift ? shift[ch] : 0.f;  al[k] = act ? alpha[ch] : 1.f;
+    }
+    const bool stat = st.p != nullptr;
+    float pk[4] = {0.f, 0.f, 0.f, 0.f}, qk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (stat) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pk[k] = st.p[k * g.n + j];  qk[k] = st.q[k * g.n + j]; }
     }
     float s_sc[4] = {0.f, 0.f, 0.f, 0.f}, s_sh[4] = {0.f, 0.f, 0.f, 0.f}, s_al[4] = {0.f, 0.f, 0.f, 0.f};
     // ---- stage: G_k and x on the band + halo, zero outside the image
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
                 s_sc[k] += gz * zv[k];
                 s_sh[k] += gz;
             }
-            run += gz * sc[k];
+            run += stat ? fmaf(zv[k], pk[k], qk[k]) + gz * sc[k] : gz * sc[k];      // (same expression as mspl_bn_train_prelu_bwd_apply)
             gk[k] = run;
         }
         const int lt = (y - (y0 - FB_MAXD)) * WT + xx + FB_MAXD;
@@ -426,13 +438,15 @@ extern "C" int mspl_eesp_bwd_fused_fits(int32_t N, int32_t n, int32_t H, int32_t
     return fb_plan(N, n, H, W, dil, g) > 0 && (int64_t)N * n * g.bands < (1ll << 31);
 }
 
-extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
-                                   const float* scale, const float* shift, const float* alpha, const float* bn_mean,
-                                   const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
-                                   float* gscale, float* gshift, float* galpha, const float* proj_c, const float* proj_scale,
-                                   const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
-                                   float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream) {
+static int eesp_bwd_fused_launch(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
+                                 const float* scale, const float* shift, const float* alpha, const float* bn_mean,
+                                 const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
+                                 float* gscale, float* gshift, float* galpha, const float* proj_c, const float* proj_scale,
+                                 const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
+                                 float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, const float* stat_p, const float* stat_q,
+                                 void* stream) {
     MSPL_REQUIRE(z && gy && x && w4 && dil && gx && gw, MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: null pointer");
+    MSPL_REQUIRE((stat_p == nullptr) == (stat_q == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: statistics coefficients p / q must come together");
     MSPL_REQUIRE((proj_mean == nullptr) == (proj_inv == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: proj mean / inv must come together");
     MSPL_REQUIRE((bn_mean == nullptr) == (bn_inv == nullptr), MSPL_ERR_NULL_POINTER, "eesp_bwd_fused: mean / inv must come together");
     FbGeom g;
@@ -449,8 +463,30 @@ extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float*
     FbProj pj;
     pj.c = proj_c; pj.scale = proj_scale; pj.shift = proj_shift; pj.alpha = proj_alpha; pj.mean = proj_mean; pj.inv = proj_inv;
     pj.gscale = g_proj_scale; pj.gshift = g_proj_shift; pj.galpha = g_proj_alpha;
+    FbStat st;
+    st.p = stat_p; st.q = stat_q;
     hipLaunchKernelGGL(eesp_bwd_fused_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, z, gy, x, w4, scale, shift, alpha,
-                       bn_mean, bn_inv, g, gx, gp, gscale, gshift, galpha, pj);
+                       bn_mean, bn_inv, g, gx, gp, gscale, gshift, galpha, pj, st);
     MSPL_CHECK_LAUNCH("eesp_bwd_fused");
     return MSPL_OK;
+}
+
+extern "C" int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
+                                   const float* scale, const float* shift, const float* alpha, const float* bn_mean,
+                                   const float* bn_inv, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
+                                   float* gscale, float* gshift, float* galpha, const float* proj_c, const float* proj_scale,
+                                   const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
+                                   float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream) {
+    return eesp_bwd_fused_launch(z, gy, x, w4, dil, scale, shift, alpha, bn_mean, bn_inv, N, n, H, W, gx, gw, gscale, gshift, galpha, proj_c,
+                                 proj_scale, proj_shift, proj_alpha, proj_mean, proj_inv, g_proj_scale, g_proj_shift, g_proj_alpha, nullptr,
+                                 nullptr, stream);
+}
+
+extern "C" int mspl_eesp_bwd_fused_bnstat(const float* z, const float* gy, const float* x, const float* w4, const int32_t* dil,
+                                          const float* scale, const float* shift, const float* alpha, const float* stat_p,
+                                          const float* stat_q, int32_t N, int32_t n, int32_t H, int32_t W, float* gx, float* const* gw,
+                                          void* stream) {
+    MSPL_REQUIRE(stat_p && stat_q && scale && shift, MSPL_ERR_NULL_POINTER, "eesp_bwd_fused_bnstat: null pointer");
+    return eesp_bwd_fused_launch(z, gy, x, w4, dil, scale, shift, alpha, nullptr, nullptr, N, n, H, W, gx, gw, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_p, stat_q, stream);
 }

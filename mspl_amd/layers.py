@@ -195,6 +195,7 @@ def _bn_act(z, bn, alpha=None, pre_add=None, residual=None):
 
 
 _FUSED_TRAIN_FWD = os.environ.get('MSPL_TRAIN_FUSED_FWD', '1') != '0'
+_EESP_DW_BN = os.environ.get('MSPL_EESP_DW_BN', '1') != '0'    # EESP in train(): K2 + br_after_cat as one autograd node
 _CONV_SKIP = os.environ.get('MSPL_CONV_SKIP', '1') != '0'      # EESP in train(): projection + skip connection as one autograd node
 _FUSED_BN_TRAIN = os.environ.get('MSPL_FUSED_BN_TRAIN', '1') != '0'      # batch-statistics BN + PReLU as one autograd node
 _FUSED_DW_EXP = os.environ.get('MSPL_EESP_EXP', '1') != '0'   # inference: K2 + K3 of a stride-1 EESP block as one launch
@@ -445,8 +446,13 @@ class EESP(nn.Module):
             o1 = _bn_act(z1, pj.bn, pj.act.weight)
         else:
             o1 = self.proj_1x1(input)
-        cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
-        cat = self.br_after_cat(cat)
+        if (self.stride == 1 and br.bn.training and _EESP_DW_BN and o1.requires_grad
+                and ag.eesp_dw_bn_fits(o1.shape, self.dilations)):
+            # K2 + br_after_cat (batch statistics) as one node: its backward is two launches (autograd.EespDwBNFn)
+            cat = ag.eesp_dw_bn(o1, [m.conv.weight for m in self.spp_dw], self.dilations, br.bn, br.act.weight)
+        else:
+            cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
+            cat = self.br_after_cat(cat)
         if self.stride == 2 and self.downAvg:
             return _conv_bn_act(cat, exp.conv, exp.bn)
         return _conv_bn_act(cat, exp.conv, exp.bn, self.module_act.weight, residual=skip if has_res else None)

@@ -567,6 +567,45 @@ def test_fused_pyramid_batch_statistics_equals_node_per_op(cfg):
             close(a, b, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 7, 12, 20), (1, 128, 128, 9, 9, 15), (3, 256, 256, 9, 18, 30), (16, 64, 64, 9, 36, 60)])
+def test_eesp_block_batch_statistics_fused_k2_node(cfg):
+    """autograd.EespDwBNFn (K2 + br_after_cat in train(): BatchNorm sums launch + mspl_eesp_bwd_fused_bnstat) against the node-per-op
+    form of the same block: output, input gradient, every parameter gradient, BatchNorm buffers."""
+    from mspl_amd import layers
+    N, cin, cout, r_lim, h, w = cfg
+    m = layers.EESP(cin, cout, stride=1, r_lim=r_lim, down_method='esp')
+    m.load_state_dict(synth_state_dict(m.state_dict(), 43))
+    m = m.to(DEV).train()
+    x = rnd(N, cin, h, w, seed=3).to(DEV)
+    go = rnd(N, cout, h, w, seed=4).to(DEV)
+    start = {k: v.clone() for k, v in m.state_dict().items()}
+    res = {}
+    for fused in (False, True):
+        prev = layers._EESP_DW_BN
+        layers._EESP_DW_BN = fused
+        m.load_state_dict(start)
+        try:
+            xi = x.clone().requires_grad_(True)
+            for p in m.parameters():
+                p.grad = None
+            with torch.enable_grad():
+                y = m(xi)
+                y.backward(go)
+            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                          {k: v.clone() for k, v in m.named_buffers()})
+        finally:
+            layers._EESP_DW_BN = prev
+    close(res[True][0], res[False][0], atol=2e-5, rtol=1e-4)
+    close(res[True][1], res[False][1], atol=1e-4, rtol=2e-3)
+    for k in res[False][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 3e-3 * scale + 2e-5, (k, float((a - b).abs().max()), scale)
+    for k, b in res[False][3].items():
+        a = res[True][3][k]
+        assert torch.equal(a, b) if b.dtype == torch.int64 else bool(torch.allclose(a, b, rtol=1e-5, atol=1e-6)), k
+
+
 def test_fused_pyramid_training_with_gradient_sinks():
     """Inside grad_sinks() the fused node adds its parameter gradients straight into existing .grad buffers (the flat optimizer
     buffers of the train step): same values as the returned-gradient form, accumulated on top of what the buffers held."""
