@@ -577,6 +577,11 @@ int mspl_eesp_bwd_fused(const float* z, const float* gy, const float* x, const f
                         const float* proj_shift, const float* proj_alpha, const float* proj_mean, const float* proj_inv,
                         float* g_proj_scale, float* g_proj_shift, float* g_proj_alpha, void* stream);
 
+/* mspl_hff_bn_prelu_suffix_bwd for br_after_cat in train(): out_k = sum_{m >= k} (p z + q + direct gradient)_m, branch-major (4,N,n,HW);
+ * (scale, shift) = the batch fold, stat_p / stat_q from mspl_bn_train_prelu_bwd (which also produced the parameter gradients).  For the
+ * strided blocks and for shapes mspl_eesp_bwd_fused_bnstat does not cover; mspl_eesp_dw_bwd follows. */
+int mspl_hff_bn_stat_suffix_bwd(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                const float* stat_p, const float* stat_q, int32_t N, int32_t n, int32_t HW, float* out, void* stream);
 /* The same launch for br_after_cat in train() (batch statistics, the supervised loop): (scale, shift) = the batch fold, stat_p / stat_q
  * (4n each) = the statistics-path coefficients of mspl_bn_train_prelu_bwd (which has already produced d gamma / d beta / d alpha): the
  * suffix sum runs over gz = p * z + q + direct gradient; gx = dL/dx of K2's input, gw accumulated as above. */

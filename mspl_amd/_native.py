@@ -137,6 +137,7 @@ SIGNATURES = {
     'mspl_nid_hist_fwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_nid_hist_bwd': [c_f32p, c_f32p] + [c_i32] * 5 + [ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_eesp_bwd_fused_fits': [c_i32] * 4 + [ctypes.POINTER(c_i32)],
+    'mspl_hff_bn_stat_suffix_bwd': [c_f32p] * 7 + [c_i32] * 3 + [c_f32p, ctypes.c_void_p],
     'mspl_eesp_bwd_fused_bnstat': [c_f32p] * 4 + [ctypes.POINTER(c_i32)] + [c_f32p] * 5 + [c_i32] * 4 + [c_f32p, ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_void_p],
     'mspl_eesp_bwd_fused': [c_f32p] * 4 + [ctypes.POINTER(c_i32)] + [c_f32p] * 5 + [c_i32] * 4 + [c_f32p, ctypes.POINTER(ctypes.c_void_p)] +
                            [c_f32p] * 12 + [ctypes.c_void_p],

@@ -202,17 +202,17 @@ def conv_skip(x, w, groups):
 
 
 class EespDwBNFn(torch.autograd.Function):
-    """K2 (the four dilated depthwise 3x3 + HFF + cat) and br_after_cat in train() of a stride-1 EESP block as ONE node (the supervised
-    loop): forward = the K2 kernel + the BatchNorm node's forward (one launch on small planes); backward = the BatchNorm node's sums /
+    """K2 (the four dilated depthwise 3x3 + HFF + cat) and br_after_cat in train() of an EESP block as ONE node (the supervised
+    loop; the strided blocks and shapes the fused backward does not cover take mspl_hff_bn_stat_suffix_bwd + mspl_eesp_dw_bwd): forward = the K2 kernel + the BatchNorm node's forward (one launch on small planes); backward = the BatchNorm node's sums /
     coefficients launch (mspl_bn_train_prelu_bwd without outputs) + mspl_eesp_bwd_fused_bnstat, which applies p z + q + the direct
     gradient, the HFF suffix sum and both gradients of the four branches from LDS: two launches where the node-per-op form ran the
     BatchNorm backward (1-2), the suffix sum, the data and the weight gradient, and wrote / re-read the 4n-channel gradient twice."""
 
     @staticmethod
-    def forward(ctx, x, w0, w1, w2, w3, dil, gamma, beta, alpha, running_mean, running_var, eps, momentum, ws, nbt):
+    def forward(ctx, x, w0, w1, w2, w3, dil, stride, gamma, beta, alpha, running_mean, running_var, eps, momentum, ws, nbt):
         x = _c(x)
         w4 = torch.stack([w.reshape(-1, 3, 3) for w in (w0, w1, w2, w3)]).contiguous()
-        z = ops.eesp_dw_hff(x, w4, dil, 1)
+        z = ops.eesp_dw_hff(x, w4, dil, stride)
         N, C = z.shape[:2]
         hw = z[0, 0].numel()
         st = torch.empty(4, C, dtype=torch.float32, device=z.device)       # mean, invstd, scale, shift
@@ -226,14 +226,14 @@ class EespDwBNFn(torch.autograd.Function):
                                                     _p(beta_c), _p(ws), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), _p(nbt), _stream()))
             y = ops.pointwise(z, Epi(st[2], st[3], alpha_c))
         ctx.save_for_backward(x, w4, z, st, gamma_c, alpha_c, ws)
-        ctx.cfg = (tuple(dil), w0.shape)
+        ctx.cfg = (tuple(dil), w0.shape, stride)
         ctx.sinks = ([_sink(w) for w in (w0, w1, w2, w3)], (_sink(gamma), _sink(beta), _sink(alpha)))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w4, z, st, gamma, alpha, ws = ctx.saved_tensors
-        dil, wshape = ctx.cfg
+        dil, wshape, stride = ctx.cfg
         wsinks, (s_g, s_b, s_a) = ctx.sinks
         gy = _c(gy)
         N, n, H, W = x.shape
@@ -243,18 +243,27 @@ class EespDwBNFn(torch.autograd.Function):
         direct = s_g is not None and s_b is not None
         out = torch.empty(4, C, dtype=torch.float32, device=dev)
         gal = s_a if s_a is not None else torch.zeros(C, device=dev)
-        check(lib.mspl_bn_train_prelu_bwd(_p(z), None, _p(gy), _p(st[2]), _p(st[3]), _p(alpha), _p(gamma), _p(st[0]), _p(st[1]), N, C, H * W,
-                                          None, None, _p(ws), 1 if direct else 0, _p(s_g if direct else out[0]),
+        check(lib.mspl_bn_train_prelu_bwd(_p(z), None, _p(gy), _p(st[2]), _p(st[3]), _p(alpha), _p(gamma), _p(st[0]), _p(st[1]), N, C,
+                                          z.shape[2] * z.shape[3], None, None, _p(ws), 1 if direct else 0, _p(s_g if direct else out[0]),
                                           _p(s_b if direct else out[1]), _p(gal), _p(out[2]), _p(out[3]), _stream()))
         tmp = torch.zeros((4,) + tuple(wshape), device=dev, dtype=torch.float32) if any(t is None for t in wsinks) else None
         dst = [wsinks[k] if wsinks[k] is not None else tmp[k] for k in range(4)]
         ptrs = (ctypes.c_void_p * 4)(*[d.data_ptr() for d in dst])
         dil_c = (ctypes.c_int32 * 4)(*dil)
         gx = torch.empty_like(x)
-        check(lib.mspl_eesp_bwd_fused_bnstat(_p(z), _p(gy), _p(x), _p(w4), dil_c, _p(st[2]), _p(st[3]), _p(alpha), _p(out[2]), _p(out[3]),
-                                             N, n, H, W, _p(gx), ptrs, _stream()))
+        if stride == 1 and _FUSED_EESP_BWD and lib.mspl_eesp_bwd_fused_fits(N, n, H, W, dil_c):
+            check(lib.mspl_eesp_bwd_fused_bnstat(_p(z), _p(gy), _p(x), _p(w4), dil_c, _p(st[2]), _p(st[3]), _p(alpha), _p(out[2]), _p(out[3]),
+                                                 N, n, H, W, _p(gx), ptrs, _stream()))
+        else:
+            # strided blocks / shapes the one-launch form does not cover: statistics path + direct gradient + suffix sum in one pass,
+            # then the two gradient kernels of the four branches
+            Ho, Wo = z.shape[2:]
+            gs = torch.empty((4, N, n, Ho, Wo), device=dev, dtype=torch.float32)
+            check(lib.mspl_hff_bn_stat_suffix_bwd(_p(z), _p(gy), _p(st[2]), _p(st[3]), _p(alpha), _p(out[2]), _p(out[3]), N, n, Ho * Wo,
+                                                  _p(gs), _stream()))
+            check(lib.mspl_eesp_dw_bwd(_p(gs), _p(x), _p(w4), dil_c, stride, N, n, H, W, _p(gx), ptrs, _stream()))
         gws = [None if wsinks[k] is not None else tmp[k] for k in range(4)]
-        return (gx, *gws, None, None if direct else out[0], None if direct else out[1], None if s_a is not None else gal,
+        return (gx, *gws, None, None, None if direct else out[0], None if direct else out[1], None if s_a is not None else gal,
                 None, None, None, None, None, None)
 
 
@@ -264,12 +273,12 @@ def eesp_dw_bn_fits(shape, dil):
     return bool(_FUSED_EESP_BWD and lib.mspl_eesp_bwd_fused_fits(N, n, H, W, (ctypes.c_int32 * 4)(*dil)))
 
 
-def eesp_dw_bn(x, ws, dil, bn, alpha):
+def eesp_dw_bn(x, ws, dil, bn, alpha, stride=1):
     """PReLU(BatchNorm_train(K2(x))) for br_after_cat in train(): see EespDwBNFn."""
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
-    return EespDwBNFn.apply(x, ws[0], ws[1], ws[2], ws[3], tuple(dil), bn.weight, bn.bias, alpha, bn.running_mean, bn.running_var,
+    return EespDwBNFn.apply(x, ws[0], ws[1], ws[2], ws[3], tuple(dil), int(stride), bn.weight, bn.bias, alpha, bn.running_mean, bn.running_var,
                             float(bn.eps), float(bn.momentum), _bn_workspace(bn, x.device), bn.num_batches_tracked)
 
 

@@ -1038,7 +1038,10 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
                                                                   const float* __restrict__ alpha, const float* __restrict__ bn_mean,
                                                                   const float* __restrict__ bn_inv, int n, int HW, int chunks,
                                                                   int64_t total, float* __restrict__ out, float* __restrict__ gscale,
-                                                                  float* __restrict__ gshift, float* __restrict__ galpha) {
+                                                                  float* __restrict__ gshift, float* __restrict__ galpha,
+                                                                  const float* __restrict__ stat_p, const float* __restrict__ stat_q) {
+    // stat_p / stat_q (4n each, or null): br_after_cat in train(): the statistics path p * z + q joins the direct gradient before the
+    // suffix sum (mspl_hff_bn_stat_suffix_bwd; the channel sums were taken by mspl_bn_train_prelu_bwd, gscale / gshift / galpha null)
     const int tix = (int)threadIdx.x, tstep = 256;
     int b = (int)blockIdx.x;
     const int chunk = b % chunks;  b /= chunks;
@@ -1052,6 +1055,12 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
         sc[k] = scale ? scale[ch] : 1.f;  sh[k] = shift ? shift[ch] : 0.f;  al[k] = act ? alpha[ch] : 1.f;
         s_sc[k] = s_sh[k] = s_al[k] = 0.f;
     }
+    const bool stat = stat_p != nullptr;
+    float pk[4] = {0.f, 0.f, 0.f, 0.f}, qk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (stat) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pk[k] = stat_p[k * n + j];  qk[k] = stat_q[k * n + j]; }
+    }
     const size_t in0 = ((size_t)img * 4 * n + j) * (size_t)HW, kin = (size_t)n * HW;
     const size_t out0 = ((size_t)img * n + j) * (size_t)HW;
     auto one = [&](int k, float zv, float g) {
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
         if (!pos) s_al[k] += g * u;
         s_sc[k] += gz * zv;
         s_sh[k] += gz;
-        return gz * sc[k];
+        return stat ? fmaf(zv, pk[k], qk[k]) + gz * sc[k] : gz * sc[k];
     };
     if ((HW & 3) == 0) {
         const int q4 = HW >> 2, per = (q4 + chunks - 1) / chunks;
@@ -1666,7 +1675,24 @@ extern "C" int mspl_hff_bn_prelu_suffix_bwd(const float* z, const float* gy, con
     const int64_t blocks = (int64_t)N * n * chunks;
     MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "hff_bn_prelu_suffix_bwd: grid too large");
     hipLaunchKernelGGL(hff_bn_prelu_suffix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, scale, shift, alpha,
-                       bn_mean, bn_inv, n, HW, chunks, total, out, gscale, gshift, galpha);
+                       bn_mean, bn_inv, n, HW, chunks, total, out, gscale, gshift, galpha, (const float*)nullptr, (const float*)nullptr);
     MSPL_CHECK_LAUNCH("hff_bn_prelu_suffix_bwd");
+    return MSPL_OK;
+}
+
+extern "C" int mspl_hff_bn_stat_suffix_bwd(const float* z, const float* gy, const float* scale, const float* shift, const float* alpha,
+                                           const float* stat_p, const float* stat_q, int32_t N, int32_t n, int32_t HW, float* out,
+                                           void* stream) {
+    MSPL_REQUIRE(z && gy && out && scale && shift && stat_p && stat_q, MSPL_ERR_NULL_POINTER, "hff_bn_stat_suffix_bwd: null pointer");
+    MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_bn_stat_suffix_bwd: bad shape");
+    const int64_t total = (int64_t)N * n * HW;
+    int chunks = 1;
+    while ((int64_t)N * n * chunks < 2048 && HW / (chunks * 2) >= 1024) chunks *= 2;
+    const int64_t blocks = (int64_t)N * n * chunks;
+    MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "hff_bn_stat_suffix_bwd: grid too large");
+    hipLaunchKernelGGL(hff_bn_prelu_suffix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, gy, scale, shift, alpha,
+                       (const float*)nullptr, (const float*)nullptr, n, HW, chunks, total, out, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, stat_p, stat_q);
+    MSPL_CHECK_LAUNCH("hff_bn_stat_suffix_bwd");
     return MSPL_OK;
 }

@@ -446,10 +446,10 @@ class EESP(nn.Module):
             o1 = _bn_act(z1, pj.bn, pj.act.weight)
         else:
             o1 = self.proj_1x1(input)
-        if (self.stride == 1 and br.bn.training and _EESP_DW_BN and o1.requires_grad
-                and ag.eesp_dw_bn_fits(o1.shape, self.dilations)):
-            # K2 + br_after_cat (batch statistics) as one node: its backward is two launches (autograd.EespDwBNFn)
-            cat = ag.eesp_dw_bn(o1, [m.conv.weight for m in self.spp_dw], self.dilations, br.bn, br.act.weight)
+        if br.bn.training and _EESP_DW_BN and o1.requires_grad:
+            # K2 + br_after_cat (batch statistics) as one node: its backward is two launches for the stride-1 blocks, three otherwise
+            # (autograd.EespDwBNFn)
+            cat = ag.eesp_dw_bn(o1, [m.conv.weight for m in self.spp_dw], self.dilations, br.bn, br.act.weight, self.stride)
         else:
             cat = ag.eesp_dw(o1, [m.conv.weight for m in self.spp_dw], self.dilations, self.stride)
             cat = self.br_after_cat(cat)

@@ -567,17 +567,18 @@ def test_fused_pyramid_batch_statistics_equals_node_per_op(cfg):
             close(a, b, atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize('cfg', [(2, 64, 64, 7, 12, 20), (1, 128, 128, 9, 9, 15), (3, 256, 256, 9, 18, 30), (16, 64, 64, 9, 36, 60)])
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 7, 12, 20, 1), (1, 128, 128, 9, 9, 15, 1), (3, 256, 256, 9, 18, 30, 1), (16, 64, 64, 9, 36, 60, 1),
+                                 (2, 32, 96, 13, 16, 24, 2), (1, 64, 64, 9, 15, 21, 2), (1, 16, 16, 9, 40, 300, 1)])
 def test_eesp_block_batch_statistics_fused_k2_node(cfg):
     """autograd.EespDwBNFn (K2 + br_after_cat in train(): BatchNorm sums launch + mspl_eesp_bwd_fused_bnstat) against the node-per-op
     form of the same block: output, input gradient, every parameter gradient, BatchNorm buffers."""
     from mspl_amd import layers
-    N, cin, cout, r_lim, h, w = cfg
-    m = layers.EESP(cin, cout, stride=1, r_lim=r_lim, down_method='esp')
+    N, cin, cout, r_lim, h, w, stride = cfg
+    m = layers.EESP(cin, cout, stride=stride, r_lim=r_lim, down_method='avg' if stride == 2 else 'esp')
     m.load_state_dict(synth_state_dict(m.state_dict(), 43))
     m = m.to(DEV).train()
     x = rnd(N, cin, h, w, seed=3).to(DEV)
-    go = rnd(N, cout, h, w, seed=4).to(DEV)
+    go = rnd(N, cout, (h - 1) // stride + 1, (w - 1) // stride + 1, seed=4).to(DEV)
     start = {k: v.clone() for k, v in m.state_dict().items()}
     res = {}
     for fused in (False, True):
@@ -591,7 +592,7 @@ def test_eesp_block_batch_statistics_fused_k2_node(cfg):
             with torch.enable_grad():
                 y = m(xi)
                 y.backward(go)
-            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+            res[fused] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
                           {k: v.clone() for k, v in m.named_buffers()})
         finally:
             layers._EESP_DW_BN = prev
