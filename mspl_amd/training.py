@@ -111,6 +111,25 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
     return loss.detach(), optimizer
 
 
+SETTLE_THRESHOLD = 0.55      # four lanes overlapping take 0.44-0.45 of the same graphs back to back; two lanes sharing a queue ~0.7
+
+
+def settle_seating(serial_ms, first_ms, measure, new_candidate, attempts=3, threshold=SETTLE_THRESHOLD):
+    """Decision logic of `GraphedTrainStep._settle_streams`, free of GPU calls.  `first_ms` is the time of all lanes on seating 0,
+    `serial_ms` of the same graphs back to back on one stream; `new_candidate()` makes another seating and returns its index,
+    `measure(index)` times it.  Returns {'seating', 'lanes_ms', 'settled', 'attempts'}: the first seating under `threshold` x serial,
+    else -- after `attempts` candidates -- the fastest one seen with settled = False (the caller warns and reports it)."""
+    best_ms, best = first_ms, 0
+    used = 0
+    while best_ms > threshold * serial_ms and used < attempts:
+        k = new_candidate()
+        used += 1
+        ms = measure(k)
+        if ms < best_ms:
+            best_ms, best = ms, k
+    return {'seating': best, 'lanes_ms': best_ms, 'settled': bool(best_ms <= threshold * serial_ms), 'attempts': used}
+
+
 class GraphedTrainStep:
     """train_step with zero_grad + forward + loss + backward replayed as hipGraphs (the step is ~1400 launches of 5-100 us; eager
     issue from Python is slower than the GPU executes them).  The gradient all-reduce and the Adam kernel stay outside the graphs,
@@ -184,8 +203,11 @@ class GraphedTrainStep:
                 raise RuntimeError('GraphedTrainStep(lanes=%d): %d parameter gradients went through AccumulateGrad instead of an '
                                    'atomic gradient sink; concurrent lanes would race on them' % (self.lanes, len(stray)))
         if self.lanes > 1:
+            # the capture did not execute: the lanes read this step's transposed weights and BatchNorm folds from self.graph's pool,
+            # so it runs once before the lanes are timed (they would otherwise run on uninitialised memory)
+            self.graph.replay()
             self._settle_streams()
-        self._finish()      # the capture did not execute: run the step it recorded
+        self._finish()      # run the step the capture recorded
 
     def _lanes_ms(self, streams, reps=2):
         """Wall time of one replay of every lane graph, lane i on streams[i % len(streams)] (the gradients they add up are thrown away by
@@ -211,20 +233,26 @@ class GraphedTrainStep:
         """The lanes must really overlap: measured on the captured graphs themselves.  `_concurrent_streams` picks streams with a spin
         kernel, and that has been seen to let two lanes share a hardware queue now and then (a 4-lane step of 10.6-11 ms instead of
         6.7: twice in ~25 processes) -- a replay may run on any stream, so the lanes are re-seated until all lanes together take
-        clearly less than the same graphs back to back on one stream; the best seating seen is kept."""
+        clearly less than the same graphs back to back on one stream; the best seating seen is kept (`settle_seating` is the decision,
+        a pure function of the timings: tests/test_host.py drives it with injected ones).  The lanes are timed on REAL data: the
+        caller has replayed `self.graph` (zeroed gradients, this step's transposed weights and BatchNorm folds) before."""
         from .uest import _concurrent_streams
         self._lanes_ms(self.streams, 1)                                  # warm-up
         serial = self._lanes_ms(self.streams[:1])
-        best_ms, best_streams = self._lanes_ms(self.streams), self.streams
-        for _ in range(attempts):
-            if best_ms <= 0.55 * serial:              # (four lanes overlapping: 0.44-0.45 of the serial time; two sharing a queue: ~0.7)
-                break
-            cand = _concurrent_streams(self.lanes, self.images.device)
-            ms = self._lanes_ms(cand)
-            if ms < best_ms:
-                best_ms, best_streams = ms, cand
-        self.streams = best_streams
-        self.lane_overlap = {'lanes_ms': round(best_ms, 3), 'serial_ms': round(serial, 3)}
+        pool = [self.streams]           # candidate stream sets: bounded, and the losers are dropped with this list
+
+        def candidate():
+            pool.append(_concurrent_streams(self.lanes, self.images.device))
+            return len(pool) - 1
+
+        d = settle_seating(serial, self._lanes_ms(self.streams), lambda k: self._lanes_ms(pool[k]), candidate, attempts)
+        self.streams = pool[d['seating']]
+        self.lane_overlap = {'lanes_ms': round(d['lanes_ms'], 3), 'serial_ms': round(serial, 3), 'settled': d['settled'],
+                             'attempts': d['attempts'], 'lanes': self.lanes}
+        if not d['settled']:
+            import warnings
+            warnings.warn('GraphedTrainStep(lanes=%d): the lane graphs did not overlap after %d re-seatings (%.2f ms against %.2f ms '
+                          'back to back); the step runs on the best seating seen' % (self.lanes, d['attempts'], d['lanes_ms'], serial))
 
     def _finish(self):
         self.graph.replay()

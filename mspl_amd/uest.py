@@ -354,8 +354,16 @@ class PipelinedLabelPass:
         self._lane_no = 0
         self._bufs = {}
 
+    def join(self):
+        """The current stream waits for everything queued on the lanes' streams (results consumed with on_lane=True are otherwise
+        ordered only against their own lane)."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
     @property
     def hist(self):
+        self.join()          # the lanes' launches add to their histograms on the lanes' streams
         total = self.lanes[0].hist.clone()
         for lane in self.lanes[1:]:
             total += lane.hist

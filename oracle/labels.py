@@ -106,6 +106,36 @@ def generate_pseudo_label(forward, loader, classes, save_pred_path, class_weight
     return image_paths, label_paths, depth_paths, maps, class_weights_from_histogram(class_array, class_weighting)
 
 
+def generate_pseudo_label_multi_model(forwards, os_data_list, loader, classes, save_pred_path, merge_label_policy=None,
+                                      class_weighting='normal', use_depth=False):
+    """uest_seg_multi_os.py:891-950, the multi-source relabelling loop, image by image: per source model get_output -> argmax
+    (:901-904) -> LUT (:907-912); merge_outputs with args.merge_label_policy (:916-917) -> class_array (:920-921) -> file-name rule and
+    path lists (:923-936) -> class weights (:940-947).  forwards: one callable per source model, image (1,3,H,W) -> (pred, pred_aux).
+    Same return value as generate_pseudo_label."""
+    image_paths, label_paths, depth_paths, maps = [], [], [], []
+    class_array = np.zeros(classes)
+    for batch in loader:
+        image, names = batch[0], batch[-2]
+        for k in range(image.shape[0]):
+            srcs = []
+            for forward, os_data in zip(forwards, os_data_list):
+                main, aux = forward(image[k:k + 1])
+                prob, _ = get_output(main, aux)
+                amax = np.asarray(np.argmax(prob[0].numpy().transpose(1, 2, 0), axis=2), dtype=np.uint8)
+                srcs.append(to_greenhouse(amax, os_data))
+            merged = merge_outputs(np.array(srcs), classes, merge_label_policy)
+            for i in range(classes):
+                class_array[i] += (merged == i).sum()
+            path_name = names[k]
+            image_name = path_name.split('/')[-1].rsplit('.', 1)[0]
+            maps.append(merged.astype(np.uint8))
+            image_paths.append(path_name)
+            label_paths.append('%s/%s.png' % (save_pred_path, image_name))
+            if use_depth:
+                depth_paths.append(path_name.replace('color', 'depth'))
+    return image_paths, label_paths, depth_paths, maps, class_weights_from_histogram(class_array, class_weighting)
+
+
 def uw_seg_loss(pred, target, u_weight, class_weights, ignore_idx=None):
     """UncertaintyWeightedSegmentationLoss.forward, loss_fns/segmentation_loss.py:155-175.
 

@@ -97,3 +97,15 @@ EVAL_CASES = {
     'eval_c5_ign4': (5, 'greenhouse', (2, 3, 64, 96), 3, 61, 600, 4, 62, False),      # the uest target model: class 4 = "other" ignored
     'eval_c13_ign255': (13, 'camvid', (3, 3, 48, 80), 2, 63, 610, 255, 64, True),     # CamVid-style: 255 = void
 }
+
+# the two label loops as whole functions (uest_seg_multi_os.py:730-830 generate_pseudo_label, :832-956
+# generate_pseudo_label_multi_model): name -> (models [(classes, dataset, os_data, sd seed)], image size (H, W), images, first input
+# seed, merge_label_policy, class_weighting).  Image names carry a directory and two dots, so the reference's file-name rule
+# (`name.split('/')[-1].rsplit('.', 1)[0]`, :803-805) is exercised.
+LABEL_LOOP_CASES = {
+    'self_c5': ([(5, 'greenhouse', None, 71)], (48, 64), 7, 700, None, 'normal'),
+    'self_c5_unweighted': ([(5, 'greenhouse', None, 72)], (32, 48), 3, 710, None, 'none'),
+    'multi3_all': ([(13, 'camvid', 'camvid', 61), (20, 'city', 'cityscapes', 62), (5, 'greenhouse', 'forest', 63)], (48, 64), 5, 720,
+                   'all', 'normal'),
+    'multi2_half': ([(13, 'camvid', 'camvid', 64), (5, 'greenhouse', 'forest', 65)], (32, 48), 4, 730, 'half', 'normal'),
+}

@@ -24,8 +24,8 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
-from tests.synth import grad_sample_index, synth_eval_batches, synth_image_u8, synth_input, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LABEL_LOOP_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
+from tests.synth import grad_sample_index, synth_adversarial_logits, synth_eval_batches, synth_image_u8, synth_input, synth_label_loop_images, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
 from nn_layers.eesp import EESP, DownSampler  # noqa: E402
@@ -423,7 +423,144 @@ def gen_eval():
     save('eval', **out)
 
 
+def gen_label_loops():
+    """The two relabelling loops as WHOLE functions -- generate_pseudo_label (uest_seg_multi_os.py:730-830) and
+    generate_pseudo_label_multi_model (:832-956) -- AST-extracted together with the script functions they call (get_output :669-693,
+    merge_outputs :695-718, update_image_list :720-728, ScoreUpdater :1257-) and run with the reference's own model class and
+    PixelwiseKLD on a stub dataset that serves seeded tensors (the real GreenhouseRGBDSegmentation needs image files and cv2).  What
+    is real: the loop, torch's DataLoader (batch size 1, string collation), PIL's PNG writer, the list writer, the class-weight rule.
+    Stored: the list file's lines (save path as {SAVE}), the DECODED label files, the class weights, and per pixel the smallest top-2
+    probability margin over the models (so a test knows where two fp32 forwards may legitimately disagree)."""
+    import tempfile
+    import time
+    import types
+    from collections import OrderedDict
+    import os.path as osp
+    from packaging import version
+    from PIL import Image
+    from torch.utils import data
+    from torch import nn
+
+    class Quiet(object):                       # tqdm(total=...) as a context manager and tqdm(iterable)
+        def __init__(self, it=None, total=None):
+            self.it = it
+        def __iter__(self):
+            return iter(self.it)
+        def __enter__(self):
+            return self
+        def __exit__(self, *exc):
+            return False
+        def close(self):
+            pass
+
+    class Log(object):
+        def info(self, *a):
+            pass
+
+    lns = {'np': np}
+    tree = ast.parse(open(os.path.join(REF, 'data_loader/segmentation/greenhouse.py')).read())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], 'id', '').startswith('id_'):
+            exec(compile(ast.Module([node], []), 'greenhouse', 'exec'), lns)
+    ns = {'np': np, 'torch': torch, 'nn': nn, 'data': data, 'version': version, 'time': time, 'osp': osp, 'Image': Image,
+          'tqdm': Quiet, 'OrderedDict': OrderedDict, 'PixelwiseKLD': PixelwiseKLD}
+    ns.update({k: v for k, v in lns.items() if k.startswith('id_')})
+    path = os.path.join(REF, 'uest_seg_multi_os.py')
+    extract_functions(path, {'get_output', 'merge_outputs', 'update_image_list', 'generate_pseudo_label',
+                             'generate_pseudo_label_multi_model'}, ns)
+    for node in ast.parse(open(path).read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == 'ScoreUpdater':
+            exec(compile(ast.Module([node], []), path, 'exec'), ns)
+    out, meta = {}, {}
+    real_mod = sys.modules.get('data_loader.segmentation.greenhouse')
+    for name, case in sorted(LABEL_LOOP_CASES.items()):
+        specs, (H, W), n, in_seed, policy, weighting = case
+        items = synth_label_loop_images(case)
+
+        class StubDataset(data.Dataset):      # train=False item of GreenhouseRGBDSegmentation without depth (greenhouse.py:270)
+            def __init__(self, **kw):
+                assert kw.get('train') is False and not kw.get('use_depth')
+            def __len__(self):
+                return len(items)
+            def __getitem__(self, i):
+                return items[i][0], torch.zeros(H, W, dtype=torch.int64), items[i][1], 1.0
+
+        stub = types.ModuleType('data_loader.segmentation.greenhouse')
+        stub.GreenhouseRGBDSegmentation = StubDataset
+        sys.modules['data_loader.segmentation.greenhouse'] = stub
+        ms = []
+        for C, ds, os_data, sd_seed in specs:
+            m = build_model('espdnetue', 2.0, C, ds).eval()
+            m.load_state_dict(synth_state_dict(m.state_dict(), sd_seed))
+            ms.append(m)
+        args = argparse.Namespace(classes=5, test_image_size='%d,%d' % (H, W), eval_scale=1.0, dataset='greenhouse',
+                                  data_tgt_train_list='unused.lst', use_traversable=False, use_depth=False, pin_memory=False,
+                                  eval_training=False, merge_label_policy=policy, class_weighting=weighting)
+        ns['args'] = args
+        save_path = tempfile.mkdtemp()
+        os.makedirs(os.path.join(save_path, 'pred'))
+        try:
+            with _cuda_means_here(), torch.no_grad():        # get_output's default device is the literal 'cuda' (:669)
+                if specs[0][2] is None:
+                    lst, cw = ns['generate_pseudo_label'](ms[0], 'cpu', save_path, 0, n, None, None, args, Log(), None, None)
+                else:
+                    lst, cw = ns['generate_pseudo_label_multi_model'](ms, [s[2] for s in specs], 'cpu', save_path, 0, n, None, None,
+                                                                       args, Log(), None, None)
+                margin = np.full((n, H, W), np.inf, dtype=np.float32)
+                for i, (x, _) in enumerate(items):
+                    for m in ms:
+                        prob, _ = ns['get_output'](m, x[None])
+                        top = np.sort(prob, axis=0)
+                        margin[i] = np.minimum(margin[i], top[-1] - top[-2])
+        finally:
+            if real_mod is None:
+                del sys.modules['data_loader.segmentation.greenhouse']
+            else:
+                sys.modules['data_loader.segmentation.greenhouse'] = real_mod
+        lines = open(lst).read().replace(save_path, '{SAVE}').splitlines()
+        maps = np.stack([np.asarray(Image.open(ln.split(',')[1].replace('{SAVE}', save_path))) for ln in lines])
+        assert maps.dtype == np.uint8 and maps.shape == (n, H, W) and osp.basename(lst) == 'tgt_train.lst'
+        out[name + '.maps'] = maps
+        out[name + '.margin'] = margin
+        out[name + '.class_weights'] = cw.numpy()
+        meta[name] = lines
+        print(name, 'weights', cw.numpy(), 'pixels with margin < 1e-4:', int((margin < 1e-4).sum()))
+    save('label_loops', **out)
+    with open(os.path.join(HERE, 'label_loops.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def gen_argmax_adversarial():
+    """The reference's label rule -- get_output (uest_seg_multi_os.py:669-693, AST-extracted, fed through a stub "model" that returns
+    the prepared heads) followed by np.argmax over the class axis (:797-798) -- on logits whose two largest entries are 0..4 ulp apart
+    (tests.synth.synth_adversarial_logits).  Stored: the reference's class per pixel and the probabilities it gave the two candidates."""
+    from collections import OrderedDict
+    from torch import nn
+    ns = {'np': np, 'torch': torch, 'nn': nn, 'OrderedDict': OrderedDict, 'PixelwiseKLD': PixelwiseKLD,
+          'args': argparse.Namespace(use_depth=False)}
+    extract_functions(os.path.join(REF, 'uest_seg_multi_os.py'), {'get_output'}, ns)
+    out = {}
+    for C in (5, 13, 20):
+        pred, aux, a, b, k = synth_adversarial_logits(C, C)
+        amax = np.zeros(a.shape, dtype=np.uint8)
+        pa = np.zeros(a.shape, dtype=np.float32)
+        pb = np.zeros(a.shape, dtype=np.float32)
+        with _cuda_means_here(), torch.no_grad():
+            for i in range(pred.shape[0]):
+                output, _ = ns['get_output'](lambda image, i=i: (pred[i:i + 1], aux[i:i + 1]), torch.zeros(1))
+                amax[i] = np.asarray(np.argmax(output.transpose(1, 2, 0), axis=2), dtype=np.uint8)
+                pa[i] = np.take_along_axis(output, a[i][None], 0)[0]
+                pb[i] = np.take_along_axis(output, b[i][None], 0)[0]
+        z = (pred + 0.5 * aux).numpy()
+        print('C=%d: reference class differs from argmax of the logits on %d of %d adversarial pixels; candidates tied in probability: %d'
+              % (C, int((amax != z.argmax(1)).sum()), amax.size, int((pa == pb).sum())))
+        out['C%d.amax' % C] = amax
+        out['C%d.pa' % C] = pa
+        out['C%d.pb' % C] = pb
+    save('argmax_adversarial', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio', 'supervised', 'nid', 'eval']
+    which = sys.argv[1:] or ['layers', 'models', 'zoo', 'labels', 'loss', 'train', 'aspp', 'rgbd', 'imageio', 'supervised', 'nid', 'eval', 'label_loops', 'argmax_adversarial']
     for w in which:
         globals()['gen_' + w]()

@@ -118,3 +118,48 @@ def grad_sample_index(numel):
     if idx[-1] != numel - 1:
         idx.append(numel - 1)
     return torch.tensor(idx, dtype=torch.int64)
+
+
+def synth_label_loop_images(case):
+    """The seeded target-domain images of a tests.cases.LABEL_LOOP_CASES entry: [(image (3,H,W), name)] -- shared by the golden
+    generator (which serves them to the reference's label loops through a stub dataset) and the tests."""
+    specs, (H, W), n, in_seed, policy, weighting = case
+    return [(synth_input((3, H, W), in_seed + i), '/data/greenhouse/color/seq.%d/frame_%03d.v2.jpg' % (i % 2, i)) for i in range(n)]
+
+
+def synth_adversarial_logits(C, seed, pixels=2048):
+    """(pred, aux) of shape (pixels/64, C, 8, 8) whose combined logits z = pred + 0.5 aux have their two LARGEST entries 0..4 ulp
+    apart at every pixel, over four magnitude bands (|z| ~ 0.02, 0.3, 2, 12) -- the inputs on which `np.argmax(softmax(z))`
+    (uest_seg_multi_os.py:687-691,798) and an argmax of z itself can differ: fp32 softmax may give both candidates the same
+    probability and the first maximum then picks the lower class id.  Returns (pred, aux, a, b, k): classes a != b hold the top two,
+    z[b] = z[a] advanced by k ulp (k may be negative).  aux is zero on even pixels and a coarse dyadic value on odd ones (0.5 aux is
+    exact either way; pred is chosen so that the SUM has the wanted spacing)."""
+    import numpy as np
+    rng = np.random.default_rng(4000 + seed)
+    n = pixels
+    scale = np.array([0.02, 0.3, 2.0, 12.0], dtype=np.float32)[rng.integers(0, 4, n)]
+    z = (rng.standard_normal((n, C)).astype(np.float32) * scale[:, None] * np.float32(0.5)).astype(np.float32)
+    a = rng.integers(0, C, n)
+    b = (a + rng.integers(1, C, n)) % C
+    k = rng.integers(-4, 5, n)
+    top = (np.abs(z).max(axis=1) + scale * rng.uniform(0.05, 1.0, n).astype(np.float32)).astype(np.float32)
+    zb = top.copy()
+    for step in range(1, 5):
+        up = k >= step
+        dn = k <= -step
+        zb[up] = np.nextafter(zb[up], np.float32(np.inf))
+        zb[dn] = np.nextafter(zb[dn], np.float32(-np.inf))
+    z[np.arange(n), a] = top
+    z[np.arange(n), b] = zb
+    aux = np.zeros((n, C), dtype=np.float32)
+    odd = np.arange(n) % 2 == 1
+    aux[odd] = (rng.integers(-8, 9, (int(odd.sum()), C)) * 0.25).astype(np.float32)
+    pred = (z - np.float32(0.5) * aux).astype(np.float32)
+    # the sum the networks' consumers form; where the subtraction above was inexact the spacing is re-imposed on the sum
+    zs = (pred + np.float32(0.5) * aux).astype(np.float32)
+    bad = (zs[np.arange(n), a] != top) | (zs[np.arange(n), b] != zb) | (np.argsort(zs, axis=1)[:, -1:] != np.where(k > 0, b, a)[:, None]).ravel() & (k != 0)
+    aux[bad] = 0.0
+    pred[bad] = z[bad]
+    shape = (n // 64, 8, 8, C)
+    to = lambda t: torch.from_numpy(np.ascontiguousarray(t.reshape(shape).transpose(0, 3, 1, 2)))
+    return to(pred), to(aux), a.reshape(shape[:3]), b.reshape(shape[:3]), k.reshape(shape[:3])

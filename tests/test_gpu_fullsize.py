@@ -158,6 +158,30 @@ def test_pipelined_label_pass_equals_single_lane(depth, group):
     assert torch.equal(plp.hist, ref.hist) and int(plp.hist.sum()) == 7 * 16 * 288 * 480
 
 
+def test_pipelined_histogram_without_a_writer():
+    """on_lane=True hands results back without making the current stream wait for the lane; nothing else (no LabelWriter, no
+    synchronize) orders the lanes before the histogram is read: PipelinedLabelPass.hist must join the lanes itself."""
+    import argparse
+    from mspl_amd import models, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 5))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(78)
+    batches = [torch.randn((16, 3, 256, 480), generator=g).cuda() for _ in range(6)]
+    plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=5, use_graph=True, with_kld=False), depth=3, group=2)
+    for rep in range(2):
+        plp.reset()
+        torch.cuda.synchronize()
+        for b in batches:
+            plp(b, on_lane=True)
+        for _ in plp.flush(on_lane=True):
+            pass
+        h = plp.hist                       # no synchronize, no writer in between
+        assert int(h.sum()) == 6 * 16 * 256 * 480
+
+
 def test_graphed_pass_follows_parameter_updates():
     """A captured pass bakes in pointers to the folded-BN / packed-weight caches and to the parameter storages.  The uest loop
     alternates label passes and train rounds on the SAME model: after a train step (FlatAdam re-points .data, the Adam kernel

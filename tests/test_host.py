@@ -339,3 +339,37 @@ def test_espdnet_state_dict_and_loaders(tmp_path):
     assert torch.equal(m1.state_dict()['depth_base_net.level1.conv.weight'], full['depth_base_net.level1.conv.weight'])
     assert not torch.equal(m1.state_dict()[k], full[k]) and torch.equal(m2.state_dict()[k], full[k])
     assert not torch.equal(m2.state_dict()['bu_br_l2.1.weight'], full['bu_br_l2.1.weight'])
+
+
+def test_settle_seating_decision_on_injected_timings():
+    """GraphedTrainStep._settle_streams' decision (mspl_amd/training.py: settle_seating) on injected timings: lanes that overlap at
+    once / only after a re-seating / never.  The replacement of DataParallel's implicit overlap (utilities/parallel_wrapper.py:17-45)
+    must say so when the lanes do not run side by side instead of silently taking 1.6x the time."""
+    from mspl_amd.training import SETTLE_THRESHOLD, settle_seating
+    serial = 15.0
+
+    def run(first, later, attempts=3):
+        made = []
+
+        def cand():
+            made.append(len(made) + 1)
+            return made[-1]
+
+        d = settle_seating(serial, first, lambda k: later[k - 1], cand, attempts)
+        return d, len(made)
+
+    # overlapped at once: no candidate is ever built
+    d, made = run(0.44 * serial, [])
+    assert d == {'seating': 0, 'lanes_ms': 0.44 * serial, 'settled': True, 'attempts': 0} and made == 0
+    # two lanes share a queue (0.7 of serial), the second candidate overlaps: stop there, do not build a third
+    d, made = run(0.70 * serial, [0.72 * serial, 0.45 * serial, 0.40 * serial])
+    assert d['seating'] == 2 and d['settled'] and d['attempts'] == 2 and made == 2 and d['lanes_ms'] == 0.45 * serial
+    # never settles: bounded number of candidates, the fastest seating seen is kept and the outcome says "not settled"
+    d, made = run(0.95 * serial, [0.9 * serial, 0.7 * serial, 0.8 * serial])
+    assert made == 3 and d['attempts'] == 3 and not d['settled'] and d['seating'] == 2 and d['lanes_ms'] == 0.7 * serial
+    # a slower candidate never replaces the first seating
+    d, made = run(0.6 * serial, [0.9 * serial] * 3)
+    assert d['seating'] == 0 and not d['settled']
+    # exactly at the threshold counts as settled
+    d, _ = run(SETTLE_THRESHOLD * serial, [])
+    assert d['settled']

@@ -386,3 +386,53 @@ def test_script_level_generate_pseudo_label_reference_signature(tmp_path, monkey
             ns['generate_pseudo_label'](m, 'cuda', save, 3, 5, None, None, args, Log(), None, None)
     finally:
         _purge_reference_names()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['self_c5', 'self_c5_unweighted', 'multi3_all', 'multi2_half'])
+def test_label_loop_functions_vs_reference_golden(tmp_path, name, golden):
+    """generate_pseudo_label / generate_pseudo_label_multi_model against the REFERENCE's own functions (uest_seg_multi_os.py:730-830,
+    :832-956, AST-extracted and run on CPU by tests/golden/make_golden.py gen_label_loops): list lines and order, decoded label files,
+    class weights.  Two fp32 forwards cannot agree on the argmax where the top-2 probabilities are within rounding of each other; the
+    golden carries the reference's top-2 margin per pixel, and every pixel whose margin exceeds 2e-3 (10x the logit tolerance) must
+    be IDENTICAL."""
+    import argparse
+    import json
+    from mspl_amd import models, uest
+    from tests.cases import LABEL_LOOP_CASES
+    from tests.conftest import GOLDEN
+    from tests.synth import synth_label_loop_images, synth_state_dict
+    g = golden('label_loops')
+    lines = json.load(open(os.path.join(GOLDEN, 'label_loops.json')))[name]
+    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name]
+    items = synth_label_loop_images(LABEL_LOOP_CASES[name])
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    ms = []
+    for C_, ds, os_data, seed in specs:
+        m = models.ESPDNetwithUncertaintyEstimation(a, classes=C_, dataset=ds, fix_pyr_plane_proj=True)
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed))
+        ms.append(m)
+    loader = [(torch.stack([x for x, _ in items[i:i + 2]]), None, [nm for _, nm in items[i:i + 2]], 1.0) for i in range(0, n, 2)]
+    if specs[0][2] is None:
+        lst, cw = uest.generate_pseudo_label(ms[0], loader, str(tmp_path), class_weighting=weighting, in_flight=2, batches_per_launch=2)
+    else:
+        lst, cw = uest.generate_pseudo_label_multi_model(ms, [s[2] for s in specs], loader, str(tmp_path), merge_label_policy=policy,
+                                                         class_weighting=weighting, in_flight=2)
+    got_lines = open(lst).read().replace(str(tmp_path), '{SAVE}').splitlines()
+    assert got_lines == lines
+    want, margin = g[name + '.maps'], g[name + '.margin']
+    got = np.stack([oio.png_decode_gray8(open(ln.split(',')[1].replace('{SAVE}', str(tmp_path)), 'rb').read()) for ln in got_lines])
+    assert got.shape == want.shape and got.dtype == np.uint8
+    sure = margin > 2e-3
+    assert sure.mean() > 0.9 and np.array_equal(got[sure], want[sure])
+    ndiff = int((got != want).sum())
+    assert ndiff <= int((~sure).sum())
+    ref_w = g[name + '.class_weights']
+    if ndiff == 0:
+        assert np.array_equal(cw.cpu().numpy(), ref_w)
+    else:       # counts differ by at most ndiff pixels per class
+        hist = np.array([(got == c).sum() for c in range(5)], dtype=np.float64)
+        from oracle import labels as olab
+        assert np.array_equal(cw.cpu().numpy(), olab.class_weights_from_histogram(hist, weighting).astype(np.float32))
+        big = ref_w < 1e9
+        assert np.allclose(cw.cpu().numpy()[big], ref_w[big], rtol=4.0 * ndiff / max(1.0, hist[big & (ref_w > 0)].min()) + 1e-6)

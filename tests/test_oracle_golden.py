@@ -12,9 +12,9 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, LABEL_LOOP_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
 from tests.conftest import GOLDEN
-from tests.synth import synth_eval_batches, synth_input, synth_labels, synth_state_dict
+from tests.synth import synth_adversarial_logits, synth_eval_batches, synth_input, synth_label_loop_images, synth_labels, synth_state_dict
 
 KEYS = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
 
@@ -216,3 +216,65 @@ def test_eval_step(name, golden):
     iou0, loss0 = olab.val_seg_ue(fwd, loader, cw, ign, C, aux_weight=0.0)
     np.testing.assert_allclose(iou0, g[name + '.test_iou'], rtol=0, atol=1e-6)
     assert abs(loss0 - float(g[name + '.test_loss'])) < 2e-5
+
+
+LOOP_LINES = json.load(open(os.path.join(GOLDEN, 'label_loops.json')))
+
+
+@pytest.mark.parametrize('name', sorted(LABEL_LOOP_CASES))
+def test_label_loops_vs_reference_functions(name, golden):
+    """oracle.labels.generate_pseudo_label / generate_pseudo_label_multi_model against the reference's own functions
+    (uest_seg_multi_os.py:730-830, :832-956; AST-extracted and run by tests/golden/make_golden.py gen_label_loops on a stub dataset):
+    the list file's lines and order (file-name rule), the label maps the reference wrote as PNG files, the class weights."""
+    g = golden('label_loops')
+    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name]
+    items = synth_label_loop_images(LABEL_LOOP_CASES[name])
+    # ragged batches on purpose: the reference's loader has batch size 1, the restatement walks a batch element by element
+    loader, i = [], 0
+    for bs in [2, 1, 3, 2, 2]:
+        if i < n:
+            part = items[i:i + bs]
+            loader.append((torch.stack([x for x, _ in part]), None, [nm for _, nm in part], 1.0))
+            i += len(part)
+    fwds = []
+    for C, ds, os_data, sd_seed in specs:
+        sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % C], sd_seed)
+        fwds.append(lambda x, sd=sd: onet.espdnet_ue_forward(sd, x))
+    with torch.no_grad():
+        if specs[0][2] is None:
+            ri, rl, rd, maps, cw = olab.generate_pseudo_label(fwds[0], loader, 5, '{SAVE}/pred', weighting)
+        else:
+            ri, rl, rd, maps, cw = olab.generate_pseudo_label_multi_model(fwds, [s[2] for s in specs], loader, 5, '{SAVE}/pred',
+                                                                          policy, weighting)
+    assert ['%s,%s' % (a, b) for a, b in zip(ri, rl)] == LOOP_LINES[name] and rd == []
+    want, margin = g[name + '.maps'], g[name + '.margin']
+    got = np.stack(maps)
+    assert got.dtype == np.uint8 and got.shape == want.shape
+    # the restatement and the reference module agree to ~1e-6 on the probabilities: away from exact ties the maps are IDENTICAL
+    assert np.array_equal(got[margin > 1e-5], want[margin > 1e-5])
+    ndiff = int((got != want).sum())
+    assert ndiff <= int((margin <= 1e-5).sum())
+    if ndiff == 0:
+        np.testing.assert_array_equal(cw.astype(np.float32), g[name + '.class_weights'])
+    # the integer / float64 stage alone, on the reference's own maps: exact
+    hist = np.array([(want == c).sum() for c in range(5)], dtype=np.float64)
+    np.testing.assert_array_equal(olab.class_weights_from_histogram(hist, weighting).astype(np.float32), g[name + '.class_weights'])
+
+
+@pytest.mark.parametrize('C', [5, 13, 20])
+def test_argmax_rule_on_adversarial_logits(C, golden):
+    """The oracle's label rule (softmax THEN first-max argmax, uest_seg_multi_os.py:687-691,798) on logits whose top two entries are
+    0..4 ulp apart, against the reference's own get_output + np.argmax on the same logits (gen_argmax_adversarial).  The restatement
+    runs the same torch softmax, so it reproduces the reference's choice wherever that choice does not hinge on the last bit of a
+    probability: allowed to differ only where the reference itself gave both candidates probabilities at most 1 ulp apart."""
+    g = golden('argmax_adversarial')
+    pred, aux, a, b, k = synth_adversarial_logits(C, C)
+    prob, _ = olab.get_output(pred, aux)
+    got = olab.argmax_labels(prob)
+    want, pa, pb = g['C%d.amax' % C], g['C%d.pa' % C], g['C%d.pb' % C]
+    assert np.all((got == a) | (got == b)) and np.all((want == a) | (want == b))
+    one_ulp = np.abs(pa - pb) <= np.spacing(np.maximum(pa, pb))
+    assert np.array_equal(got[~one_ulp], want[~one_ulp])
+    # the rule itself on the stored probabilities: larger probability wins, equal probabilities -> the LOWER class id
+    rule = np.where(pa > pb, a, np.where(pb > pa, b, np.minimum(a, b)))
+    assert np.array_equal(rule, want)
