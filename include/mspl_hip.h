@@ -72,6 +72,11 @@ typedef struct {
  * fewer, longer workgroups are preferred (another pass fills the ramp and tail) and the big-LDS fused K1+K2 launch is not used.
  * Per call, not per process: the library holds no mutable global state and is re-entrant (rounds 1-2 had a process-wide switch). */
 #define MSPL_LAUNCH_THROUGHPUT 1u
+/* Form of the stride-2 depthwise launch (mspl_eesp_dw_hff_fwd): by default the library picks between the register-streaming and
+ * the direct / LDS-tiled forms from the shape; OFF never takes the streaming form, FORCE takes it whenever the shape allows.  The
+ * forms are bit-identical (tests compare them through these flags; rounds 2-4 read an environment variable per call instead). */
+#define MSPL_LAUNCH_K2_STREAM_OFF 2u
+#define MSPL_LAUNCH_K2_STREAM_FORCE 4u
 
 const char* mspl_version(void);
 /* ABI revision of this library; it changes whenever a struct layout or a signature in this header does.  3 = this header. */

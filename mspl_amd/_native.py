@@ -14,7 +14,9 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmspl_hip.so')
+# (the probes under tools/ point MSPL_HIP_LIB at a `make TUNING=1` / `STAMPS=1` build, libmspl_hip_tuning.so; the product library
+# itself reads no environment variable)
+LIB_PATH = os.environ.get('MSPL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmspl_hip.so')
 
 c_f32p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -32,6 +34,8 @@ class Epilogue(ctypes.Structure):
 
 ABI_VERSION = 3                 # include/mspl_hip.h: mspl_abi_version()
 LAUNCH_THROUGHPUT = 1           # MSPL_LAUNCH_THROUGHPUT
+LAUNCH_K2_STREAM_OFF = 2        # MSPL_LAUNCH_K2_STREAM_OFF
+LAUNCH_K2_STREAM_FORCE = 4      # MSPL_LAUNCH_K2_STREAM_FORCE
 
 
 _EP = ctypes.POINTER(Epilogue)

@@ -41,6 +41,16 @@ void set_error(const char* fmt, ...);
 #define MSPL_STAMP_ENV(name) 0
 #endif
 
+// Tuning switches (tile shapes, forcing an alternative kernel form, stopping a kernel after a phase -- DESIGN.md "Tuning aids"): the
+// default build compiles every one of them to its default, so no environment variable can change which kernel a C caller gets
+// (include/mspl_hip.h: "no global mutable state").  `make TUNING=1` (-DMSPL_TUNING) brings the environment reads back for the
+// probes under tools/.  Launch-shape choices a CALLER may legitimately make travel in mspl_epilogue_t.flags (MSPL_LAUNCH_*).
+#ifdef MSPL_TUNING
+#define MSPL_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define MSPL_TUNE_INT(name, dflt) (dflt)
+#endif
+
 // Write-through (sc1) 16- and 8-byte stores for kernel OUTPUTS.  A plain store leaves its line dirty in the XCD's L2 and the
 // whole of a kernel's output is written back at the kernel boundary (+ bytes / 6 TB/s before the successor starts: 3 us behind
 // 17.7 MB, MI355X_MICROARCH.md "boundary" row; measured here: K2 at 36x60 15.6 -> 12.3 us).  With sc1 the bytes leave L2 while the
@@ -95,6 +105,7 @@ struct Epi {
     int coff;   // first destination channel of this op
     int hw;     // destination pixels per plane
     float* raw; // convolutions: also store the bare accumulator here (same shape as the destination, ctot == C), or null
+    unsigned flags;   // MSPL_LAUNCH_* of the call (host side only)
 };
 
 static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
@@ -109,6 +120,7 @@ static inline Epi make_epi(const mspl_epilogue_t* ep, int C_default, int hw) {
         e.reinf_r = ep->reinf_r; e.reinf_w = ep->reinf_w; e.gate = ep->gate;
         if (ep->out_ctot > 0) { e.ctot = ep->out_ctot; e.coff = ep->out_coff; }
         e.raw = ep->raw_out;
+        e.flags = ep->flags;
     }
     return e;
 }

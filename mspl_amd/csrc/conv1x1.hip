@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void conv1x1_thin_kernel(const float* __restri
 // 0 = launched.  Shapes: M <= 16 per group, K in 8..64 (multiple of 8), planes a multiple of 4 pixels, >= 400 workgroups.
 static int launch_thin_try(const float* x, const float* w, int N, int Cin, int Cout, int groups, int HW, const Epi& e, float* out,
                            hipStream_t s) {
-    static const int enabled = getenv("MSPL_PW_THIN") ? atoi(getenv("MSPL_PW_THIN")) : 1;
+    static const int enabled = MSPL_TUNE_INT("MSPL_PW_THIN", 1);
     const int K = Cin / groups, M = Cout / groups;
     // measured (tools/bench_ops.py, bs 16): 32 -> 16 at 144x240 26.1 -> 23.0 us, 16 -> 13 18.3 -> 15.6, 128 -> 32 g4 at 72x120
     // 23.9 -> 18.9; with fewer than ~2 workgroups per CU (48 -> 16 at 72x120: 144) the MFMA kernel's finer tiles win (13 vs 20 us)
@@ -864,7 +864,7 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     g.KS = g.K | 1;
     int mbr = ((g.M + 31) / 32) * 32;
     if (mbr > 128) mbr = 128;
-    static const int dbg_plds = getenv("MSPL_PW_PIPE_LDS") ? atoi(getenv("MSPL_PW_PIPE_LDS")) : 40;     // KiB of weights per workgroup
+    static const int dbg_plds = MSPL_TUNE_INT("MSPL_PW_PIPE_LDS", 40);     // KiB of weights per workgroup
     while (mbr > 32 && (size_t)mbr * (g.KS + ROWC) * 4 > (size_t)dbg_plds * 1024) mbr -= 32;
     if (mbr == 96) mbr = 64;
     g.MB = mbr;
@@ -878,8 +878,8 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
         return g.HW % ns == 0 && al(x, a) && al(out, a) && (!ep || (al(ep->pre_add, a) && al(ep->residual, a) && al(ep->reinf_r, a)));
     };
     int nsub = ok(2) ? 2 : 1;
-    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;
-    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    static const int dbg_nsub = MSPL_TUNE_INT("MSPL_PW_NSUB", 0);
+    static const int dbg_tpw = MSPL_TUNE_INT("MSPL_PW_TPW", 0);
     if ((dbg_nsub == 1 || dbg_nsub == 2) && ok(dbg_nsub)) nsub = dbg_nsub;
     g.ptiles = (int)ceil_div64((int64_t)g.N * g.HW, 32 * nsub);
     // workgroups: at most one resident round (3 per CU), each walking TPW tiles per wave
@@ -938,7 +938,7 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
 // Launch of the register-resident-weights kernel (K % 8 == 0, K <= 128, aligned weights).
 static int launch_areg(const float* x, const float* w, PwGeom g, const Epi& e, const mspl_epilogue_t* ep, float* out,
                        hipStream_t s) {
-    static const int dbg_astage = getenv("MSPL_PW_ASTAGE") ? atoi(getenv("MSPL_PW_ASTAGE")) : -1;
+    static const int dbg_astage = MSPL_TUNE_INT("MSPL_PW_ASTAGE", -1);
     g.astage = dbg_astage >= 0 ? dbg_astage : !(g.K <= 32 && (int64_t)g.N * g.HW >= 100000);
     g.KS = g.K | 1;
     int mbr = ((g.M + 31) / 32) * 32;
@@ -959,8 +959,8 @@ static int launch_areg(const float* x, const float* w, PwGeom g, const Epi& e, c
     auto tiles_of = [&](int ns) { return (int64_t)g.G * g.mblocks * g.mc_total * ceil_div64((int64_t)g.N * g.HW, 32 * ns); };
     int nsub = 1;
     if (ok(2) && tiles_of(2) >= 4096) nsub = 2;
-    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;   // tuning override
-    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    static const int dbg_nsub = MSPL_TUNE_INT("MSPL_PW_NSUB", 0);   // tuning override
+    static const int dbg_tpw = MSPL_TUNE_INT("MSPL_PW_TPW", 0);
     if ((dbg_nsub == 1 || dbg_nsub == 2) && ok(dbg_nsub)) nsub = dbg_nsub;
     g.ptiles = (int)ceil_div64((int64_t)g.N * g.HW, 32 * nsub);
     int tpw = 1;
@@ -1040,7 +1040,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     const int K32 = (g.K + 31) & ~31;
     g.KS = K32 | 1;
     g.vecw = ((g.K & 3) == 0) && ((((uintptr_t)w) & 15) == 0);
-    static const int dbg_areg = getenv("MSPL_PW_AREG") ? atoi(getenv("MSPL_PW_AREG")) : 1;
+    static const int dbg_areg = MSPL_TUNE_INT("MSPL_PW_AREG", 1);
     const int ng8 = g.K >> 3;
     const bool ng_ok = ng8 == 2 || ng8 == 3 || ng8 == 4 || ng8 == 6 || ng8 == 8 || ng8 == 12 || ng8 == 16;
     // K = 256 / 512 (the decoder's first projection) only when the staged rows fit LDS (few output channels)
@@ -1048,7 +1048,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     // measured (tools/bench_ops.py): the register-weights kernel wins for short K on large maps (no staging, no barrier);
     // for K >= 64 its 150-185 VGPRs leave 2 workgroups per CU and the 18x30 / 36x60 grids then need a second round
     const bool areg_shape = dbg_areg == 2 || (g.K <= 32 && (int64_t)N * HW >= 100000);
-    static const int dbg_pipe = getenv("MSPL_PW_PIPE") ? atoi(getenv("MSPL_PW_PIPE")) : 1;
+    static const int dbg_pipe = MSPL_TUNE_INT("MSPL_PW_PIPE", 1);
     const bool pipe_shape = true;      // measured faster than the LDS-ring and register-weights forms on every eligible shape
     if (dbg_pipe && pipe_shape && (g.K & 7) == 0 && (ng_ok || ng_big) && g.vecw &&
         (size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32))
@@ -1060,7 +1060,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     MSPL_REQUIRE((size_t)N * Cin * HW * sizeof(float) < (1ull << 32) && (size_t)N * e.ctot * HW * sizeof(float) < (1ull << 32),
                  MSPL_ERR_UNSUPPORTED, "conv1x1: tensor exceeds the 32-bit byte offsets of the matrix-core kernel");
     const size_t lds_cap = 96 * 1024;       // hard cap (of the 160 KiB per CU)
-    static const int dbg_lds = getenv("MSPL_PW_LDS") ? atoi(getenv("MSPL_PW_LDS")) : 0;
+    static const int dbg_lds = MSPL_TUNE_INT("MSPL_PW_LDS", 0);
     const size_t lds_want = dbg_lds ? (size_t)dbg_lds * 1024 : 40 * 1024;      // preferred: several workgroups per CU
     MSPL_REQUIRE((size_t)32 * (g.KS + rowf) * 4 <= lds_cap, MSPL_ERR_UNSUPPORTED,
                  "conv1x1: K=%d per group exceeds the LDS weight tile", g.K);
@@ -1099,8 +1099,8 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     if (ok(4) && waves_of(4) >= 2048) nsub = 4;
     else if (ok(2) && waves_of(2) >= 2048) nsub = 2;
     else if (ok(2) && !ok(1)) nsub = 2;
-    static const int dbg_nsub = getenv("MSPL_PW_NSUB") ? atoi(getenv("MSPL_PW_NSUB")) : 0;   // tuning override
-    static const int dbg_tpw = getenv("MSPL_PW_TPW") ? atoi(getenv("MSPL_PW_TPW")) : 0;
+    static const int dbg_nsub = MSPL_TUNE_INT("MSPL_PW_NSUB", 0);   // tuning override
+    static const int dbg_tpw = MSPL_TUNE_INT("MSPL_PW_TPW", 0);
     if (dbg_nsub && ok(dbg_nsub)) nsub = dbg_nsub;
     g.ptiles = (int)ceil_div64((int64_t)N * HW, 32 * nsub);
     const int64_t wave_tiles = (int64_t)groups * g.mblocks * g.ptiles;
@@ -1118,7 +1118,7 @@ extern "C" int mspl_conv1x1_fwd(const float* x, const float* w, int32_t N, int32
     dim3 grid((unsigned)blocks), blk(256);
     // ring depth = B groups (8 k-values each) in flight per wave (deeper rings measured slower: they cost occupancy)
     int ring = 4;
-    static const int dbg_ring = getenv("MSPL_PW_RING") ? atoi(getenv("MSPL_PW_RING")) : 0;
+    static const int dbg_ring = MSPL_TUNE_INT("MSPL_PW_RING", 0);
     if (nsub < 4 && (dbg_ring == 4 || dbg_ring == 8 || dbg_ring == 16)) ring = dbg_ring;
 #define MSPL_PW(NS, RG) hipLaunchKernelGGL((conv1x1_mfma_kernel<NS, RG>), grid, blk, lds, s, x, w, g, e, out)
     if (nsub == 4) MSPL_PW(4, 4);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv1x1_splitk_kernel(const float* __rest
 // Returns 1 when the shape / epilogue is not this kernel's (the caller continues with the tile-pipelined kernel).
 int conv1x1_splitk_try(const float* x, const float* w, int N, int Cin, int Cout, int groups, int HW, const Epi& e, float* out,
                        hipStream_t s) {
-    static const int enabled = getenv("MSPL_PW_SPLITK") ? atoi(getenv("MSPL_PW_SPLITK")) : 1;
+    static const int enabled = MSPL_TUNE_INT("MSPL_PW_SPLITK", 1);
     const int M = Cout / groups, K = Cin / groups;
     if (!enabled || M > 32 || K < 64 || (K & 31) != 0) return 1;          // K/4 per wave in chunks of 8 or 16 MFMA steps
     // measured (tools/bench_ops.py conv1x1): wins for the ungrouped deep-and-narrow projections of the pyramid (512->16: 22.1 ->

@@ -100,8 +100,8 @@ int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M,
     g.ngroups = N * g.gpi;
     // waves per tile: enough to put ~3 waves on every SIMD (MSPL_WGRAD_WAVES, 3072), at least MSPL_WGRAD_MINREP pixel groups per
     // wave when the range allows (each workgroup leaves with 1024 atomics), never more waves than groups
-    static const int target = getenv("MSPL_WGRAD_WAVES") ? atoi(getenv("MSPL_WGRAD_WAVES")) : 3072;
-    static const int minrep = getenv("MSPL_WGRAD_MINREP") ? atoi(getenv("MSPL_WGRAD_MINREP")) : 1;
+    static const int target = MSPL_TUNE_INT("MSPL_WGRAD_WAVES", 3072);
+    static const int minrep = MSPL_TUNE_INT("MSPL_WGRAD_MINREP", 1);
     int64_t ns = (target + tiles - 1) / tiles;
     if (ns * minrep > g.ngroups) ns = g.ngroups / (minrep > 0 ? minrep : 1);
     if (ns < 4) ns = 4;

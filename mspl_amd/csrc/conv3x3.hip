@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void gconv3x3_stream_kernel(const float* __res
 
 // Returns MSPL_OK when launched, 1 when the shape is left to the LDS-tiled kernel.
 static int gconv3x3_stream_try(const float* x, const float* w, const C3Geom& g3, const Epi& e, float* out, hipStream_t s) {
-    static const int off = getenv("MSPL_GC3S") ? atoi(getenv("MSPL_GC3S")) == 0 : 0;
+    static const int off = (MSPL_TUNE_INT("MSPL_GC3S", 1) == 0);
     auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
     if (off || (g3.W & 3) != 0 || g3.W < 16 || g3.W > 256 || g3.H < 4) return 1;
     if (!(al16(x) && al16(out) && al16(e.pre_add) && al16(e.residual) && al16(e.reinf_r) && al16(e.raw))) return 1;
@@ -479,7 +479,7 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     g.total = (unsigned)blocks; g.xcd_per = xcd_per(blocks);
     dim3 grid(8u * g.xcd_per), blk(256);
     const size_t lds = lds_of(th);
-    static const int no_uniw = getenv("MSPL_C3_UNIW") ? atoi(getenv("MSPL_C3_UNIW")) == 0 : 0;
+    static const int no_uniw = (MSPL_TUNE_INT("MSPL_C3_UNIW", 1) == 0);
     const bool uniw = g.coblks == 1 && !no_uniw;
 #define MSPL_C3(CB) do { if (uniw) hipLaunchKernelGGL((conv3x3_kernel<STRIDE, CB, true>), grid, blk, lds, s, x, w, g, e, out); \
                          else hipLaunchKernelGGL((conv3x3_kernel<STRIDE, CB, false>), grid, blk, lds, s, x, w, g, e, out); } while (0)
@@ -519,7 +519,7 @@ extern "C" int mspl_conv3x3_fwd(const float* x, const float* w, int32_t N, int32
     g.Wo = (W - 1) / stride + 1;
     const Epi e = make_epi(ep, Cout, g.Ho * g.Wo);
     hipStream_t s = (hipStream_t)stream;
-    static const int no_dws = getenv("MSPL_DWS") ? atoi(getenv("MSPL_DWS")) == 0 : 0;       // tuning aid: 0 = LDS-tiled form only
+    static const int no_dws = (MSPL_TUNE_INT("MSPL_DWS", 1) == 0);       // tuning aid: 0 = LDS-tiled form only
     if (stride == 1 && !no_dws && dwconv3x3_stream_ok(g, x, out, e)) return launch_dws(x, w, g, e, out, s);
     if (stride == 1) {
         const int rc = gconv3x3_stream_try(x, w, g, e, out, s);

@@ -261,7 +261,7 @@ extern "C" int mspl_dense_conv_fwd(const float* x, const float* w_packed, int32_
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W; g.taps = ksize * ksize; g.dil = dilation;
     g.mblocks = ceil_div(Cout, DC_BM);
     const int64_t P = (int64_t)N * H * W;
-    static const int dbg_wide = getenv("MSPL_DC_WIDE") ? atoi(getenv("MSPL_DC_WIDE")) : -1;
+    static const int dbg_wide = MSPL_TUNE_INT("MSPL_DC_WIDE", -1);
     const bool wide = dbg_wide >= 0 ? dbg_wide != 0 : (ceil_div64(P, DC_BN2) * g.mblocks >= 512);     // enough 128-pixel tiles to fill the chip
     const int64_t ptiles = ceil_div64(P, wide ? DC_BN2 : DC_BN);
     MSPL_REQUIRE(ptiles * g.mblocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "dense_conv: grid too large");

@@ -575,11 +575,11 @@ __global__ __launch_bounds__(512, 2) void eesp_dw_direct_kernel(const float* __r
 // Returns MSPL_OK when launched, 1 when the shape is left to the tiled kernel.
 template <int STRIDE, class DS>
 static int launch_direct(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out, hipStream_t s) {
-    static const int dbg = getenv("MSPL_DW_DIRECT") ? atoi(getenv("MSPL_DW_DIRECT")) : 1;
-    static const int dbg_rv = getenv("MSPL_DW_RV") ? atoi(getenv("MSPL_DW_RV")) : 0;
-    static const int dbg_cp = getenv("MSPL_DW_DCP") ? atoi(getenv("MSPL_DW_DCP")) : 0;
-    static const int dbg_th = getenv("MSPL_DW_DTH") ? atoi(getenv("MSPL_DW_DTH")) : 0;
-    static const int dbg_t = getenv("MSPL_DW_DT") ? atoi(getenv("MSPL_DW_DT")) : 0;
+    static const int dbg = MSPL_TUNE_INT("MSPL_DW_DIRECT", 1);
+    static const int dbg_rv = MSPL_TUNE_INT("MSPL_DW_RV", 0);
+    static const int dbg_cp = MSPL_TUNE_INT("MSPL_DW_DCP", 0);
+    static const int dbg_th = MSPL_TUNE_INT("MSPL_DW_DTH", 0);
+    static const int dbg_t = MSPL_TUNE_INT("MSPL_DW_DT", 0);
     // Measured (tools/bench_ops.py k2, batch 16): stride 2 -- 72x120 -> 36x60: 13.6 -> 10.5 us, 36x60 -> 18x30: 9.1 -> 7.4 us,
     // 144x240 -> 72x120: 32.3 -> 30.9 us.  Stride 1 (18x30: 12.0 vs 11.3 us, 36x60: 15.6 vs 12.6 us) stays with the tiled kernel:
     // there every input row is read by 7-9 output rows and the 16-byte loads of all those lanes go through the CU's one
@@ -622,7 +622,7 @@ static int launch_direct(const float* x, const float* w, int N, int n, int H, in
         }
     }
     if (T == 0) return 1;
-    if (dbg_cp > 0 && dbg_cp <= 4 && n % dbg_cp == 0) cp = dbg_cp;
+    if (dbg_cp > 0 && dbg_cp <= 4 && n % std::max(dbg_cp, 1) == 0) cp = dbg_cp;
     if (dbg_th > 0) th = ceil_div(std::min(dbg_th, g.Ho), RV) * RV;
     if (dbg_cp > 0 || dbg_th > 0 || dbg_t > 0) {
         const int items = cp * (th / RV) * g.XS;
@@ -640,7 +640,7 @@ static int launch_direct(const float* x, const float* w, int N, int n, int H, in
     if (max_items >= 4096 || !magic_exact(g.mag_xs, g.XS, max_items + 1024)) return 1;
     for (int rg = 1; rg <= th / RV; ++rg)
         if (!magic_exact(magic20(rg), rg, cp * rg + 1024 / g.XS + 2)) return 1;
-    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    static const int dbg_wt = MSPL_TUNE_INT("MSPL_DW_WT", 1);
     g.wt = dbg_wt;
     const dim3 grid((unsigned)ntiles), blk((unsigned)T);
 #define MSPL_DD(RVV) do { if (partial) hipLaunchKernelGGL((eesp_dw_direct_kernel<STRIDE, DS, RVV, true>), grid, blk, 0, s, x, w, g, e, out); \
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256) void eesp_dw_stream2_kernel(const float* __res
 // Returns MSPL_OK when launched, 1 when the shape is left to the other forms.
 template <class DS>
 static int launch_stream2(const float* x, const float* w, int N, int n, int H, int W, const Epi& e, float* out, hipStream_t s) {
-    const char* menv = getenv("MSPL_DW_STREAM");                 // 0 off, 1 auto, 2 whenever the shape allows; read per call (tests switch it)
-    const int mode = menv ? atoi(menv) : 1;
+    // 0 off, 1 auto, 2 whenever the shape allows: a per-call launch flag (the forms are bit-identical; tests compare them)
+    const int mode = (e.flags & MSPL_LAUNCH_K2_STREAM_OFF) ? 0 : (e.flags & MSPL_LAUNCH_K2_STREAM_FORCE) ? 2 : 1;
     if (!mode || DS::maxd() > 4) return 1;
     if ((W & 7) != 0 || W / 8 > 63 || H < 8) return 1;
     if (e.pre_add || e.residual || e.reinf_r || e.gate || e.raw) return 1;
@@ -861,7 +861,7 @@ static int launch_stream2(const float* x, const float* w, int N, int n, int H, i
     // MSPL_DW_SSEG sweep: 144x240 n=24 batch 16: SEG 6 / 16 / 26 / 36 = 25.0 / 20.9 / 23.6 / 28.4 us (960 waves at 16), batch 32:
     // 42.5 / 38.2 / 46.3 / 36.5 us (768 waves at 36); 72x120 n=32 batch 16: 9.6 / 15.6 / 21.5 / 27.3 us (768 waves at 6); the direct
     // form: 30.9, 55.7 and 10.5 us).
-    static const int dbg_seg = getenv("MSPL_DW_SSEG") ? atoi(getenv("MSPL_DW_SSEG")) : 0;
+    static const int dbg_seg = MSPL_TUNE_INT("MSPL_DW_SSEG", 0);
     auto waves_of = [&](int sg) { return (int64_t)n * ceil_div64((int64_t)N * ceil_div(g.Ho, sg), g.SUB); };
     int seg = 6;
     for (int sg = 16; sg - 10 < g.Ho; sg += 10)
@@ -874,7 +874,7 @@ static int launch_stream2(const float* x, const float* w, int N, int n, int H, i
     const int64_t waves = (int64_t)n * g.wpc;
     if (waves >= (1ll << 31)) return 1;
     g.total = (unsigned)waves;
-    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    static const int dbg_wt = MSPL_TUNE_INT("MSPL_DW_WT", 1);
     g.wt = dbg_wt;
     if (g.wt) hipLaunchKernelGGL((eesp_dw_stream2_kernel<DS, true>), dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, s, x, w, e.scale, e.shift,
                                  e.alpha, e.ctot, e.coff, g, out);
@@ -914,10 +914,10 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
         if ((g.XS & 3) == 0) { while (((lsh - g.XS) & 15) != 0) lsh += 4; }      // (XS % 4 != 0: no exact fit; a few 2-way conflicts)
         g.RS = 2 * lsh;
     }
-    static const int dbg_lds = getenv("MSPL_DW_LDS") ? atoi(getenv("MSPL_DW_LDS")) : 0;     // KiB per workgroup
-    static const int dbg_cp = getenv("MSPL_DW_CP") ? atoi(getenv("MSPL_DW_CP")) : 0;
-    static const int dbg_th = getenv("MSPL_DW_TH") ? atoi(getenv("MSPL_DW_TH")) : 0;
-    static const int dbg_wgs = getenv("MSPL_DW_WGS") ? atoi(getenv("MSPL_DW_WGS")) : 0;     // persistent workgroups per CU
+    static const int dbg_lds = MSPL_TUNE_INT("MSPL_DW_LDS", 0);     // KiB per workgroup
+    static const int dbg_cp = MSPL_TUNE_INT("MSPL_DW_CP", 0);
+    static const int dbg_th = MSPL_TUNE_INT("MSPL_DW_TH", 0);
+    static const int dbg_wgs = MSPL_TUNE_INT("MSPL_DW_WGS", 0);     // persistent workgroups per CU
     static unsigned long long* stamp_buf = nullptr;
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_DW_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)4 * 65536 * sizeof(unsigned long long));
@@ -925,8 +925,8 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
     // chunks.  Score (lower is better): idle lanes of the item loop (items rarely fill whole rounds of T lanes: 18 x 8 strips
     // = 144 items leave 44 % of 256 lanes idle, 4 such planes fill 192 lanes three times) x halo rows re-read x a penalty for
     // fewer tiles than the chip needs to be busy.
-    static const int dbg_thr = getenv("MSPL_DW_THREADS") ? atoi(getenv("MSPL_DW_THREADS")) : 0;
-    static const int dbg_persist = getenv("MSPL_DW_PERSIST") ? atoi(getenv("MSPL_DW_PERSIST")) : -1;
+    static const int dbg_thr = MSPL_TUNE_INT("MSPL_DW_THREADS", 0);
+    static const int dbg_persist = MSPL_TUNE_INT("MSPL_DW_PERSIST", -1);
     const size_t lds_budget = (size_t)(dbg_lds > 0 ? dbg_lds : 38) * 1024;
     auto rin_of = [&](int th) { return (th - 1) * STRIDE + 1 + 2 * MAXD; };
     auto lds_of = [&](int th, int cp) { return ((size_t)cp * rin_of(th) * g.RS + 16 + (size_t)cp * 64) * sizeof(float); };
@@ -987,7 +987,7 @@ static int launch(const float* x, const float* w, int N, int n, int H, int W, co
         if (blocks > 8) blocks -= blocks % 8;             // ids b and b + 8 share an XCD: keep the stride a multiple of 8
     }
     g.stamps = (dbg_stamp && blocks <= 65536) ? stamp_buf : nullptr;
-    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;     // 0: plain stores (A/B aid)
+    static const int dbg_wt = MSPL_TUNE_INT("MSPL_DW_WT", 1);     // 0: plain stores (A/B aid)
     g.wt = dbg_wt && (size_t)N * e.ctot * g.Ho * g.Wo * sizeof(float) < (1ull << 31);
     if (persist) hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, true>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
     else hipLaunchKernelGGL((eesp_dw_hff_kernel<STRIDE, DS, false>), dim3((unsigned)blocks), dim3(T), lds, s, x, w, g, e, out);
@@ -1210,7 +1210,7 @@ static int eesp_proj_dw_plan(int N, int Cin, int n, int groups, int H, int W, co
     g.RS = 4 * g.XS + 8;                                   // 4 zero columns + the row + zero fill for the right-hand taps
     // bands: enough workgroups for every CU (a launch of 16 images x 8 slabs is 128 workgroups); every band re-computes up to
     // 2 * maxd projection rows
-    static const int dbg_bands = getenv("MSPL_FRONT_BANDS") ? atoi(getenv("MSPL_FRONT_BANDS")) : 0;
+    static const int dbg_bands = MSPL_TUNE_INT("MSPL_FRONT_BANDS", 0);
     g.mag_w = magic20(W); g.mag_xs = magic20(g.XS);
     const int max_bands = 3;                               // (more bands = more of the projection re-computed in the halos than computed once)
     for (int bands = 1; bands <= max_bands; ++bands) {
@@ -1237,7 +1237,7 @@ extern "C" int mspl_eesp_proj_dw_hff_fits(int32_t N, int32_t Cin, int32_t n, int
     // with three launches of 32 images in flight it costs 1.7 % (its workgroups hold 50-100 KB of LDS and 512 threads, which
     // crowds out the other lanes' kernels).  So: used unless the caller asks for throughput launch shapes (MSPL_LAUNCH_THROUGHPUT,
     // per call); MSPL_EESP_FRONT=0 / =2 force it off / on.
-    static const int mode = getenv("MSPL_EESP_FRONT") ? atoi(getenv("MSPL_EESP_FRONT")) : 1;
+    static const int mode = MSPL_TUNE_INT("MSPL_EESP_FRONT", 1);
     if (mode == 0 || !dil || (mode == 1 && (launch_flags & MSPL_LAUNCH_THROUGHPUT))) return 0;
     FrGeom g; size_t lds;
     return eesp_proj_dw_plan(N, Cin, n, groups, H, W, dil, g, lds);
@@ -1256,9 +1256,9 @@ extern "C" int mspl_eesp_proj_dw_hff_fwd(const float* x, const float* wp, const 
     MSPL_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 15) == 0, MSPL_ERR_UNSUPPORTED, "eesp_proj_dw_hff: unaligned tensors");
     const Epi e = make_epi(ep, 4 * n, H * W);
     MSPL_REQUIRE((size_t)N * e.ctot * H * W * sizeof(float) < (1ull << 31), MSPL_ERR_UNSUPPORTED, "eesp_proj_dw_hff: output too large");
-    static const int dbg_wt = getenv("MSPL_DW_WT") ? atoi(getenv("MSPL_DW_WT")) : 1;
+    static const int dbg_wt = MSPL_TUNE_INT("MSPL_DW_WT", 1);
     g.wt = dbg_wt;
-    static const int dbg_stop = getenv("MSPL_FRONT_STOP") ? atoi(getenv("MSPL_FRONT_STOP")) : 0;
+    static const int dbg_stop = MSPL_TUNE_INT("MSPL_FRONT_STOP", 0);
     g.stop = dbg_stop;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * groups * g.bands)), blk(512);

@@ -191,7 +191,7 @@ extern "C" int mspl_eesp_dw_bwd(const float* gs, const float* x, const float* w4
     hipStream_t s = (hipStream_t)stream;
     if (gx) {
         MSPL_REQUIRE((int64_t)N * n <= 65535, MSPL_ERR_BAD_SHAPE, "eesp_dw_bwd: too many planes (%lld)", (long long)N * n);
-        static const int s2_form = getenv("MSPL_DW_BWD_S2") ? atoi(getenv("MSPL_DW_BWD_S2")) : 1;
+        static const int s2_form = MSPL_TUNE_INT("MSPL_DW_BWD_S2", 1);
         if (s2_form && stride == 2 && (H & 1) == 0 && (W & 1) == 0 && (((uintptr_t)gx) & 7) == 0)
             hipLaunchKernelGGL(eesp_dw_bwd_data_s2_kernel, dim3((unsigned)ceil_div((H / 2) * (W / 2), 256), (unsigned)(N * n)), dim3(256), 0, s, gs,
                                w4, g, gx);

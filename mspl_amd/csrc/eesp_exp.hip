@@ -439,7 +439,7 @@ static XePlan xe_plan(int n, int H, int W, const int32_t* dil) {
 using namespace mspl;
 
 extern "C" int mspl_eesp_dw_exp_fits(int32_t N, int32_t n, int32_t H, int32_t W, const int32_t dil[4], uint32_t flags) {
-    static const int enabled = getenv("MSPL_EESP_EXP") ? atoi(getenv("MSPL_EESP_EXP")) : 1;
+    static const int enabled = MSPL_TUNE_INT("MSPL_EESP_EXP", 1);
     (void)flags;
     if (!enabled || !dil || N < 1) return 0;
     return xe_plan(n, H, W, dil).kind != 0 ? 1 : 0;
@@ -486,10 +486,14 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
     const float* dwp = packed;
     const float* ap = packed + (size_t)n * XE_REC;
     const dim3 grid((unsigned)nwg), blk(512);
+#ifdef MSPL_DEBUG_STAMPS
     static unsigned long long* stamp_buf = nullptr;
     static const int dbg_stamp = MSPL_STAMP_ENV("MSPL_XE_STAMP");
     if (dbg_stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 8 * 12 * sizeof(unsigned long long));
     unsigned long long* stamps = nwg <= 8192 ? stamp_buf : nullptr;
+#else
+    unsigned long long* const stamps = nullptr;      // (the kernels' stamp argument: compiled out with the stamps)
+#endif
 #define XE_ARGS grid, blk, 0, stream, r, dwp, ap, ep->scale, ep->shift, ep->alpha, ep->residual, out, next_packed, nscale, nshift, nalpha, rnext, H, bands, (int)nwg, stamps
 #define XE_GO(NX) do { \
     if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
@@ -500,6 +504,7 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
 #undef XE_GO
 #undef XE_ARGS
     MSPL_CHECK_LAUNCH("eesp_dw_exp");
+#ifdef MSPL_DEBUG_STAMPS
     if (stamps) {   // debug only (STAMPS=1 builds): synchronous dump of the step timeline (100 MHz ticks)
         (void)hipDeviceSynchronize();
         static unsigned long long host[8192 * 8 * 12];
@@ -514,6 +519,7 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
         for (int k = 0; k < 12; ++k) fprintf(stderr, "%.2f(%.2f) ", avg[k], mx[k]);
         fprintf(stderr, "\n");
     }
+#endif
     return MSPL_OK;
 }
 

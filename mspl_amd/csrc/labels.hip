@@ -665,7 +665,7 @@ static int label_epilogue_impl(const float* mainp, const float* aux, int32_t N, 
             if (!ok) st.vec = 0;
         }
         const size_t lds = ((size_t)st.nrm * C * st.wms + (size_t)st.nra * C * st.was + 32) * sizeof(float);
-        static const int dbg_reg = getenv("MSPL_LE_REG") ? atoi(getenv("MSPL_LE_REG")) : 0;     // tuning aid: force the register form
+        static const int dbg_reg = MSPL_TUNE_INT("MSPL_LE_REG", 0);     // tuning aid: force the register form
         if (lds <= 128 * 1024 && (st.nrm + st.nra) * C < 4096 && st.wms <= 256 && st.was <= 256 && (!st.vec || (st.wms <= 256 && st.was <= 256)) && !(dbg_reg && !hist)) {
             const dim3 grid((unsigned)ceil_div(W, 256), (unsigned)(4 * ceil_div(ceil_div(H, LE_RB), 4)), (unsigned)N);
             unsigned int* ws = nullptr;

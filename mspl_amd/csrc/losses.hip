@@ -149,7 +149,7 @@ extern "C" int mspl_weighted_ce_fwd(const float* pred, const int64_t* target, co
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "weighted_ce: bad shape N=%d C=%d HW=%d", N, C, HW);
     const int64_t total = (int64_t)N * HW;
     // (measured at 16 x 13 x 288x480: 143 / 96 / 92 / 128 / 231 us at 512 / 1024 / 2048 / 4096 / 8640 workgroups)
-    static const int max_blocks = getenv("MSPL_LOSS_BLOCKS") ? atoi(getenv("MSPL_LOSS_BLOCKS")) : 2048;
+    static const int max_blocks = MSPL_TUNE_INT("MSPL_LOSS_BLOCKS", 2048);
     const int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), max_blocks);
     hipLaunchKernelGGL(wce_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
                        u_weight, class_weights, ignore_index, C, HW, sums, total);

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
 // Returns MSPL_OK when launched, 1 when the shape is left to the band form.
 static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                            const float* const* stage_w, float* const* out, hipStream_t stream) {
-    static const int off = getenv("MSPL_PREP_STREAM") ? atoi(getenv("MSPL_PREP_STREAM")) == 0 : 0;
+    static const int off = (MSPL_TUNE_INT("MSPL_PREP_STREAM", 1) == 0);
     if (off || (w & 1) || (((uintptr_t)x) & 15)) return 1;
     const int VW = (w & 3) == 0 ? 4 : 2;
     PsGeom g;
@@ -365,7 +365,7 @@ static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, c
     g.RBS = (w + 3) & ~3;
     // waves per workgroup: one trip of the 2x2 branch should cover the map's rows (all of a plane's row loads in flight at once:
     // one workgroup per CU is all a launch of N * P = 256 planes gives, so the loads of a CU come from this workgroup alone)
-    static const int dbg_waves = getenv("MSPL_PREP_WAVES") ? atoi(getenv("MSPL_PREP_WAVES")) : 0;
+    static const int dbg_waves = MSPL_TUNE_INT("MSPL_PREP_WAVES", 0);
     int hmax = 1;
     for (int i = 0; i < nb; ++i) hmax = std::max(hmax, (int)hs[i]);
     int waves = 4;
@@ -394,7 +394,7 @@ static size_t prep_plan(PrepGeom& g, int64_t planes) {
     int S = planes >= 128 ? 2 : (int)ceil_div64(256, planes);
     if (S < 1) S = 1;
     if (S > 16) S = 16;
-    static const int dbg_s = getenv("MSPL_PREP_S") ? atoi(getenv("MSPL_PREP_S")) : 0;
+    static const int dbg_s = MSPL_TUNE_INT("MSPL_PREP_S", 0);
     if (dbg_s > 0) S = dbg_s;
     for (;; S *= 2) {                             // ... and few enough input rows per band to fit LDS
         g.S = S;
@@ -459,7 +459,7 @@ extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int3
         g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i];
     }
     const size_t lds = prep_plan(g, planes);
-    static const int dbg_stop = getenv("MSPL_PREP_STOP") ? atoi(getenv("MSPL_PREP_STOP")) : 0;
+    static const int dbg_stop = MSPL_TUNE_INT("MSPL_PREP_STOP", 0);
     g.stop = dbg_stop;
     MSPL_REQUIRE(lds > 0, MSPL_ERR_UNSUPPORTED, "pyr_down_prep: no row band of a %dx%d map fits LDS (see mspl_pyr_down_prep_lds_bytes)", h, w);
     const int64_t blocks = planes * g.S;

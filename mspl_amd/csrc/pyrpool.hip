@@ -393,7 +393,7 @@ static int pyrpool_fused_launch(const float* x, int32_t N, int32_t P, int32_t h,
     MSPL_REQUIRE(nb >= 1 && nb <= PYR_MAXB, MSPL_ERR_UNSUPPORTED, "pyrpool_fused: %d branches (1..%d)", nb, PYR_MAXB);
     if (int rc = check_epi(ep, P, "pyrpool_fused", zcat != nullptr)) return rc;
     if (!dry) {   // register-streaming form first, then the LDS-tiled stencil form; shapes they do not cover fall through to the table-driven kernel
-        static const int force_tables = getenv("MSPL_PYR_TABLES") ? atoi(getenv("MSPL_PYR_TABLES")) : 0;
+        static const int force_tables = MSPL_TUNE_INT("MSPL_PYR_TABLES", 0);
         if (!force_tables) {
             // (the training forward -- zcat wanted -- exists in the streaming and in the table form)
             const int rc3 = pyrpool_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, down_e, br_scale, br_shift, br_alpha, merge_w,
@@ -453,7 +453,7 @@ static int pyrpool_fused_launch(const float* x, int32_t N, int32_t P, int32_t h,
         off = (off + 3) & ~3;
     }
     g.mag_bw = magic(g.TW + 2);
-    static const int dbg_stop = getenv("MSPL_PYR_STOP") ? atoi(getenv("MSPL_PYR_STOP")) : 0;
+    static const int dbg_stop = MSPL_TUNE_INT("MSPL_PYR_STOP", 0);
     g.stop_after = dbg_stop;
     g.BW = (g.TW + 2 + 3 + 4) & ~3;      // halo tile row stride, 16-byte aligned rows, +4 for the strip over-read
     g.boff = off;
@@ -467,7 +467,7 @@ static int pyrpool_fused_launch(const float* x, int32_t N, int32_t P, int32_t h,
     const Epi e = make_epi(ep, P, h * w);
     int cpb = 1;
     while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= 2048) cpb *= 2;
-    static const int dbg_cpb = getenv("MSPL_PYR_CPB") ? atoi(getenv("MSPL_PYR_CPB")) : 0;
+    static const int dbg_cpb = MSPL_TUNE_INT("MSPL_PYR_CPB", 0);
     if (dbg_cpb > 0 && P % dbg_cpb == 0) cpb = dbg_cpb;
     g.CPB = cpb; g.cblocks = P / cpb;
     const int64_t blocks = (int64_t)N * g.cblocks * g.tiles_y * g.tiles_x;

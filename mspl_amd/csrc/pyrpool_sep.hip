@@ -545,10 +545,10 @@ int pyrpool_sep_try(const float* x, int N, int P, int h, int w, int nb, const in
     const int64_t min_blocks = (launch_flags & MSPL_LAUNCH_THROUGHPUT) ? 512 : 2048;
     int cpb = 1;
     while (cpb * 2 <= P && P % (cpb * 2) == 0 && (int64_t)N * (P / (cpb * 2)) * g.tiles_y * g.tiles_x >= min_blocks) cpb *= 2;
-    static const int dbg_cpb = getenv("MSPL_PYR_CPB") ? atoi(getenv("MSPL_PYR_CPB")) : 0;
+    static const int dbg_cpb = MSPL_TUNE_INT("MSPL_PYR_CPB", 0);
     if (dbg_cpb > 0 && P % dbg_cpb == 0) cpb = dbg_cpb;
     g.CPB = cpb; g.cblocks = P / cpb;
-    static const int dbg_stop = getenv("MSPL_PYR_STOP") ? atoi(getenv("MSPL_PYR_STOP")) : 0;
+    static const int dbg_stop = MSPL_TUNE_INT("MSPL_PYR_STOP", 0);
     g.stop_after = dbg_stop;
     const int64_t blocks = (int64_t)N * g.cblocks * g.tiles_y * g.tiles_x;
     if (blocks >= (1ll << 31)) return 1;

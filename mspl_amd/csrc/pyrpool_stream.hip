@@ -373,9 +373,9 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
                        const float* const* stage_w, const float* const* down_e, const float* br_scale,
                        const float* br_shift, const float* br_alpha, const float* merge_w, const Epi& e, float* out,
                        hipStream_t stream, float* zcat) {
-    static const int off = getenv("MSPL_PYR_STREAM") ? atoi(getenv("MSPL_PYR_STREAM")) == 0 : 0;
+    static const int off = (MSPL_TUNE_INT("MSPL_PYR_STREAM", 1) == 0);
     // maps narrower than ~half a wave leave most lanes idle: the LDS-tiled form is faster there (18x30: 12 vs 17 us)
-    static const int min_w = getenv("MSPL_PYR_STREAM_MINW") ? atoi(getenv("MSPL_PYR_STREAM_MINW")) : 40;
+    static const int min_w = MSPL_TUNE_INT("MSPL_PYR_STREAM_MINW", 40);
     if (off || nb != 5 || w < min_w || ((int64_t)N * P) % 4 != 0) return 1;
     if (e.pre_add || e.residual || e.reinf_r || e.gate) return 1;    // only the scale/shift/PReLU epilogue
     // branch pattern: up, up, same, down, down (strictly)
@@ -406,7 +406,7 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
     g.ncb = ceil_div(w, g.CBW);
     // rows per segment: enough waves to put >= 2 on every SIMD when the maps allow, halo rows (2 of SEG + 2 branch rows, 6 of
     // SEG + 6 x rows) kept small otherwise
-    static const int dbg_seg = getenv("MSPL_PYR_SEG") ? atoi(getenv("MSPL_PYR_SEG")) : 0;
+    static const int dbg_seg = MSPL_TUNE_INT("MSPL_PYR_SEG", 0);
     int seg = std::min(h, P3_SEGMAX);
     while (seg > 6 && (int64_t)N * P * g.ncb * ceil_div(h, seg) < 2048) --seg;
     seg = ceil_div(h, ceil_div(h, seg));

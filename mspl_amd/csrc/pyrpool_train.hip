@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream_kernel(const float*
 static int pyr_branch_bwd_stream_try(const float* x, const float* gt, const float* wst, const float* add0, const float* add1, int N,
                                      int P, int h, int w, int hs, int ws, int accumulate, float* gx, float* gw, hipStream_t stream,
                                      bool dry) {
-    static const int off = getenv("MSPL_PYR_BWD_STREAM") ? atoi(getenv("MSPL_PYR_BWD_STREAM")) == 0 : 0;
+    static const int off = (MSPL_TUNE_INT("MSPL_PYR_BWD_STREAM", 1) == 0);
     if (off || (w & 1) || ((int64_t)N * P) % 4 != 0 || hs < h || ws < w || h < 2 || w < 2) return 1;
     if (!dry && ((((uintptr_t)gx) | ((uintptr_t)add0) | ((uintptr_t)add1)) & 7)) return 1;
     // (a branch of the map's own size is the plain 3x3: its coefficient tables have one unit entry inside the 3-tap band)
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
 static int pyr_branch_bwd_stream3_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
                                       const float* const* stage_w, const float* const* gt, float* const* gw, const float* add0,
                                       const float* add1, float* gx, hipStream_t stream, bool dry) {
-    static const int off = getenv("MSPL_PYR_BWD_STREAM3") ? atoi(getenv("MSPL_PYR_BWD_STREAM3")) == 0 : 0;
+    static const int off = (MSPL_TUNE_INT("MSPL_PYR_BWD_STREAM3", 1) == 0);
     if (off || (w & 1) || w < 2 || h < 2 || ((int64_t)N * P) % 4 != 0 || nb < 1 || nb > 3) return 1;
     const bool same = hs[nb - 1] == h && ws[nb - 1] == w;
     const int nup = nb - (same ? 1 : 0);

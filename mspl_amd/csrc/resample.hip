@@ -430,7 +430,7 @@ extern "C" int mspl_bilinear_fwd(const float* x, int32_t N, int32_t C, int32_t H
     }
     {   // register-streaming form: rows of whole 16-byte strips, at most one wave wide, enough rows to walk
         auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
-        static const int no_stream = getenv("MSPL_BILINEAR_STREAM") ? atoi(getenv("MSPL_BILINEAR_STREAM")) == 0 : 0;
+        static const int no_stream = (MSPL_TUNE_INT("MSPL_BILINEAR_STREAM", 1) == 0);
         if (!no_stream && (Wo & 3) == 0 && g.XS <= 64 && Ho >= 8 && al16(out) && al16(e.pre_add) && al16(e.residual) && al16(e.reinf_r) &&
             (int64_t)Hi * Wi < (1ll << 29) && (int64_t)Ho * Wo < (1ll << 29)) {
             BsGeom b;

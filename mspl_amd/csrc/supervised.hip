@@ -682,7 +682,7 @@ extern "C" int mspl_bn_batch_stats_fused_fwd(const float* z, int32_t N, int32_t 
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0 && N <= 65535 && C <= 65535, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: bad shape N=%d C=%d HW=%d",
                  N, C, HW);
     MSPL_REQUIRE(((uintptr_t)ws_zeroed & 7) == 0, MSPL_ERR_BAD_SHAPE, "bn_batch_stats_fused: workspace must be 8-byte aligned");
-    static const int target = getenv("MSPL_BN_BLOCKS") ? atoi(getenv("MSPL_BN_BLOCKS")) : 768;
+    static const int target = MSPL_TUNE_INT("MSPL_BN_BLOCKS", 768);
     const int64_t units = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW);
     int64_t parts = ceil_div64(target, C);
     if (parts > units / 512) parts = units / 512;

@@ -1168,7 +1168,7 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
     }
     const int64_t total = (int64_t)N * g.Ho * g.Wo;
     if (K == 1) {
-        static const bool no_mfma = getenv("MSPL_WGRAD_LDS") != nullptr;      // A/B aid: force the 16x16 LDS kernel
+        static const bool no_mfma = MSPL_TUNE_INT("MSPL_WGRAD_LDS", 0) != 0;      // A/B aid: force the 16x16 LDS kernel
         if (!no_mfma && conv1x1_wgrad_mfma_try(gy, x, N, groups, g.cout_g, g.cin_g, g.Ho * g.Wo, gw, s) == 0) {
             MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1, mfma)");
             return MSPL_OK;
@@ -1184,7 +1184,7 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_CHECK_LAUNCH("conv_bwd_weight(1x1)");
         return MSPL_OK;
     }
-    static const int s2_strip = getenv("MSPL_G3X3_WGRAD_S2STRIP") ? atoi(getenv("MSPL_G3X3_WGRAD_S2STRIP")) : 1;
+    static const int s2_strip = MSPL_TUNE_INT("MSPL_G3X3_WGRAD_S2STRIP", 1);
     if (s2_strip && K == 3 && g.cin_g == 3 && g.cout_g % 4 == 0 && Cout >= 16 && g.stride == 2 && g.dil == 1 && g.pad == 1 && (g.W & 7) == 0 &&
         (g.H & 1) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0) {
         const int64_t strips = total / 4;
@@ -1202,7 +1202,7 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         MSPL_CHECK_LAUNCH("conv_bwd_weight(3x3, few input channels, 4 output channels per workgroup)");
         return MSPL_OK;
     }
-    static const int strip_form = getenv("MSPL_G3X3_WGRAD_STRIP") ? atoi(getenv("MSPL_G3X3_WGRAD_STRIP")) : 1;
+    static const int strip_form = MSPL_TUNE_INT("MSPL_G3X3_WGRAD_STRIP", 1);
     if (strip_form && K == 3 && (g.cin_g <= 5 || g.cin_g == 8) && g.stride == 1 && g.dil == 1 && g.pad == 1 && (g.W & 3) == 0 &&
         ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0) {
         const int64_t strips = total / 4;
@@ -1253,7 +1253,7 @@ static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const f
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
     // ~MSPL_AFF_BLOCKS workgroups (default 768: three per CU keep the memory system busy with two 16-byte loads per operand in
     // flight per thread), at least ~2 units per thread, and as few same-address atomic chains per channel as that allows
-    static const int target = getenv("MSPL_AFF_BLOCKS") ? atoi(getenv("MSPL_AFF_BLOCKS")) : 768;
+    static const int target = MSPL_TUNE_INT("MSPL_AFF_BLOCKS", 768);
     const int64_t units = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW);
     int64_t parts = ceil_div64(target, C);
     if (parts > units / 512) parts = units / 512;
@@ -1433,7 +1433,7 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
     const int64_t total = (int64_t)N * C * Hi * Wi;
     // candidate window per input pixel is 2/scale + 3 wide: beyond 12 columns a wave per input pixel is the better shape
     const bool wide = g.sw <= 0.f || 2.0f / g.sw + 3.0f > 12.0f;
-    static const int rows_form = getenv("MSPL_BILINEAR_BWD_ROWS") ? atoi(getenv("MSPL_BILINEAR_BWD_ROWS")) : 1;
+    static const int rows_form = MSPL_TUNE_INT("MSPL_BILINEAR_BWD_ROWS", 1);
     if (wide && rows_form && Wo <= 8192 && (int64_t)N * C * Hi < (1ll << 31)) {
         hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3((unsigned)((int64_t)N * C * Hi)), dim3(256), (size_t)Wo * sizeof(float),
                            (hipStream_t)stream, gy, g, gx);
@@ -1447,7 +1447,7 @@ extern "C" int mspl_bilinear_bwd(const float* gy, int32_t N, int32_t C, int32_t 
         return MSPL_OK;
     }
     const int planes = N * C, gyd = planes < 65535 ? planes : 65535;
-    static const int tile_form = getenv("MSPL_BILINEAR_BWD_TILE") ? atoi(getenv("MSPL_BILINEAR_BWD_TILE")) : 1;
+    static const int tile_form = MSPL_TUNE_INT("MSPL_BILINEAR_BWD_TILE", 1);
     if (tile_form && g.sh > 0.f && g.sw > 0.f) {
         // candidate windows (rows and columns) of at most 8 (x2) or 12 (x4): the tiled separable form
         const float cw = 2.0f / g.sw + 3.0f, rw = 2.0f / g.sh + 3.0f;
@@ -1554,7 +1554,7 @@ static int uw_loss_launch(const float* pred, const float* aux, const int64_t* ta
     const int64_t total = (int64_t)N * HW;
     // (measured, one atomic per workgroup: 16 x 5 x 256x480 two heads 156 / 105 / 95 / 92 / 112 us at 512 / 1024 / 2048 / 4096 / 7680
     // workgroups; the 4-image micro-batches of the graphed step 32 / 28 / 36 us at 512 / 1024 / 1920)
-    static const int max_blocks = getenv("MSPL_LOSS_BLOCKS") ? atoi(getenv("MSPL_LOSS_BLOCKS")) : 1024;
+    static const int max_blocks = MSPL_TUNE_INT("MSPL_LOSS_BLOCKS", 1024);
     const int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), max_blocks);
     hipLaunchKernelGGL(uw_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, aux, target,
                        class_weights, N, C, HW, ce_scale, out_scale / (float)total, loss_acc, gpred, gaux, kld_out);

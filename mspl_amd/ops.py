@@ -61,8 +61,10 @@ class launch_flags(object):
     """with launch_flags(throughput=True): every op issued by this thread asks for launch shapes that favour steady-state
     efficiency over the latency of a lone launch (PipelinedLabelPass captures its lanes like this).  Results never change."""
 
-    def __init__(self, throughput=False):
+    def __init__(self, throughput=False, k2_stream=None):
         self.value = nat.LAUNCH_THROUGHPUT if throughput else 0
+        if k2_stream is not None:       # False: never the streaming form of the stride-2 depthwise launch; True: whenever the shape allows
+            self.value |= nat.LAUNCH_K2_STREAM_FORCE if k2_stream else nat.LAUNCH_K2_STREAM_OFF
 
     def __enter__(self):
         self.prev = getattr(_LAUNCH, 'flags', 0)

@@ -46,7 +46,7 @@ def test_eesp_dw_hff(dil, stride, shape):
 
 @pytest.mark.parametrize('dil', [[1, 2, 3, 4], [1, 1, 2, 3]])
 @pytest.mark.parametrize('shape', [(2, 3, 144, 240), (3, 5, 70, 248), (5, 2, 37, 120), (1, 2, 9, 504), (2, 4, 64, 8)])
-def test_eesp_dw_hff_stride2_streaming_form(dil, shape, monkeypatch):
+def test_eesp_dw_hff_stride2_streaming_form(dil, shape):
     """The register-streaming stride-2 kernel (forced: these planes are too few for its automatic choice) against the same
     reference, and bit-identical to the direct / tiled forms (same summation order per accumulator)."""
     from mspl_amd import ops
@@ -61,16 +61,16 @@ def test_eesp_dw_hff_stride2_streaming_form(dil, shape, monkeypatch):
         outs.append(o if k == 0 else o + outs[-1])
     ref = F.prelu(torch.cat(outs, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha)
     ep = Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV))
-    monkeypatch.setenv('MSPL_DW_STREAM', '0')
-    base = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
-    monkeypatch.setenv('MSPL_DW_STREAM', '2')
-    got = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
-    raw = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2)
-    # into a channel slice of a wider destination
-    dst = torch.full((N, 4 * n + 3, got.shape[2], got.shape[3]), -5.0, device=DEV)
-    sc2, sh2, al2 = torch.ones(4 * n + 3), torch.zeros(4 * n + 3), torch.ones(4 * n + 3)
-    sc2[2:2 + 4 * n], sh2[2:2 + 4 * n], al2[2:2 + 4 * n] = scale, shift, alpha
-    ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, Epi(sc2.to(DEV), sh2.to(DEV), al2.to(DEV)), out=(dst, 2))
+    with ops.launch_flags(k2_stream=False):
+        base = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
+    with ops.launch_flags(k2_stream=True):
+        got = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, ep)
+        raw = ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2)
+        # into a channel slice of a wider destination
+        dst = torch.full((N, 4 * n + 3, got.shape[2], got.shape[3]), -5.0, device=DEV)
+        sc2, sh2, al2 = torch.ones(4 * n + 3), torch.zeros(4 * n + 3), torch.ones(4 * n + 3)
+        sc2[2:2 + 4 * n], sh2[2:2 + 4 * n], al2[2:2 + 4 * n] = scale, shift, alpha
+        ops.eesp_dw_hff(x.to(DEV), w.to(DEV), dil, 2, Epi(sc2.to(DEV), sh2.to(DEV), al2.to(DEV)), out=(dst, 2))
     close(got, ref)
     close(raw, torch.cat(outs, 1))
     assert torch.equal(got, base)

@@ -373,3 +373,16 @@ def test_settle_seating_decision_on_injected_timings():
     # exactly at the threshold counts as settled
     d, _ = run(SETTLE_THRESHOLD * serial, [])
     assert d['settled']
+
+
+def test_product_library_reads_no_environment():
+    """include/mspl_hip.h promises a library without global mutable state: the default build imports neither getenv (the ~70 tuning
+    switches of rounds 1-4 are compiled to their defaults; `make TUNING=1` builds libmspl_hip_tuning.so for the probes) nor
+    hipMalloc (it never allocates device memory; the stamp buffers exist in `make STAMPS=1` builds only)."""
+    import subprocess
+    undefined = subprocess.run(['nm', '-D', '--undefined-only', _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {ln.split()[-1].split('@')[0] for ln in undefined.splitlines() if ln.strip()}
+    assert 'getenv' not in names and 'secure_getenv' not in names
+    assert not any(n.startswith('hipMalloc') for n in names)
+    blob = open(_native.LIB_PATH, 'rb').read()
+    assert b'MSPL_PW_' not in blob and b'MSPL_DW_' not in blob and b'MSPL_PYR_' not in blob
