@@ -263,6 +263,52 @@ def three_source_rate(dev, iters=24):
     return out
 
 
+def cityscapes_rate(dev, iters=12):
+    """The label pass away from the tuned shape: ESPDNet-UE s=2.0 C=20 on Cityscapes-shaped 16 x 3 x 512 x 1024 batches
+    (train_espdnetue_city.sh:6 trains at 512x256 and evaluates at 1024x512; BASELINE.md section 3: 1 392.2 MB of algorithmic
+    activation traffic per image).  64 columns at level 4 and 128 at level 3: the stride-1 EESP blocks take the fused K2 + K3
+    launch with one row per band / two half-row bands per row (csrc/eesp_exp.hip kinds 5 / 6).  hipGraph replay, three launches in
+    flight, one batch per launch (a batch of 16 is already four times the pixels of the headline's).  Extra field."""
+    import torch
+    from mspl_amd import models, ops, uest
+    from tests.synth import synth_state_dict
+    a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
+    m = models.ESPDNetwithUncertaintyEstimation(a, classes=20, dataset='city', fix_pyr_plane_proj=True)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 4))
+    x = torch.randn(BATCH, 3, 512, 1024, generator=torch.Generator().manual_seed(22)).to(dev)
+    bytes_img = 1392.2e6
+    out = {'workload': 'ESPDNet-UE s=2.0 C=20 single-source label pass, 16 x 3 x 512 x 1024 fp32 (Cityscapes shape), hipGraph replay',
+           'unit': 'images/s',
+           'fused_eesp_launch': bool(ops.eesp_dw_exp_fits((BATCH, 128, 32, 64), [1, 1, 2, 3]) and
+                                     ops.eesp_dw_exp_fits((BATCH, 64, 64, 128), [1, 2, 3, 4]))}
+    for depth in (1, 3):
+        plp = uest.PipelinedLabelPass(lambda: uest.SelfLabelPass(m, classes=20, device=dev, use_graph=True, with_kld=False),
+                                      depth=depth, device=dev, group=1)
+        for _ in range(2 * depth + 1):
+            plp(x)
+        list(plp.flush())
+        samples = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                plp(x)
+            list(plp.flush())
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) / iters)
+        dt = sorted(samples)[1]
+        out['in_flight_%d' % depth] = {'value': round(BATCH / dt, 1), 'ms_per_batch': round(dt * 1e3, 3),
+                                       'path_roofline_frac': round(bytes_img * BATCH / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        pixels = int(plp.hist.sum())
+        del plp
+    out['value'] = out['in_flight_3']['value']
+    out['pixels_counted_ok'] = pixels == (3 * iters + 2 * 3 + 1) * BATCH * 512 * 1024
+    out['path_roofline'] = {'algorithmic_bytes_per_image': bytes_img, 'achieved': round(bytes_img * out['value'] / 1e9, 1),
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(bytes_img * out['value'] / 1e9 / HBM_PEAK_GBS, 4),
+                            'source': 'BASELINE.md section 3 (SURVEY 8(d) accounting at 512x1024, C=20)'}
+    return out
+
+
 SUPERVISED_BYTES_PER_IMAGE = 947.7e6     # tools/train_bytes.py 13 288 480: the same accounting for C=13 at 288x480
 EVAL_BYTES_PER_IMAGE = 306.7e6           # forward of the C=5 model at 256x480 (305.7 MB, tools/train_bytes.py) + the int64 labels (8 B / pixel)
 TRAIN_BYTES_PER_IMAGE = 820.5e6          # DESIGN.md section 7 / tools/train_bytes.py: forward (305.7 MB, = SURVEY 8(d)'s 306.9) + data-gradient + weight-gradient
@@ -945,6 +991,7 @@ def main():
                 out[name] = {'error': repr(e_)[:300]}
         if world == 1 and not args.no_three_source:
             extra('three_source', three_source_rate, dev)
+            extra('cityscapes_512x1024', cityscapes_rate, dev)
         if world == 1 and not args.no_train:
             extra('train_step', train_step_rate, dev)
             extra('eval_step', eval_step_rate, dev)

@@ -98,7 +98,10 @@ __global__ void eesp_exp_pack_next_kernel(const float* __restrict__ w1, int n, f
 // waves per workgroup (one of each per SIMD) does NOT overlap the two kinds of work -- the depthwise waves' step got 1.2 us
 // longer exactly while the matrix waves' 1.1 us of v_mfma_f32_32x32x2_f32 ran: the fp32 MFMA runs at the vector rate and holds
 // the SIMD's vector issue.  So every wave does both, and a step costs (vector work) + (matrix work) per SIMD.
-template <int NCH, int W, int TH, int KC, int GPW, class DS, bool NEXT>
+// W is the width of a BAND; WI the width of the image.  WI == W: a band is TH whole rows (every shape of rounds 4).  WI == 2 W (TH = 1):
+// a band is half a row -- 1024-pixel-wide inputs have 128 columns at level 3, twice what the 64-pixel matrix tile holds; the staged
+// rows then carry REAL halo columns on the inner side (staged per chunk, P float2 more per row), zero ones on the image border.
+template <int NCH, int W, int TH, int KC, int GPW, class DS, bool NEXT, int WI = W>
 __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __restrict__ r, const float* __restrict__ dwp,
                                                              const float* __restrict__ ap, const float* __restrict__ escale,
                                                              const float* __restrict__ eshift, const float* __restrict__ ealpha,
@@ -115,7 +118,9 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     constexpr int RTPG = NCH / 32;             // 32-row tiles per group
     constexpr int NPW = 4 / GPW;               // workgroups per band
     constexpr int PXV = TH * W;                // pixels of a band
-    constexpr int HW2 = W / 2;
+    constexpr bool SPLIT = WI != W;            // half-row bands
+    static_assert(!SPLIT || (WI == 2 * W && TH == 1), "half-row bands: TH = 1, two bands per row");
+    constexpr int HW2 = SPLIT ? (W + 2 * 4) / 2 : W / 2;      // float2 items of a staged row (SPLIT: with the halo columns)
     constexpr int ITEMS = KC * ROWS * HW2;     // float2 items of a staged chunk
     constexpr int IPT = (ITEMS + 511) / 512;
     constexpr int CPW = KC / 8;                // channels per wave and chunk in the depthwise stage
@@ -147,8 +152,9 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     const int gs = lid % NPW;  lid /= NPW;
     const int band = lid % bands;
     const int img = lid / bands;
-    const int y0 = band * TH;
-    const int HW = H * W;
+    const int y0 = SPLIT ? band >> 1 : band * TH;
+    const int x0 = SPLIT ? (band & 1) * W : 0;           // first image column of the band
+    const int HW = H * WI;
     const int g_first = gs * GPW;
 
     const int gl = wave / RTPG, rtile = wave % RTPG;     // matrix stage: this wave's group (local) and row tile
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
 
     // ---- staging (L): chunk c of the reduced tensor, rows y0 - MAXD .. y0 + TH - 1 + MAXD of KC channels
     const float* rimg = r + (size_t)img * NCH * HW;
-    const int glin0 = (y0 - MAXD) * HW2;                 // float2 index of the first staged row inside a plane (may be negative)
+    const int glin0 = (y0 - MAXD) * (W / 2);             // float2 index of the first staged row inside a plane (may be negative)
     float2 sv[IPT];
     auto load_chunk = [&](int c) {
         const float* rc = rimg + (size_t)c * KC * HW;
@@ -166,11 +172,20 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
             const int ic = i < ITEMS ? i : 0;
             const int j = ic / (ROWS * HW2);
             const int rem = ic - j * (ROWS * HW2);
-            const int gl2 = glin0 + rem;
-            const bool ok = gl2 >= 0 && gl2 < H * HW2;
-            const int gc = ok ? gl2 : 0;
-            const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + 2 * gc);   // unconditional load from a clamped address
-            sv[q] = ok ? v : make_float2(0.f, 0.f);
+            if (!SPLIT) {
+                const int gl2 = glin0 + rem;
+                const bool ok = gl2 >= 0 && gl2 < H * HW2;
+                const int gc = ok ? gl2 : 0;
+                const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + 2 * gc);   // unconditional load from a clamped address
+                sv[q] = ok ? v : make_float2(0.f, 0.f);
+            } else {
+                const int row = rem / HW2, c2 = rem - row * HW2;
+                const int gy = y0 - MAXD + row, gx = x0 - 4 + 2 * c2;                   // (P = 4: float2-aligned columns)
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < WI;
+                const int go = ok ? gy * WI + gx : 0;
+                const float2 v = *reinterpret_cast<const float2*>(rc + (size_t)j * HW + go);
+                sv[q] = ok ? v : make_float2(0.f, 0.f);
+            }
         }
     };
     auto store_chunk = [&](float* dst) {
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
                 const int j = i / (ROWS * HW2);
                 const int rem = i - j * (ROWS * HW2);
                 const int row = rem / HW2, c2 = rem - row * HW2;
-                *reinterpret_cast<float2*>(dst + (j * ROWS + row) * RS + P + 2 * c2) = sv[q];
+                *reinterpret_cast<float2*>(dst + (j * ROWS + row) * RS + (SPLIT ? 0 : P) + 2 * c2) = sv[q];
             }
         }
     };
@@ -252,10 +267,12 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     // ---- prologue: zero the halo columns of both row buffers (never overwritten), chunk 0 -> LDS, branches of chunk 0
     load_chunk(0);
     load_a(0, a_cur);
-    for (int i = tid; i < 2 * KC * ROWS * 2 * P; i += 512) {
-        const int c8 = i % (2 * P);
-        const int rr = i / (2 * P);                              // (buffer, channel, row) flattened
-        lds_[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
+    if (!SPLIT) {
+        for (int i = tid; i < 2 * KC * ROWS * 2 * P; i += 512) {
+            const int c8 = i % (2 * P);
+            const int rr = i / (2 * P);                              // (buffer, channel, row) flattened
+            lds_[rr * RS + (c8 < P ? c8 : W + c8)] = 0.f;
+        }
     }
     store_chunk(rt_[0]);
     load_chunk(1);
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     const int rows_here = (H - y0) < TH ? (H - y0) : TH;
     const bool pok = 2 * li < rows_here * W;
     const int ch0 = g * NCH + rtile * 32 + 4 * half;
-    const size_t obase = ((size_t)img * 4 * NCH + ch0) * HW + (size_t)y0 * W + 2 * li;
+    const size_t obase = ((size_t)img * 4 * NCH + ch0) * HW + (size_t)y0 * WI + x0 + 2 * li;
     float2 resv[16];
     constexpr int M1 = NCH / 4;                                    // rows of a group of the next projection
     constexpr int RPW = 16 / RTPG;                                 // accumulator registers of the next stage that a wave finishes
@@ -403,7 +420,7 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
                 float v0 = fmaf(sres[0][q], sc, sh), v1 = fmaf(sres[1][q], sc, sh);
                 v0 = v0 > 0.f ? v0 : al * v0;
                 v1 = v1 > 0.f ? v1 : al * v1;
-                *reinterpret_cast<float2*>(rnext + ((size_t)img * NCH + ch) * HW + (size_t)y0 * W + 2 * li) = make_float2(v0, v1);
+                *reinterpret_cast<float2*>(rnext + ((size_t)img * NCH + ch) * HW + (size_t)y0 * WI + x0 + 2 * li) = make_float2(v0, v1);
             }
         }
     }
@@ -421,16 +438,22 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
 
 // ------------------------------------------------------------------ host side
 struct XePlan {
-    int kind;        // 0: none; 1: n = 128, W = 30; 2: n = 64, W = 60 (288x480 / 256x480 inputs); 3: n = 128, W = 32; 4: n = 64, W = 64 (512-wide inputs)
+    int kind;        // 0: none; 1: n = 128, W = 30; 2: n = 64, W = 60 (288x480 / 256x480 inputs); 3: n = 128, W = 32; 4: n = 64, W = 64 (512-wide inputs);
+                     // 5: n = 128, W = 64; 6: n = 64, W = 128 as half-row bands (1024-wide inputs)
     int TH, KC, GPW;
+    int split;       // bands per row (1, or 2 for half-row bands)
 };
 
 static XePlan xe_plan(int n, int H, int W, const int32_t* dil) {
-    XePlan p = {0, 0, 0, 0};
+    XePlan p = {0, 0, 0, 0, 1};
     if (H < 1) return p;
     const bool d1123 = dil[0] == 1 && dil[1] == 1 && dil[2] == 2 && dil[3] == 3, d1234 = dil[0] == 1 && dil[1] == 2 && dil[2] == 3 && dil[3] == 4;
     if (n == 128 && d1123 && (W == 30 || W == 32)) { p.kind = W == 30 ? 1 : 3; p.TH = 2; p.KC = 16; p.GPW = 2; }
     else if (n == 64 && d1234 && (W == 60 || W == 64)) { p.kind = W == 60 ? 2 : 4; p.TH = 1; p.KC = 8; p.GPW = 4; }
+    // 1024-pixel-wide inputs (Cityscapes 1024x512, train_espdnetue_city.sh:6): 64 columns at level 4 (one row per band), 128 at level 3
+    // (two half-row bands per row)
+    else if (n == 128 && d1123 && W == 64) { p.kind = 5; p.TH = 1; p.KC = 16; p.GPW = 2; }
+    else if (n == 64 && d1234 && W == 128) { p.kind = 6; p.TH = 1; p.KC = 8; p.GPW = 4; p.split = 2; }
     return p;
 }
 
@@ -480,7 +503,7 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
     const bool next = next_packed != nullptr;
     MSPL_REQUIRE(!next || (nscale && nshift && nalpha && rnext), MSPL_ERR_NULL_POINTER,
                  "eesp_dw_exp: the next projection needs its packed weights, scale, shift, alpha and a destination");
-    const int bands = ceil_div(H, p.TH);
+    const int bands = ceil_div(H, p.TH) * p.split;
     const int64_t nwg = (int64_t)N * bands * (4 / p.GPW);
     MSPL_REQUIRE(nwg < (1ll << 30), MSPL_ERR_BAD_SHAPE, "eesp_dw_exp: grid too large");
     const float* dwp = packed;
@@ -499,7 +522,9 @@ static int xe_launch(const float* r, const float* packed, const int32_t dil[4], 
     if (p.kind == 1) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 30, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
     else if (p.kind == 2) hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 60, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), XE_ARGS); \
     else if (p.kind == 3) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 32, 2, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
-    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 64, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), XE_ARGS); } while (0)
+    else if (p.kind == 4) hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 64, 1, 8, 4, XDil<1, 2, 3, 4>, NX>), XE_ARGS); \
+    else if (p.kind == 5) hipLaunchKernelGGL((eesp_dw_exp_kernel<128, 64, 1, 16, 2, XDil<1, 1, 2, 3>, NX>), XE_ARGS); \
+    else hipLaunchKernelGGL((eesp_dw_exp_kernel<64, 64, 1, 8, 4, XDil<1, 2, 3, 4>, NX, 128>), XE_ARGS); } while (0)
     if (next) XE_GO(true); else XE_GO(false);
 #undef XE_GO
 #undef XE_ARGS

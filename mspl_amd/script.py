@@ -37,11 +37,9 @@ def _target_loader(args):
 
 
 def _mode(args):
-    """:749-752 / :871-876.  The label passes put their models in eval() themselves; `--eval-training` (batch-statistics BatchNorm
-    at batch size 1 under no_grad) has no fused inference form and fails loudly instead of silently labelling in eval mode."""
-    if getattr(args, 'eval_training', False):
-        raise RuntimeError('mspl_amd: --eval-training (label generation with BatchNorm in train() mode) is not supported: the '
-                           'inference kernels fold the running statistics (DESIGN.md section 1)')
+    """:749-752 / :871-876: `--eval-training` labels with the models in train() mode (BatchNorm with the statistics of each single
+    image -- the reference's loader has batch size 1); otherwise eval()."""
+    return bool(getattr(args, 'eval_training', False))
 
 
 def _log(logger, round_idx):
@@ -52,11 +50,11 @@ def _log(logger, round_idx):
 def generate_pseudo_label(model, device, save_path, round_idx, tgt_num=None, label_2_id=None, valid_labels=None, args=None,
                           logger=None, class_encoding=None, writer=None, testloader=None):
     """uest_seg_multi_os.py:730-830 with its own signature; returns (tgt_train_lst, class_weights float32 on `device`)."""
-    _mode(args)
+    eval_training = _mode(args)
     loader = testloader if testloader is not None else _target_loader(args)
     _log(logger, round_idx)
     lst, w = uest.generate_pseudo_label(
-        model, loader, save_path, classes=args.classes, class_weighting=getattr(args, 'class_weighting', 'normal'),
+        model, loader, save_path, eval_training=eval_training, classes=args.classes, class_weighting=getattr(args, 'class_weighting', 'normal'),
         use_depth=getattr(args, 'use_depth', False), device=device, in_flight=int(getattr(args, 'label_in_flight', 3)),
         batches_per_launch=int(getattr(args, 'label_batches_per_launch', 2)))
     print('class_weights : {}'.format(w.cpu().numpy()))   # :826
@@ -66,11 +64,11 @@ def generate_pseudo_label(model, device, save_path, round_idx, tgt_num=None, lab
 def generate_pseudo_label_multi_model(model_list, os_data_list, device, save_path, round_idx, tgt_num=None, label_2_id=None,
                                       valid_labels=None, args=None, logger=None, class_encoding=None, writer=None, testloader=None):
     """uest_seg_multi_os.py:832-956 with its own signature."""
-    _mode(args)
+    eval_training = _mode(args)
     loader = testloader if testloader is not None else _target_loader(args)
     _log(logger, round_idx)
     lst, w = uest.generate_pseudo_label_multi_model(
-        model_list, os_data_list, loader, save_path, classes=args.classes,
+        model_list, os_data_list, loader, save_path, eval_training=eval_training, classes=args.classes,
         merge_label_policy=getattr(args, 'merge_label_policy', 'all'), class_weighting=getattr(args, 'class_weighting', 'normal'),
         use_depth=getattr(args, 'use_depth', False), device=device, in_flight=int(getattr(args, 'label_in_flight', 3)),
         batches_per_launch=int(getattr(args, 'label_batches_per_launch', 1)))

@@ -42,6 +42,21 @@ def _lowres(model, image, pyr=None):
     return out if isinstance(out, tuple) else (out, None)
 
 
+def _lowres_batch_stats(model, images, pyr=None):
+    """`--eval-training` label generation (uest_seg_multi_os.py:749-752, 871-876): the model is in train() mode under no_grad, so
+    every BatchNorm normalises with the statistics of ITS OWN batch -- and the reference's loader has batch size 1 (:746), so the
+    statistics are per image.  Reproduced image by image through the batch-statistics forward kernels (the autograd form of the
+    layers: the inference kernels fold RUNNING statistics and cannot serve this mode); the running statistics receive the same
+    momentum updates as in the reference.  Returns the heads of the whole batch."""
+    mains, auxs = [], []
+    for k in range(images.shape[0]):
+        with torch.enable_grad():
+            main, aux = _lowres(model, images[k:k + 1], pyr)
+        mains.append(main.detach())
+        auxs.append(None if aux is None else aux.detach())
+    return torch.cat(mains), (None if auxs[0] is None else torch.cat(auxs))
+
+
 def get_output(model, image, model_name='espdnetue', device='cuda'):
     """Drop-in for uest_seg_multi_os.get_output: (softmax(pred + 0.5*aux) of batch element 0 as a numpy
     (C,H,W) array, KL(pred||aux) map as numpy (H,W)).  The upsample, the softmax and the KLD run in one
@@ -213,10 +228,12 @@ class PseudoLabelPass(_GraphedPassMixin):
     """
 
     def __init__(self, model_list, os_data_list, classes=GREENHOUSE_CLASSES, merge_label_policy='all',
-                 device='cuda', use_graph=False):
+                 device='cuda', use_graph=False, eval_training=False):
         if len(model_list) != len(os_data_list) or not model_list:
             raise ValueError('model_list and os_data_list must be non-empty and of equal length')
-        self.models = [m.to(device).eval() for m in model_list]
+        # eval_training: args.eval_training of the reference (:871-876): models in train() mode, per-image batch statistics
+        self.eval_training = bool(eval_training)
+        self.models = [(m.to(device).train() if self.eval_training else m.to(device).eval()) for m in model_list]
         self.os_data = list(os_data_list)
         self.classes = classes
         self.thresh = resolve_thresh(len(model_list), merge_label_policy)
@@ -226,7 +243,7 @@ class PseudoLabelPass(_GraphedPassMixin):
             lut = LUTS.get(d)
             self.luts.append(None if lut is None else torch.from_numpy(lut.astype(np.uint8)).to(self.device))
         self.hist = torch.zeros(classes, dtype=torch.int64, device=self.device)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not self.eval_training      # (the running statistics change with every image: nothing to replay)
         self._graphs = {}
 
     def reset(self):
@@ -234,6 +251,11 @@ class PseudoLabelPass(_GraphedPassMixin):
 
     def _run(self, images):
         maps = []
+        if self.eval_training:
+            for m, lut in zip(self.models, self.luts):
+                main, aux = _lowres_batch_stats(m, images)
+                maps.append(ops.label_epilogue(main, aux, images.shape[2:], lut=lut)['labels'])
+            return ops.merge_labels(maps, self.classes, self.thresh, NO_AGREEMENT_CLASS, self.hist), maps
         # the average-pool pyramid of the batch (input reinforcement of every DownSampler) does not depend on the model: once per batch
         shared = all(hasattr(m, 'depth_base_net') and getattr(m.base_net, 'input_reinforcement', False) for m in self.models)
         pyr = layers.ImagePyramid(images) if shared and len(self.models) > 1 else None
@@ -576,7 +598,7 @@ def _label_loop(p, testloader, save_path, labels_of, class_weighting, use_depth,
 def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save_path, classes=GREENHOUSE_CLASSES,
                                       merge_label_policy='all', class_weighting='normal', use_depth=False, device='cuda',
                                       use_graph=True, writer_workers=None, in_flight=3, pre_sharded=False, _label_pass=None,
-                                      batches_per_launch=1, transform=None):
+                                      batches_per_launch=1, transform=None, eval_training=False):
     """uest_seg_multi_os.py:832-956 end to end: label every batch of `testloader` with all source models, merge, write
     `<save_path>/pred/<image_name>.png`, write `<save_path>/tgt_train.lst` and return (tgt_train_lst, class_weights).
 
@@ -595,14 +617,16 @@ def generate_pseudo_label_multi_model(model_list, os_data_list, testloader, save
     `group` (consecutive loader batches labelled by one launch; worth ~5 % at batch 16).  transform: see _label_loop."""
     p = _label_pass if _label_pass is not None else PipelinedLabelPass(
         lambda: PseudoLabelPass(model_list, os_data_list, classes=classes, merge_label_policy=merge_label_policy,
-                                device=device, use_graph=use_graph), depth=in_flight, device=device, group=batches_per_launch)
+                                device=device, use_graph=use_graph, eval_training=eval_training),
+        # eval_training: the images update the models' running statistics in loader order -- one lane, one batch per launch
+        depth=1 if eval_training else in_flight, device=device, group=1 if eval_training else batches_per_launch)
     return _label_loop(p, testloader, save_path, lambda out: out, class_weighting, use_depth, device, writer_workers, pre_sharded,
                        transform, _label_pass is not None)
 
 
 def generate_pseudo_label(model, testloader, save_path, classes=GREENHOUSE_CLASSES, class_weighting='normal', use_depth=False,
                           device='cuda', use_graph=True, writer_workers=None, in_flight=3, batches_per_launch=2, pre_sharded=False,
-                          _label_pass=None, transform=None):
+                          _label_pass=None, transform=None, eval_training=False):
     """uest_seg_multi_os.py:730-830 end to end, the single-model relabelling of every self-training round (called at :527-528):
     loader -> get_output (`softmax(pred + 0.5 aux)`, :795) -> argmax (:798) -> `class_array` (:800-801) -> `<save_path>/pred/<image_name>.png`
     (:803-811) -> path lists (:813-816) -> update_image_list (:820) -> class weights (:822-828); returns (tgt_train_lst, class_weights).
@@ -611,10 +635,12 @@ def generate_pseudo_label(model, testloader, save_path, classes=GREENHOUSE_CLASS
     monotone, the probabilities are never written -- and the class histogram), `in_flight` launches of `batches_per_launch` loader
     batches each overlap on the GPU, the PNG files are written by LabelWriter's native threads.  Loader tuples, rank sharding,
     `pre_sharded`, `_label_pass` and `transform` as in generate_pseudo_label_multi_model.  The reference's loader is batch size 1
-    (:746); BatchNorm is in eval mode, so any batch size gives the same maps."""
+    (:746); BatchNorm is in eval mode, so any batch size gives the same maps.  eval_training=True is the reference's
+    `--eval-training` (:749-752): train() mode under no_grad, i.e. BatchNorm with the statistics of each single image (and the
+    momentum updates of the running statistics that come with it) -- `_lowres_batch_stats`; one lane, no graph."""
     p = _label_pass if _label_pass is not None else PipelinedLabelPass(
-        lambda: SelfLabelPass(model, classes=classes, device=device, use_graph=use_graph, with_kld=False),
-        depth=in_flight, device=device, group=batches_per_launch)
+        lambda: SelfLabelPass(model, classes=classes, device=device, use_graph=use_graph, with_kld=False, eval_training=eval_training),
+        depth=1 if eval_training else in_flight, device=device, group=1 if eval_training else batches_per_launch)
     return _label_loop(p, testloader, save_path, lambda out: out[0] if isinstance(out, (tuple, list)) else out, class_weighting,
                        use_depth, device, writer_workers, pre_sharded, transform, _label_pass is not None)
 
@@ -625,12 +651,13 @@ class SelfLabelPass(_GraphedPassMixin):
     get_output computes (:691) -- kept on the device for the uncertainty-weighted loss instead of being
     copied to the host and dropped.  __call__(images) -> (labels uint8 (N,H,W), kld fp32 (N,H,W))."""
 
-    def __init__(self, model, classes=GREENHOUSE_CLASSES, device='cuda', use_graph=False, with_kld=True):
-        self.model = model.to(device).eval()
+    def __init__(self, model, classes=GREENHOUSE_CLASSES, device='cuda', use_graph=False, with_kld=True, eval_training=False):
+        self.eval_training = bool(eval_training)        # args.eval_training (:749-752): train() mode, per-image batch statistics
+        self.model = model.to(device).train() if self.eval_training else model.to(device).eval()
         self.classes = classes
         self.device = torch.device(device)
         self.hist = torch.zeros(classes, dtype=torch.int64, device=self.device)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not self.eval_training
         self.with_kld = with_kld
         self._graphs = {}
 
@@ -638,7 +665,7 @@ class SelfLabelPass(_GraphedPassMixin):
         self.hist.zero_()
 
     def _run(self, images):
-        main, aux = _lowres(self.model, images)
+        main, aux = _lowres_batch_stats(self.model, images) if self.eval_training else _lowres(self.model, images)
         if main.shape[1] <= min(24, self.classes, 32) and ops.label_epilogue_hist_fits(main, aux, images.shape[2:]):
             # every argmax is a counted class: the epilogue kernel accumulates the histogram itself (one launch; the S = 1 merge
             # would be the identity on these labels)

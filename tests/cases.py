@@ -108,4 +108,7 @@ LABEL_LOOP_CASES = {
     'multi3_all': ([(13, 'camvid', 'camvid', 61), (20, 'city', 'cityscapes', 62), (5, 'greenhouse', 'forest', 63)], (48, 64), 5, 720,
                    'all', 'normal'),
     'multi2_half': ([(13, 'camvid', 'camvid', 64), (5, 'greenhouse', 'forest', 65)], (32, 48), 4, 730, 'half', 'normal'),
+    # args.eval_training (:749-752, :871-876): models in train() mode under no_grad -> BatchNorm with the statistics of each single image
+    'self_c5_evaltrain': ([(5, 'greenhouse', None, 73)], (48, 64), 5, 740, None, 'normal', True),
+    'multi2_all_evaltrain': ([(13, 'camvid', 'camvid', 66), (5, 'greenhouse', 'forest', 67)], (48, 64), 3, 750, 'all', 'normal', True),
 }

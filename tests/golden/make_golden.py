@@ -474,7 +474,8 @@ def gen_label_loops():
     out, meta = {}, {}
     real_mod = sys.modules.get('data_loader.segmentation.greenhouse')
     for name, case in sorted(LABEL_LOOP_CASES.items()):
-        specs, (H, W), n, in_seed, policy, weighting = case
+        specs, (H, W), n, in_seed, policy, weighting = case[:6]
+        eval_training = len(case) > 6 and case[6]
         items = synth_label_loop_images(case)
 
         class StubDataset(data.Dataset):      # train=False item of GreenhouseRGBDSegmentation without depth (greenhouse.py:270)
@@ -495,7 +496,7 @@ def gen_label_loops():
             ms.append(m)
         args = argparse.Namespace(classes=5, test_image_size='%d,%d' % (H, W), eval_scale=1.0, dataset='greenhouse',
                                   data_tgt_train_list='unused.lst', use_traversable=False, use_depth=False, pin_memory=False,
-                                  eval_training=False, merge_label_policy=policy, class_weighting=weighting)
+                                  eval_training=eval_training, merge_label_policy=policy, class_weighting=weighting)
         ns['args'] = args
         save_path = tempfile.mkdtemp()
         os.makedirs(os.path.join(save_path, 'pred'))
@@ -508,7 +509,7 @@ def gen_label_loops():
                                                                        args, Log(), None, None)
                 margin = np.full((n, H, W), np.inf, dtype=np.float32)
                 for i, (x, _) in enumerate(items):
-                    for m in ms:
+                    for m in ms:                      # (still in the mode the function left them in: train() for eval_training)
                         prob, _ = ns['get_output'](m, x[None])
                         top = np.sort(prob, axis=0)
                         margin[i] = np.minimum(margin[i], top[-1] - top[-2])

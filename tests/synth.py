@@ -123,7 +123,7 @@ def grad_sample_index(numel):
 def synth_label_loop_images(case):
     """The seeded target-domain images of a tests.cases.LABEL_LOOP_CASES entry: [(image (3,H,W), name)] -- shared by the golden
     generator (which serves them to the reference's label loops through a stub dataset) and the tests."""
-    specs, (H, W), n, in_seed, policy, weighting = case
+    specs, (H, W), n, in_seed, policy, weighting = case[:6]
     return [(synth_input((3, H, W), in_seed + i), '/data/greenhouse/color/seq.%d/frame_%03d.v2.jpg' % (i % 2, i)) for i in range(n)]
 
 

@@ -79,7 +79,9 @@ def test_eesp_dw_hff_stride2_streaming_form(dil, shape):
 
 @pytest.mark.parametrize('cfg', [(2, 128, 18, 30, [1, 1, 2, 3]), (1, 128, 16, 30, [1, 1, 2, 3]), (3, 128, 5, 30, [1, 1, 2, 3]), (17, 128, 18, 30, [1, 1, 2, 3]),
                                  (2, 64, 36, 60, [1, 2, 3, 4]), (1, 64, 32, 60, [1, 2, 3, 4]), (3, 64, 3, 60, [1, 2, 3, 4]), (1, 64, 1, 60, [1, 2, 3, 4]),
-                                 (2, 128, 16, 32, [1, 1, 2, 3]), (1, 128, 7, 32, [1, 1, 2, 3]), (2, 64, 32, 64, [1, 2, 3, 4]), (1, 64, 5, 64, [1, 2, 3, 4])])
+                                 (2, 128, 16, 32, [1, 1, 2, 3]), (1, 128, 7, 32, [1, 1, 2, 3]), (2, 64, 32, 64, [1, 2, 3, 4]), (1, 64, 5, 64, [1, 2, 3, 4]),
+                                 # 1024-pixel-wide inputs: 64 columns at level 4 (one row per band), 128 at level 3 (two half-row bands per row)
+                                 (2, 128, 9, 64, [1, 1, 2, 3]), (1, 128, 1, 64, [1, 1, 2, 3]), (2, 64, 11, 128, [1, 2, 3, 4]), (1, 64, 2, 128, [1, 2, 3, 4])])
 def test_eesp_dw_exp(cfg):
     """K2 + K3 of a stride-1 EESP block in one launch (nn_layers/eesp.py:68-93) against torch fp32, and bit-identical to the
     two-launch form (same operation order in the branch arithmetic and in the matrix-core sums)."""
@@ -113,7 +115,8 @@ def test_eesp_dw_exp(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(2, 128, 18, 30, [1, 1, 2, 3]), (3, 128, 5, 30, [1, 1, 2, 3]), (17, 128, 18, 30, [1, 1, 2, 3]),
-                                 (2, 64, 36, 60, [1, 2, 3, 4]), (1, 64, 3, 60, [1, 2, 3, 4]), (2, 128, 16, 32, [1, 1, 2, 3]), (2, 64, 32, 64, [1, 2, 3, 4])])
+                                 (2, 64, 36, 60, [1, 2, 3, 4]), (1, 64, 3, 60, [1, 2, 3, 4]), (2, 128, 16, 32, [1, 1, 2, 3]), (2, 64, 32, 64, [1, 2, 3, 4]),
+                                 (2, 128, 9, 64, [1, 1, 2, 3]), (2, 64, 11, 128, [1, 2, 3, 4]), (1, 64, 1, 128, [1, 2, 3, 4])])
 def test_eesp_dw_exp_next_projection(cfg):
     """The fused K2 + K3 launch that also computes the FOLLOWING block's proj_1x1 (grouped 1x1 + BN + PReLU over its own output):
     the block output stays bit-identical to the launch without it, the reduced tensor equals conv1x1 on that output up to the

@@ -113,6 +113,34 @@ def test_zoo_real_weights_config1(golden):
     assert diff.mean() < 1e-3
 
 
+@pytest.mark.parametrize('shape', [(1, 3, 64, 1024), (2, 3, 48, 512), (1, 3, 32, 352)])
+def test_model_wide_inputs_fused_and_fallback(shape, monkeypatch):
+    """Cityscapes-shaped inputs (train_espdnetue_city.sh:6: 1024x512 and 512x256): the stride-1 EESP blocks take the fused K2 + K3 launch at
+    64 / 128 columns too (level 4: one row per band; level 3: two half-row bands per row) -- bit-identical to the three-launch form
+    when the next block's projection is left out (that stage differs in summation order), and equal to the CPU oracle.  352 columns
+    (22 / 44 at levels 4 / 3) are NOT covered by the fused launch: the blocks fall back to the three launches, same check."""
+    from mspl_amd import layers, ops
+    m = _build_model('espdnetue', 2.0, 20, 'city')
+    sd = synth_state_dict(KEYS['espdnetue_s2.0_c20'], 21)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = synth_input(shape, 77)
+    H, W = shape[2] // 16, shape[3] // 16
+    covered = ops.eesp_dw_exp_fits((shape[0], 128, H, W), [1, 1, 2, 3]) and ops.eesp_dw_exp_fits((shape[0], 64, 2 * H, 2 * W), [1, 2, 3, 4])
+    assert covered == (shape[3] in (512, 1024))
+    with torch.no_grad():
+        main, aux = m(x.to(DEV))
+        monkeypatch.setattr(layers, '_FUSED_NEXT_PROJ', False)
+        main1, aux1 = m(x.to(DEV))
+        monkeypatch.setattr(layers, '_FUSED_DW_EXP', False)
+        main0, aux0 = m(x.to(DEV))
+        rmain, raux = onet.espdnet_ue_forward(sd, x)
+    assert torch.equal(main1, main0) and torch.equal(aux1, aux0)          # K2 + K3 in one launch == the two launches, bit for bit
+    torch.testing.assert_close(main.cpu(), rmain, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(aux.cpu(), raux, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(main0.cpu(), rmain, rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize('S', [1, 2, 3, 4])
 @pytest.mark.parametrize('pol', ['all', 'half', 'none'])
 def test_merge_truth_table_bit_exact(S, pol, golden):

@@ -381,15 +381,16 @@ def test_script_level_generate_pseudo_label_reference_signature(tmp_path, monkey
         names = [['/t/color/img_%02d.png' % i for i in range(b, min(b + 2, 5))] for b in range(0, 5, 2)]
         fb = [np.stack(frames[b:b + 2]) for b in range(0, 5, 2)]
         _check_against_oracle_loop(sd, fb, names, (64, 48), lst, cw, save, False)
+        # --eval-training (:749-752): the adapter hands the flag on; the model is left in train() mode like the reference leaves it
         args.eval_training = True
-        with pytest.raises(RuntimeError, match='eval-training'):
-            ns['generate_pseudo_label'](m, 'cuda', save, 3, 5, None, None, args, Log(), None, None)
+        lst2, cw2 = ns['generate_pseudo_label'](m, 'cuda', save, 4, 5, None, None, args, Log(), None, None)
+        assert m.training and lst2 == lst and cw2.shape == cw.shape and not torch.equal(cw2, cw)
     finally:
         _purge_reference_names()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['self_c5', 'self_c5_unweighted', 'multi3_all', 'multi2_half'])
+@pytest.mark.parametrize('name', ['self_c5', 'self_c5_unweighted', 'multi3_all', 'multi2_half', 'self_c5_evaltrain', 'multi2_all_evaltrain'])
 def test_label_loop_functions_vs_reference_golden(tmp_path, name, golden):
     """generate_pseudo_label / generate_pseudo_label_multi_model against the REFERENCE's own functions (uest_seg_multi_os.py:730-830,
     :832-956, AST-extracted and run on CPU by tests/golden/make_golden.py gen_label_loops): list lines and order, decoded label files,
@@ -404,7 +405,9 @@ def test_label_loop_functions_vs_reference_golden(tmp_path, name, golden):
     from tests.synth import synth_label_loop_images, synth_state_dict
     g = golden('label_loops')
     lines = json.load(open(os.path.join(GOLDEN, 'label_loops.json')))[name]
-    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name]
+    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name][:6]
+    # the `--eval-training` cases (:749-752, :871-876): models in train() mode, BatchNorm with the statistics of each single image
+    eval_training = len(LABEL_LOOP_CASES[name]) > 6 and LABEL_LOOP_CASES[name][6]
     items = synth_label_loop_images(LABEL_LOOP_CASES[name])
     a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
     ms = []
@@ -414,17 +417,19 @@ def test_label_loop_functions_vs_reference_golden(tmp_path, name, golden):
         ms.append(m)
     loader = [(torch.stack([x for x, _ in items[i:i + 2]]), None, [nm for _, nm in items[i:i + 2]], 1.0) for i in range(0, n, 2)]
     if specs[0][2] is None:
-        lst, cw = uest.generate_pseudo_label(ms[0], loader, str(tmp_path), class_weighting=weighting, in_flight=2, batches_per_launch=2)
+        lst, cw = uest.generate_pseudo_label(ms[0], loader, str(tmp_path), class_weighting=weighting, in_flight=2, batches_per_launch=2,
+                                             eval_training=eval_training)
     else:
         lst, cw = uest.generate_pseudo_label_multi_model(ms, [s[2] for s in specs], loader, str(tmp_path), merge_label_policy=policy,
-                                                         class_weighting=weighting, in_flight=2)
+                                                         class_weighting=weighting, in_flight=2, eval_training=eval_training)
+    assert all(m.training == bool(eval_training) for m in ms)
     got_lines = open(lst).read().replace(str(tmp_path), '{SAVE}').splitlines()
     assert got_lines == lines
     want, margin = g[name + '.maps'], g[name + '.margin']
     got = np.stack([oio.png_decode_gray8(open(ln.split(',')[1].replace('{SAVE}', str(tmp_path)), 'rb').read()) for ln in got_lines])
     assert got.shape == want.shape and got.dtype == np.uint8
     sure = margin > 2e-3
-    assert sure.mean() > 0.9 and np.array_equal(got[sure], want[sure])
+    assert sure.mean() > 0.5 and np.array_equal(got[sure], want[sure])       # (three models: 75 % of the pixels have all margins > 2e-3)
     ndiff = int((got != want).sum())
     assert ndiff <= int((~sure).sum())
     ref_w = g[name + '.class_weights']

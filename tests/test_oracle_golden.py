@@ -227,7 +227,8 @@ def test_label_loops_vs_reference_functions(name, golden):
     (uest_seg_multi_os.py:730-830, :832-956; AST-extracted and run by tests/golden/make_golden.py gen_label_loops on a stub dataset):
     the list file's lines and order (file-name rule), the label maps the reference wrote as PNG files, the class weights."""
     g = golden('label_loops')
-    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name]
+    specs, (H, W), n, in_seed, policy, weighting = LABEL_LOOP_CASES[name][:6]
+    eval_training = len(LABEL_LOOP_CASES[name]) > 6 and LABEL_LOOP_CASES[name][6]
     items = synth_label_loop_images(LABEL_LOOP_CASES[name])
     # ragged batches on purpose: the reference's loader has batch size 1, the restatement walks a batch element by element
     loader, i = [], 0
@@ -239,8 +240,10 @@ def test_label_loops_vs_reference_functions(name, golden):
     fwds = []
     for C, ds, os_data, sd_seed in specs:
         sd = synth_state_dict(KEYS['espdnetue_s2.0_c%d' % C], sd_seed)
+        # eval_training: BatchNorm with the statistics of the (single-image) batch -- the restatement walks a batch element by element
         fwds.append(lambda x, sd=sd: onet.espdnet_ue_forward(sd, x))
-    with torch.no_grad():
+    import contextlib
+    with torch.no_grad(), (onet.bn_training() if eval_training else contextlib.nullcontext()):
         if specs[0][2] is None:
             ri, rl, rd, maps, cw = olab.generate_pseudo_label(fwds[0], loader, 5, '{SAVE}/pred', weighting)
         else:
