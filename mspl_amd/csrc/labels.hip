@@ -342,6 +342,14 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
         const float* mcol = ml + (mx0 - cmA);
         const float* acol = al + (ax0 - caA);
         const int mdx = mx1 - mx0, adx = ax1 - ax0;             // 1, or 0 at the clamped right edge (the reference reads column i1)
+        // Horizontally interpolated source rows are kept ACROSS the band's output rows: consecutive output rows interpolate between
+        // the same two source rows, or the lower one of the pair becomes the upper one (x2 / x4 up-sampling: ~3.5 + ~3 row
+        // interpolations per band instead of 8 + 8; 2 LDS reads and 2 vector instructions per class each).  Which rows a step
+        // needs is uniform (scalar branches); same expressions, same values as interpolating both rows for every output row.
+        float mtop[CMAX], mbot[CMAX], atop[CMAX], abot[CMAX];
+        int mkt = -1, mkb = -1, akt = -1, akb = -1;                     // source rows held in (mtop, mbot) / (atop, abot)
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) { mtop[c] = mbot[c] = atop[c] = abot[c] = 0.f; }
 #pragma unroll 1
         for (int r = 0; r < LE_RB; ++r) {
             const int y = y0 + r;
@@ -349,34 +357,66 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
             if (y < g.H) {                                              // uniform
                 int my0, my1;  float mwy0, mwy1;
                 bilinear_src(g.shm, y, g.Hm, my0, my1, mwy0, mwy1);     // uniform
-                const float* mr0 = mcol + (my0 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
-                const float* mr1 = mcol + (my1 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
-                const float* mr0b = mr0 + mdx;  const float* mr1b = mr1 + mdx;      // second source column (the same at the clamped edge)
+                if (my0 != mkt) {
+                    if (my0 == mkb) {
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) mtop[c] = mbot[c];
+                    } else {
+                        const float* mr0 = mcol + (my0 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
+                        const float* mr0b = mr0 + mdx;                  // second source column (the same at the clamped edge)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (EXACT || c < g.C) mtop[c] = mwx0 * mr0[c * wms_c] + mwx1 * mr0b[c * wms_c];
+                    }
+                    mkt = my0;
+                }
+                if (my1 != mkb) {
+                    if (my1 == mkt) {
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) mbot[c] = mtop[c];
+                    } else {
+                        const float* mr1 = mcol + (my1 - rm_lo) * (EXACT ? CMAX : g.C) * wms_c;
+                        const float* mr1b = mr1 + mdx;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (EXACT || c < g.C) mbot[c] = mwx0 * mr1[c * wms_c] + mwx1 * mr1b[c * wms_c];
+                    }
+                    mkb = my1;
+                }
                 float m[CMAX], a[CMAX];
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    m[c] = -INFINITY;
-                    if (EXACT || c < g.C) {
-                        const float top = mwx0 * mr0[c * wms_c] + mwx1 * mr0b[c * wms_c];
-                        const float bot = mwx0 * mr1[c * wms_c] + mwx1 * mr1b[c * wms_c];
-                        m[c] = mwy0 * top + mwy1 * bot;
-                    }
-                }
+                for (int c = 0; c < CMAX; ++c) m[c] = (EXACT || c < g.C) ? mwy0 * mtop[c] + mwy1 * mbot[c] : -INFINITY;
                 if (auxp) {
                     int ay0, ay1;  float awy0, awy1;
                     bilinear_src(g.sha, y, g.Ha, ay0, ay1, awy0, awy1);
-                    const float* ar0 = acol + (ay0 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
-                    const float* ar1 = acol + (ay1 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
-                    const float* ar0b = ar0 + adx;  const float* ar1b = ar1 + adx;
+                    if (ay0 != akt) {
+                        if (ay0 == akb) {
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) {
-                        a[c] = -INFINITY;
-                        if (EXACT || c < g.C) {
-                            const float top = awx0 * ar0[c * was_c] + awx1 * ar0b[c * was_c];
-                            const float bot = awx0 * ar1[c * was_c] + awx1 * ar1b[c * was_c];
-                            a[c] = awy0 * top + awy1 * bot;
+                            for (int c = 0; c < CMAX; ++c) atop[c] = abot[c];
+                        } else {
+                            const float* ar0 = acol + (ay0 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
+                            const float* ar0b = ar0 + adx;
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c)
+                                if (EXACT || c < g.C) atop[c] = awx0 * ar0[c * was_c] + awx1 * ar0b[c * was_c];
                         }
+                        akt = ay0;
                     }
+                    if (ay1 != akb) {
+                        if (ay1 == akt) {
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) abot[c] = atop[c];
+                        } else {
+                            const float* ar1 = acol + (ay1 - ra_lo) * (EXACT ? CMAX : g.C) * was_c;
+                            const float* ar1b = ar1 + adx;
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c)
+                                if (EXACT || c < g.C) abot[c] = awx0 * ar1[c * was_c] + awx1 * ar1b[c * was_c];
+                        }
+                        akb = ay1;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) a[c] = (EXACT || c < g.C) ? awy0 * atop[c] + awy1 * abot[c] : -INFINITY;
                 } else {
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) a[c] = (EXACT || c < g.C) ? 0.f : -INFINITY;
@@ -419,12 +459,14 @@ __global__ __launch_bounds__(256) void label_epilogue_lds_kernel(const float* __
     }
     if (hist_ws) {
         // counts per class over the wave (4 pixels per lane), then LDS, then this workgroup's row of the workspace
+        // (one compare per (class, row) and lane; the count over the wave is a population count of the compare's lane mask on the
+        // scalar unit -- the per-lane counts + six-step shuffle reduction this replaces were ~450 of the kernel's ~2 650 vector
+        // instructions per wave)
         for (int c = 0; c < st.ncls; ++c) {
-            unsigned cnt = 0;
+            unsigned cnt = 0;                                                        // uniform
 #pragma unroll
-            for (int r = 0; r < LE_RB; ++r) cnt += (((cnt_mask_lo >> (8 * r)) & 0xffu) == (unsigned)c);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+            for (int r = 0; r < LE_RB; ++r)
+                cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(((cnt_mask_lo >> (8 * r)) & 0xffu) == (unsigned)c));
             if ((tid & 63) == 0 && cnt) atomicAdd(&sh_hist[c], cnt);
         }
         __syncthreads();

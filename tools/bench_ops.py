@@ -271,3 +271,25 @@ def bench_k2_cold():
 
 if len(sys.argv) > 1 and sys.argv[1] == 'k2cold':
     bench_k2_cold()
+
+
+def bench_label():
+    """The label epilogue (up-sampling of both heads + argmax + histogram) at the path's shapes: C = 13 / 20 / 5 at 288x480 / 256x480,
+    C = 20 at 512x1024; alone, back to back inside a hipGraph."""
+    from mspl_amd import ops as O
+    N = 16
+    for C, H, W in [(13, 288, 480), (20, 256, 480), (5, 256, 480), (20, 512, 1024)]:
+        main = torch.randn(N, C, H // 2, W // 2, device=DEV)
+        aux = torch.randn(N, C, H // 4, W // 4, device=DEV)
+        hist = torch.zeros(C, dtype=torch.int64, device=DEV)
+        fits = O.label_epilogue_hist_fits(main, aux, (H, W))
+        t_h = timeit(lambda: O.label_epilogue_hist(main, aux, (H, W), hist, C, want_kld=False)) if fits else float('nan')
+        t_l = timeit(lambda: O.label_epilogue(main, aux, (H, W)))
+        t_k = timeit(lambda: O.label_epilogue(main, aux, (H, W), want_kld=True))
+        by = 4 * N * C * (H * W // 4 + H * W // 16) + N * H * W
+        print('label C=%2d %4dx%4d  with histogram %7.1f us (%.0f GB/s)   labels only %7.1f us   labels + kld %7.1f us'
+              % (C, H, W, t_h, by / t_h / 1e3, t_l, t_k))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'label':
+    bench_label()
