@@ -187,41 +187,40 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < PXL; ++j) colin[j] = px0 + j >= 0 && px0 + j < w;
 
-    // x row loader: columns px0-2 .. px0+PXL+1 of row r (zero outside the image).  Addresses = uniform row base (scalar
-    // arithmetic) + a per-lane 32-bit byte offset that never changes: no vector instruction goes into addressing.
-    unsigned xoff[PXL + 4];  bool xin[PXL + 4];
+    // x row loader: columns px0-2 .. px0+PXL+1 of row r (zero outside the image).  Buffer loads through a per-ROW descriptor built on
+    // the scalar unit (base = the row, records = the row's bytes, or 0 for a row outside the image) + a per-lane byte offset that
+    // never changes (columns outside the image: an offset past the records): the range check of the load returns the zeros, so
+    // no vector instruction goes into addressing or masking (rounds 2-4: one 64-bit address add per load and one multiply by a
+    // 0/1 mask per value -- 12 of the ~500 vector instructions of a row step; 28 with the low-resolution rows below).
+    // PXL == 2: px0 is even and so is w (launcher), so the six columns are three 8-byte loads, each inside or outside as a whole.
+    constexpr unsigned P3_OOB = 0x7ffffff0u;
+    unsigned xoff[PXL + 4];
 #pragma unroll
     for (int j = 0; j < PXL + 4; ++j) {
         const int cx = px0 - 2 + j;
-        xin[j] = cx >= 0 && cx < w;
-        xoff[j] = (unsigned)min(max(cx, 0), w - 1) * 4u;
+        xoff[j] = (cx >= 0 && cx < w) ? (unsigned)cx * 4u : P3_OOB;
     }
-    // Rows / columns outside the image: the address is clamped (always a valid read) and the value is multiplied by 0 when it
-    // ENTERS THE WINDOW, one iteration after it was requested.  (Rounds 1-2 selected `inside ? value : 0` next to the load: hipcc
-    // put the loads behind branches on the uniform row test and waited for each pair on the spot -- three exposed L2 round trips
-    // per row and wave.)
-    float xm[PXL + 4];
+    auto load_row = [&](int r, float (&v)[PXL + 4]) {
+        const bool rin = r >= 0 && r < h;                                                   // uniform
+        const float* row = xpl + (size_t)(rin ? r : 0) * w;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, rin ? w * 4 : 0, 0x00020000);
+        if (PXL == 2) {
 #pragma unroll
-    for (int j = 0; j < PXL + 4; ++j) xm[j] = xin[j] ? 1.f : 0.f;
-    auto load_row_raw = [&](int r, float (&v)[PXL + 4]) {
-        const char* row = reinterpret_cast<const char*>(xpl + (size_t)min(max(r, 0), h - 1) * w);
+            for (int j = 0; j < PXL + 4; j += 2) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, xoff[j], 0, 0);
+                v[j] = __uint_as_float(t.x);  v[j + 1] = __uint_as_float(t.y);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < PXL + 4; ++j) v[j] = *reinterpret_cast<const float*>(row + xoff[j]);
-    };
-    auto mask_row = [&](int r, const float (&raw)[PXL + 4], float (&v)[PXL + 4]) {
-        const float rm = (r >= 0 && r < h) ? 1.f : 0.f;                                     // uniform
-#pragma unroll
-        for (int j = 0; j < PXL + 4; ++j) v[j] = raw[j] * (rm * xm[j]);
+            for (int j = 0; j < PXL + 4; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, xoff[j], 0, 0));
+        }
     };
 
     float xw[5][PXL + 4];
     // rows br-2 .. br+2 for the first branch row br = ys - 1: rows ys-3 .. ys+1
 #pragma unroll
-    for (int rr = 0; rr < 5; ++rr) {
-        float t[PXL + 4];
-        load_row_raw(ys - 3 + rr, t);
-        mask_row(ys - 3 + rr, t, xw[rr]);
-    }
+    for (int rr = 0; rr < 5; ++rr) load_row(ys - 3 + rr, xw[rr]);
     // low-resolution values of the NEXT branch row, requested one row ahead: [map][column][ya/xa, ya/xb, yb/xa, yb/xb]
     float en[2][PXL][4];
     float enwy0[2], enwy1[2];
@@ -230,12 +229,15 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         for (int i = 0; i < 2; ++i) {
             int ya, yb;
             bilinear_src(g.sh[3 + i], min(max(r, 0), h - 1), g.hs[3 + i], ya, yb, enwy0[i], enwy1[i]);       // uniform
-            const char* ra = reinterpret_cast<const char*>((i == 0 ? e3 : e4) + ya * g.ws[3 + i]);
-            const char* rb = reinterpret_cast<const char*>((i == 0 ? e3 : e4) + yb * g.ws[3 + i]);
+            const int rowb = g.ws[3 + i] * 4;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((i == 0 ? e3 : e4) + ya * g.ws[3 + i]), 0, rowb, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((i == 0 ? e3 : e4) + yb * g.ws[3 + i]), 0, rowb, 0x00020000);
 #pragma unroll
             for (int j = 0; j < PXL; ++j) {
-                en[i][j][0] = *reinterpret_cast<const float*>(ra + dxa[i][j]); en[i][j][1] = *reinterpret_cast<const float*>(ra + dxb[i][j]);
-                en[i][j][2] = *reinterpret_cast<const float*>(rb + dxa[i][j]); en[i][j][3] = *reinterpret_cast<const float*>(rb + dxb[i][j]);
+                en[i][j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, dxa[i][j], 0, 0));
+                en[i][j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, dxb[i][j], 0, 0));
+                en[i][j][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, dxa[i][j], 0, 0));
+                en[i][j][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, dxb[i][j], 0, 0));
             }
         }
     };
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         }
         if (br < ye) load_e(br + 1);                       // next row's low-resolution values fly during this row's arithmetic
         float xn[PXL + 4];
-        load_row_raw(br + 3, xn);                          // the row that enters the window at the end of this iteration
+        load_row(br + 3, xn);                              // the row that enters the window at the end of this iteration
         __builtin_amdgcn_sched_barrier(0);
         if (rowin) {
             const float* A0 = &At[0][(br - (ys - 1)) * 24];
@@ -342,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int j = 0; j < PXL + 4; ++j) xw[rr][j] = xw[rr + 1][j];
-        mask_row(br + 3, xn, xw[4]);
+#pragma unroll
+        for (int j = 0; j < PXL + 4; ++j) xw[4][j] = xn[j];
         // ---- output row y = br - 1 is complete
         const int y = br - 1;
         if (y >= ys) {
@@ -391,7 +394,7 @@ int pyrpool_stream_try(const float* x, int N, int P, int h, int w, int nb, const
         taps[i] = R <= 1 ? 3 : 5;
     }
     const int PXL = w <= 62 ? 1 : 2;
-    if (PXL == 2 && ((w & 1) || (((uintptr_t)out) & 7))) return 1;     // 8-byte stores
+    if (PXL == 2 && ((w & 1) || (((uintptr_t)out) & 7) || (((uintptr_t)x) & 7))) return 1;     // 8-byte stores and x row loads
     if (zcat && (!e.raw || e.ctot != P || e.coff != 0)) return 1;      // training forward: un-sliced destination + raw output
     if (zcat && PXL == 2 && ((((uintptr_t)zcat) | ((uintptr_t)e.raw)) & 7)) return 1;
     Pyr3Geom g;
