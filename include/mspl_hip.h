@@ -220,6 +220,19 @@ int64_t mspl_pyr_down_prep_lds_bytes(int32_t N, int32_t P, int32_t h, int32_t w,
                                      const int32_t* ws);
 int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
                            const int32_t* ws, const float* const* stage_w, float* const* out, void* stream);
+/* The training forward of the same step: pooled[i] (N,P,hs[i],ws[i]), when given, also receives the pooled map itself
+ *     (adaptive_avg_pool2d(x, (hs[i],ws[i]))): the depthwise convolution's weight gradient reads it.  pooled == NULL: as above. */
+int mspl_pyr_down_prep_train_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                                 const int32_t* ws, const float* const* stage_w, float* const* out, float* const* pooled,
+                                 void* stream);
+/* Autograd of those branches between the transposed bilinear interpolation and the full-resolution gradient, every branch of a
+ *     pyramid in ONE launch (nn_layers/efficient_pyramid_pool.py:44-47): given g_e[i] = dL/d(dw3x3 output) (mspl_bilinear_bwd),
+ *     gw[i] (P,1,3,3) += the depthwise weight gradient (atomically: gw may be the parameter's gradient buffer), gx[i] (N,P,h,w) =
+ *     adaptive_avg_pool2d^T(dw3x3^T(g_e[i])).  nb <= 2.  Replaces conv3x3 with flipped weights + mspl_conv_bwd_weight +
+ *     mspl_adaptive_avgpool_bwd per branch. */
+int mspl_pyr_down_mid_bwd(const float* const* g_e, const float* const* pooled, const float* const* stage_w, int32_t N, int32_t P,
+                          int32_t h, int32_t w, int32_t nb, const int32_t* hs, const int32_t* ws, float* const* gw,
+                          float* const* gx, void* stream);
 
 /* K6  fused EfficientPyrPool body: all branches + merge_layer.0 (BN+PReLU) + Shuffle + merge_layer.2 (grouped
  *     3x3 + BN + PReLU) in one pass over the projected tensor.  Replaces nn_layers/efficient_pyramid_pool.py:39-58

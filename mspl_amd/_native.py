@@ -121,6 +121,11 @@ SIGNATURES = {
     'mspl_pyr_down_prep_lds_bytes': [c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)],
     'mspl_pyr_down_prep_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p],
+    'mspl_pyr_down_prep_train_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.c_void_p],
+    'mspl_pyr_down_mid_bwd': [ctypes.POINTER(ctypes.c_void_p)] * 3 + [c_i32] * 5 + [ctypes.POINTER(c_i32)] * 2 +
+                             [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.c_void_p],
     'mspl_dense_conv_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,
                             ctypes.c_void_p],
     'mspl_eval_epilogue_fwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p] + [c_i32] * 8 + [ctypes.c_float, c_i32, c_i32, ctypes.c_void_p,

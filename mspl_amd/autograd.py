@@ -569,6 +569,63 @@ class EESPFn(torch.autograd.Function):
                 gwe, r_ge, r_be, r_am if am is not None else None)
 
 
+_PYR_DOWN_FUSED = os.environ.get('MSPL_PYR_DOWN_FUSED', '1') != '0'   # low-resolution pyramid branches: one launch each way (A/B aid)
+
+
+def _pyr_down_forward(x, sizes, stage_ws, down):
+    """The scale < 1 branches of a pyramid in the training forward: (pooled maps, dw3x3(pooled) maps) per branch index.  One launch
+    for all of them (the inference prologue kernel, which also leaves the pooled maps the weight gradient needs) instead of an
+    adaptive pool + a depthwise 3x3 per branch."""
+    N, P, h, w = x.shape
+    pooled, es = {}, {}
+    if not down:
+        return pooled, es
+    dsz = [sizes[i] for i in down]
+    if _PYR_DOWN_FUSED and len(down) <= 4 and ops.pyr_down_prep_fits(x.shape, dsz):
+        outs, pools = ops.pyr_down_prep(x, dsz, [stage_ws[i] for i in down], keep_pooled=True)
+        for k, i in enumerate(down):
+            pooled[i], es[i] = pools[k], outs[k]
+        return pooled, es
+    for i in down:
+        pooled[i] = ops.adaptive_avgpool(x, sizes[i])
+        es[i] = ops.conv3x3(pooled[i], stage_ws[i], P)
+    return pooled, es
+
+
+def _pyr_down_backward(gt, x_shape, sizes, stage_ws, pooled, down, g_stage):
+    """Backward of those branches: gt[i] (N,P,h,w) = dL/d(branch value) -> the full-resolution gradients [g_x_i], the depthwise
+    weight gradients added into g_stage[i].  Transposed bilinear interpolation per branch (existing kernels), then ONE launch for
+    the depthwise 3x3's two gradients and the adaptive pool's transpose of every branch (csrc/pyr_down_bwd.hip; three launches per
+    branch before)."""
+    N, P, h, w = x_shape
+    dev = gt.device
+    g_es = []
+    for i in down:
+        hs_, ws_ = sizes[i]
+        g_e = torch.empty((N, P, hs_, ws_), device=dev, dtype=torch.float32)
+        check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
+        g_es.append(g_e)
+    adds = []
+    if _PYR_DOWN_FUSED and 1 <= len(down) <= 2 and all((sizes[i][0] + 2) * (sizes[i][1] + 2) * 4 + h * 16 <= 64 * 1024 for i in down):
+        nbd = len(down)
+        adds = [torch.empty((N, P, h, w), device=dev, dtype=torch.float32) for _ in down]
+        arr = lambda ts: (ctypes.c_void_p * nbd)(*[t.data_ptr() for t in ts])         # noqa: E731
+        sws = [_c(stage_ws[i]) for i in down]
+        hsa = (ctypes.c_int32 * nbd)(*[sizes[i][0] for i in down])
+        wsa = (ctypes.c_int32 * nbd)(*[sizes[i][1] for i in down])
+        check(lib.mspl_pyr_down_mid_bwd(arr(g_es), arr([pooled[i] for i in down]), arr(sws), N, P, h, w, nbd, hsa, wsa,
+                                        arr([g_stage[i] for i in down]), arr(adds), _stream()))
+        return adds
+    for k, i in enumerate(down):
+        hs_, ws_ = sizes[i]
+        g_pool = ops.conv3x3(g_es[k], _transposed_weights(stage_ws[i], P, 3), P, 1)
+        check(lib.mspl_conv_bwd_weight(_p(g_es[k]), _p(pooled[i]), N, P, P, P, hs_, ws_, 3, 1, 1, 1, _p(g_stage[i]), _stream()))
+        g_xi = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
+        check(lib.mspl_adaptive_avgpool_bwd(_p(g_pool), N, P, h, w, hs_, ws_, _p(g_xi), _stream()))
+        adds.append(g_xi)
+    return adds
+
+
 class PyrBodyFn(torch.autograd.Function):
     """The EfficientPyrPool body between projection_layer and the last 1x1 (nn_layers/efficient_pyramid_pool.py:39-58: the five
     branches, merge_layer.0 BatchNorm + PReLU over the concatenation, Shuffle, merge_layer.2 grouped 3x3 + BatchNorm + PReLU) as ONE
@@ -590,10 +647,7 @@ class PyrBodyFn(torch.autograd.Function):
         br_scale, br_shift = bn0['scale'], bn0['shift']
         m_scale, m_shift = bn2['scale'], bn2['shift']
         down = [i for i, (hs_, ws_) in enumerate(sizes) if (hs_ < h or ws_ < w)]
-        pooled, down_es = {}, [None] * nb
-        for i in down:
-            pooled[i] = ops.adaptive_avgpool(x, sizes[i])
-            down_es[i] = ops.conv3x3(pooled[i], stage_ws[i], P)
+        pooled, down_es = _pyr_down_forward(x, sizes, stage_ws, down)
         hs = (ctypes.c_int32 * nb)(*[int(s_[0]) for s_ in sizes])
         ws = (ctypes.c_int32 * nb)(*[int(s_[1]) for s_ in sizes])
         sw, de = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
@@ -645,16 +699,7 @@ class PyrBodyFn(torch.autograd.Function):
                                          _p(g_m_gamma), _p(g_m_beta), _p(g_m_alpha), _stream()))
         g_stage = [dst(wsinks[i], tuple(stage_ws[i].shape)) for i in range(nb)]
         # scale < 1 branches (small maps): bilinear^T -> depthwise 3x3 backward -> adaptive pool^T, existing kernels
-        adds = []
-        for i in down:
-            hs_, ws_ = sizes[i]
-            g_e = torch.empty((N, P, hs_, ws_), device=dev, dtype=torch.float32)
-            check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
-            g_pool = ops.conv3x3(g_e, _transposed_weights(stage_ws[i], P, 3), P, 1)
-            check(lib.mspl_conv_bwd_weight(_p(g_e), _p(pooled[i]), N, P, P, P, hs_, ws_, 3, 1, 1, 1, _p(g_stage[i]), _stream()))
-            g_xi = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
-            check(lib.mspl_adaptive_avgpool_bwd(_p(g_pool), N, P, h, w, hs_, ws_, _p(g_xi), _stream()))
-            adds.append(g_xi)
+        adds = _pyr_down_backward(gt, (N, P, h, w), sizes, stage_ws, pooled, down, g_stage)
         # scale >= 1 branches (up to three, pyr_body_fits) in one launch, the low-resolution contributions (up to two) added in.
         # (always launched: the stage weights' gradients come from it)
         up = [i for i in range(nb) if i not in down]
@@ -704,10 +749,7 @@ class PyrBodyBNFn(torch.autograd.Function):
         nb = len(sizes)
         dev = x.device
         down = [i for i, (hs_, ws_) in enumerate(sizes) if (hs_ < h or ws_ < w)]
-        pooled, down_es = {}, [None] * nb
-        for i in down:
-            pooled[i] = ops.adaptive_avgpool(x, sizes[i])
-            down_es[i] = ops.conv3x3(pooled[i], stage_ws[i], P)
+        pooled, down_es = _pyr_down_forward(x, sizes, stage_ws, down)
         hs = (ctypes.c_int32 * nb)(*[int(s_[0]) for s_ in sizes])
         ws = (ctypes.c_int32 * nb)(*[int(s_[1]) for s_ in sizes])
         sw, de = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
@@ -799,16 +841,7 @@ class PyrBodyBNFn(torch.autograd.Function):
         check(lib.mspl_bn_stats_path_add(_p(gt), _p(zcat), _p(out0[2]), _p(out0[3]), N, P, nb, h * w, _stream()))
         # the branches (as in PyrBodyFn)
         g_stage = [dst(wsinks[i], tuple(stage_ws[i].shape)) for i in range(nb)]
-        adds = []
-        for i in down:
-            hs_, ws_ = sizes[i]
-            g_e = torch.empty((N, P, hs_, ws_), device=dev, dtype=torch.float32)
-            check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
-            g_pool = ops.conv3x3(g_e, _transposed_weights(stage_ws[i], P, 3), P, 1)
-            check(lib.mspl_conv_bwd_weight(_p(g_e), _p(pooled[i]), N, P, P, P, hs_, ws_, 3, 1, 1, 1, _p(g_stage[i]), _stream()))
-            g_xi = torch.empty((N, P, h, w), device=dev, dtype=torch.float32)
-            check(lib.mspl_adaptive_avgpool_bwd(_p(g_pool), N, P, h, w, hs_, ws_, _p(g_xi), _stream()))
-            adds.append(g_xi)
+        adds = _pyr_down_backward(gt, (N, P, h, w), sizes, stage_ws, pooled, down, g_stage)
         up = [i for i in range(nb) if i not in down]
         nbp = len(up)
         hsa = (ctypes.c_int32 * nbp)(*[sizes[i][0] for i in up])

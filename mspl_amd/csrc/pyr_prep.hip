@@ -23,6 +23,7 @@ struct PrepGeom {
     int hs[PP_MAXB], ws[PP_MAXB], off[PP_MAXB];   // pooled map sizes and LDS offsets (floats) of a band (+2 halo rows)
     const float* wts[PP_MAXB];                    // (P,1,3,3)
     float* out[PP_MAXB];                          // (N,P,hs,ws)
+    float* pool[PP_MAXB];                         // (N,P,hs,ws) or null: the pooled maps themselves (the training forward keeps them)
     int xoff, WS;                                 // staged input rows: LDS offset, row stride (floats, multiple of 4)
     int boff;                                     // window-bound tables
     int csoff;                                    // column sums of the large-window branches: [band rows + 2][WS]
@@ -186,9 +187,11 @@ __global__ __launch_bounds__(256) void pyr_down_prep_kernel(const float* __restr
         const float* w9 = g.wts[i] + (size_t)c * 9;
         const float w00 = w9[0], w01 = w9[1], w02 = w9[2], w10 = w9[3], w11 = w9[4], w12 = w9[5], w20 = w9[6], w21 = w9[7], w22 = w9[8];
         float* dst = g.out[i] + ((size_t)plane * hs + ra) * ws;
+        float* pdst = g.pool[i] ? g.pool[i] + ((size_t)plane * hs + ra) * ws : nullptr;
         for (int ry = wave; ry < rb - ra; ry += 4) {              // LDS row ry+1 is map row ra+ry
             const float* r0p = Pm + ry * ws;
             for (int ox = lane; ox < ws; ox += 64) {
+                if (pdst) pdst[ry * ws + ox] = r0p[ws + ox];
                 auto at = [&](int dy, int xx) { return (xx >= 0 && xx < ws) ? r0p[dy * ws + xx] : 0.f; };
                 float v = w00 * at(0, ox - 1);
                 v = fmaf(w01, at(0, ox), v);      v = fmaf(w02, at(0, ox + 1), v);
@@ -219,6 +222,7 @@ struct PsGeom {
     int hs[PP_MAXB], ws[PP_MAXB], off[PP_MAXB], exact2[PP_MAXB];
     const float* wts[PP_MAXB];
     float* out[PP_MAXB];
+    float* pool[PP_MAXB];      // pooled maps (training forward) or null
     int LPR, lprp_shift;       // lanes per input row (w / VW) and log2 of its power-of-two padding
     int rboff, RBS;            // row buffers: LDS offset, floats per buffer
 };
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
             v = fmaf(w10, at(oy, ox - 1), v);  v = fmaf(w11, at(oy, ox), v);  v = fmaf(w12, at(oy, ox + 1), v);
             v = fmaf(w20, at(oy + 1, ox - 1), v);  v = fmaf(w21, at(oy + 1, ox), v);  v = fmaf(w22, at(oy + 1, ox + 1), v);
             dst[idx] = v;
+            if (g.pool[i]) g.pool[i][(size_t)plane * total + idx] = Pm[idx];
             oy += dy256;  ox += dx256;
             if (ox >= ws) { ox -= ws; ++oy; }
         }
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
 
 // Returns MSPL_OK when launched, 1 when the shape is left to the band form.
 static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, const int32_t* hs, const int32_t* ws,
-                           const float* const* stage_w, float* const* out, hipStream_t stream) {
+                           const float* const* stage_w, float* const* out, float* const* pooled, hipStream_t stream) {
     static const int off = (MSPL_TUNE_INT("MSPL_PREP_STREAM", 1) == 0);
     if (off || (w & 1) || (((uintptr_t)x) & 15)) return 1;
     const int VW = (w & 3) == 0 ? 4 : 2;
@@ -351,7 +356,7 @@ static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, c
     int off_f = 0;
     bool any_large = false;
     for (int i = 0; i < nb; ++i) {
-        g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i];
+        g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i]; g.pool[i] = pooled ? pooled[i] : nullptr;
         g.exact2[i] = (h == 2 * hs[i] && w == 2 * ws[i]) ? 1 : 0;
         if (!g.exact2[i]) {
             const int wy = ceil_div(h, hs[i]) + 1, wx = ceil_div(w, ws[i]) + 1;
@@ -434,8 +439,20 @@ extern "C" int64_t mspl_pyr_down_prep_lds_bytes(int32_t N, int32_t P, int32_t h,
     return (int64_t)prep_plan(g, (int64_t)N * P);
 }
 
+extern "C" int mspl_pyr_down_prep_train_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                                            const int32_t* ws, const float* const* stage_w, float* const* out, float* const* pooled,
+                                            void* stream);
+
 extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
                                       const int32_t* ws, const float* const* stage_w, float* const* out, void* stream) {
+    return mspl_pyr_down_prep_train_fwd(x, N, P, h, w, nb, hs, ws, stage_w, out, nullptr, stream);
+}
+
+// The training forward: the same launch also writes the pooled maps p_i = adaptive_avg_pool2d(x, (hs_i, ws_i)) (pooled[i], or
+// pooled == NULL), which the depthwise convolutions' weight gradient needs.
+extern "C" int mspl_pyr_down_prep_train_fwd(const float* x, int32_t N, int32_t P, int32_t h, int32_t w, int32_t nb, const int32_t* hs,
+                                            const int32_t* ws, const float* const* stage_w, float* const* out, float* const* pooled,
+                                            void* stream) {
     MSPL_REQUIRE(x && hs && ws && stage_w && out, MSPL_ERR_NULL_POINTER, "pyr_down_prep: null pointer");
     MSPL_REQUIRE(N > 0 && P > 0 && h > 0 && w > 0, MSPL_ERR_BAD_SHAPE, "pyr_down_prep: bad shape N=%d P=%d %dx%d", N, P, h, w);
     MSPL_REQUIRE(nb >= 1 && nb <= PP_MAXB, MSPL_ERR_UNSUPPORTED, "pyr_down_prep: %d branches (1..%d)", nb, PP_MAXB);
@@ -445,7 +462,7 @@ extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int3
         MSPL_REQUIRE(stage_w[i] && out[i], MSPL_ERR_NULL_POINTER, "pyr_down_prep: branch %d has a null pointer", i);
     }
     {
-        const int rc = mspl::prep_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, out, (hipStream_t)stream);
+        const int rc = mspl::prep_stream_try(x, N, P, h, w, nb, hs, ws, stage_w, out, pooled, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
     PrepGeom g;
@@ -456,7 +473,7 @@ extern "C" int mspl_pyr_down_prep_fwd(const float* x, int32_t N, int32_t P, int3
         MSPL_REQUIRE(hs[i] > 0 && ws[i] > 0 && hs[i] <= h && ws[i] <= w, MSPL_ERR_BAD_SHAPE,
                      "pyr_down_prep: branch %d size %dx%d for a %dx%d map", i, hs[i], ws[i], h, w);
         MSPL_REQUIRE(stage_w[i] && out[i], MSPL_ERR_NULL_POINTER, "pyr_down_prep: branch %d has a null pointer", i);
-        g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i];
+        g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.wts[i] = stage_w[i]; g.out[i] = out[i]; g.pool[i] = pooled ? pooled[i] : nullptr;
     }
     const size_t lds = prep_plan(g, planes);
     static const int dbg_stop = MSPL_TUNE_INT("MSPL_PREP_STOP", 0);

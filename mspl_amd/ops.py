@@ -387,15 +387,16 @@ def pyr_down_prep_fits(shape, sizes):
     return lib.mspl_pyr_down_prep_lds_bytes(N, P, h, w, nb, hs, ws) > 0
 
 
-def pyr_down_prep(x, sizes, stage_ws):
-    """K6 prologue: [dw3x3(adaptive_avg_pool2d(x, size_i)) for each low-resolution branch] in one launch."""
+def pyr_down_prep(x, sizes, stage_ws, keep_pooled=False):
+    """K6 prologue: [dw3x3(adaptive_avg_pool2d(x, size_i)) for each low-resolution branch] in one launch.  keep_pooled=True (the
+    training forward): returns (those maps, the pooled maps themselves)."""
     x = _f32(x, 'x')
     N, P, h, w = x.shape
     nb = len(sizes)
     hs = (ctypes.c_int32 * nb)(*[int(s[0]) for s in sizes])
     ws = (ctypes.c_int32 * nb)(*[int(s[1]) for s in sizes])
-    sw, op = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
-    outs, keep = [], []
+    sw, op, pp = (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)(), (ctypes.c_void_p * nb)()
+    outs, pools, keep = [], [], []
     for i in range(nb):
         t = _f32(stage_ws[i], 'stage weight')
         if t.numel() != P * 9:
@@ -405,6 +406,12 @@ def pyr_down_prep(x, sizes, stage_ws):
         o = torch.empty((N, P, int(sizes[i][0]), int(sizes[i][1])), device=x.device, dtype=torch.float32)
         outs.append(o)
         op[i] = o.data_ptr()
+        if keep_pooled:
+            pools.append(torch.empty_like(o))
+            pp[i] = pools[-1].data_ptr()
+    if keep_pooled:
+        check(lib.mspl_pyr_down_prep_train_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, op, pp, _stream()))
+        return outs, pools
     check(lib.mspl_pyr_down_prep_fwd(_p(x), N, P, h, w, nb, hs, ws, sw, op, _stream()))
     return outs
 

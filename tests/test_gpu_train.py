@@ -660,3 +660,42 @@ def test_fused_eesp_block_training_equals_node_per_op(cfg):
         if b is not None:
             scale = float(b.abs().max()) + 1e-6
             assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 16, 30), (1, 16, 144, 240), (3, 8, 17, 33), (2, 16, 36, 60), (1, 4, 9, 7)])
+def test_pyramid_low_resolution_branches_one_launch_each_way(cfg):
+    """The scale < 1 pyramid branches (nn_layers/efficient_pyramid_pool.py:44-47) in the training step: ops.pyr_down_prep(keep_pooled=True)
+    (one forward launch: dw3x3(adaptive_avg_pool2d(x)) AND the pooled maps) and mspl_pyr_down_mid_bwd (one backward launch: depthwise
+    data + weight gradient + the adaptive pool's transpose of both branches) against torch autograd of the same expression."""
+    import ctypes
+    import math
+    from mspl_amd import ops
+    from mspl_amd._native import check, lib
+    N, P, h, w = cfg
+    sizes = [(max(math.ceil(h * s), 5), max(math.ceil(w * s), 5)) for s in (0.5, 0.1)]
+    sizes = [(min(a, h), min(b, w)) for a, b in sizes]
+    x = rnd(N, P, h, w, seed=1)
+    ws = [rnd(P, 1, 3, 3, seed=2 + i, scale=0.4) for i in range(2)]
+    g_es = [rnd(N, P, sz[0], sz[1], seed=10 + i) for i, sz in enumerate(sizes)]
+    xr = x.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in ws]
+    pooled_ref = [F.adaptive_avg_pool2d(xr, sz) for sz in sizes]
+    es_ref = [F.conv2d(p, t, None, 1, 1, 1, P) for p, t in zip(pooled_ref, wr)]
+    grads = [torch.autograd.grad(e, [xr, t], g, retain_graph=True) for e, t, g in zip(es_ref, wr, g_es)]
+    d = lambda t: t.to(DEV)
+    if ops.pyr_down_prep_fits((N, P, h, w), sizes):
+        outs, pools = ops.pyr_down_prep(d(x), sizes, [d(t) for t in ws], keep_pooled=True)
+        for i in range(2):
+            close(pools[i], pooled_ref[i], atol=1e-6, rtol=1e-5)
+            close(outs[i], es_ref[i], atol=2e-6, rtol=1e-5)
+    pools = [d(p.detach()) for p in pooled_ref]
+    gw = [torch.full((P, 1, 3, 3), 0.5, device=DEV) for _ in range(2)]                    # accumulated INTO (a gradient sink)
+    gx = [torch.full((N, P, h, w), 7.0, device=DEV) for _ in range(2)]
+    keep = [d(g) for g in g_es], [d(t) for t in ws]
+    arr = lambda ts: (ctypes.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    hsa, wsa = (ctypes.c_int32 * 2)(*[s_[0] for s_ in sizes]), (ctypes.c_int32 * 2)(*[s_[1] for s_ in sizes])
+    check(lib.mspl_pyr_down_mid_bwd(arr(keep[0]), arr(pools), arr(keep[1]), N, P, h, w, 2, hsa, wsa, arr(gw), arr(gx),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for i in range(2):
+        close(gx[i], grads[i][0], atol=2e-6, rtol=1e-5)
+        close(gw[i] - 0.5, grads[i][1], atol=2e-4 * float(grads[i][1].abs().max() + 1), rtol=1e-4)
