@@ -341,6 +341,12 @@ int mspl_conv_bwd_data(const float* gy, const float* w, int32_t N, int32_t Cin, 
 int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
                          int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
                          float* gw, void* stream);
+/* Weight gradients of nprob grouped 1x1 convolutions in as few launches as possible, each ACCUMULATED (atomically) into gw[i] --
+ *     parameter gradient buffers that were zeroed at the start of the step.  Problem i: gy[i] (N,Cout,HW), x[i] (N,Cin,HW),
+ *     gw[i] (Cout, Cin/groups).  Nothing in a backward chain waits for a weight gradient, so the training steps queue them
+ *     (mspl_amd.autograd.WgradQueue) and flush the queue here: ~33 launches of 8-25 us per uest step become a handful. */
+int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const int32_t* N, const int32_t* Cin,
+                             const int32_t* Cout, const int32_t* groups, const int32_t* HW, int32_t nprob, void* stream);
 
 /* DownSampler tail (nn_layers/eesp.py:131-144) without materialising torch.cat: y = PReLU(cat[a, b] + reinf).  a (N,nin,HW): avg-pooled
  * input; b (N,C-nin,HW): the strided EESP branch; reinf (N,C,HW) or NULL; alpha (C).  Backward: ga / gb (shapes of a / b, contiguous),

@@ -37,6 +37,50 @@ class grad_sinks(object):
 
     def __exit__(self, *exc):
         _SINKS[0] = self.prev
+        if exc and exc[0] is not None:
+            WGRADS.clear()
+        else:
+            WGRADS.flush()        # the queued 1x1 weight gradients of this backward (nothing waited for them)
+
+
+class WgradQueue(object):
+    """Weight gradients of the grouped 1x1 convolutions that go straight into a gradient sink, queued during a backward and sent
+    out together (mspl_conv1x1_wgrad_batch: runs of up to 16 problems per launch).  Nothing in a backward chain consumes a weight
+    gradient, so the only ordering that matters is "before the optimizer reads the buffer": `grad_sinks().__exit__` flushes, on
+    the stream the step runs on (inside a graph capture: the capture's stream).  The queue keeps the two operands of every problem
+    alive until then.  A uest train step issued 33 such launches of 8-25 us each; MSPL_WGRAD_BATCH=0 restores them (A/B aid)."""
+
+    def __init__(self):
+        self.items = []
+        self.enabled = os.environ.get('MSPL_WGRAD_BATCH', '1') != '0'
+
+    def add(self, gy, x, N, Cin, Cout, groups, HW, sink):
+        self.items.append((gy, x, sink, int(N), int(Cin), int(Cout), int(groups), int(HW)))
+        if len(self.items) >= 64:
+            self.flush()
+
+    def clear(self):
+        self.items = []
+
+    def flush(self):
+        items, self.items = self.items, []
+        n = len(items)
+        if n == 0:
+            return
+        arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])      # noqa: E731
+        ints = lambda k: (ctypes.c_int32 * n)(*[it[k] for it in items])                 # noqa: E731
+        check(lib.mspl_conv1x1_wgrad_batch(arr(0), arr(1), arr(2), ints(3), ints(4), ints(5), ints(6), ints(7), n, _stream()))
+
+
+WGRADS = WgradQueue()
+
+
+def _wgrad_1x1_into_sink(gy, x, N, Cin, Cout, groups, H, W, sink):
+    """gw of a grouped 1x1 convolution, accumulated into `sink`: queued inside grad_sinks(), launched at once otherwise."""
+    if WGRADS.enabled and _SINKS[0]:
+        WGRADS.add(gy, x, N, Cin, Cout, groups, H * W, sink)
+    else:
+        check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, 1, 1, 1, 1, _p(sink), _stream()))
 
 
 def _sink(p):
@@ -191,8 +235,10 @@ class ConvSkipFn(torch.autograd.Function):
             N, Cin, H, W = x.shape
             sink = ctx.wsink
             gw = torch.empty_like(w) if sink is None else None
-            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, w.shape[0], groups, H, W, 1, 1, 1, 0 if sink is None else 1,
-                                           _p(gw if sink is None else sink), _stream()))
+            if sink is not None:
+                _wgrad_1x1_into_sink(gy, x, N, Cin, w.shape[0], groups, H, W, sink)
+            else:
+                check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, w.shape[0], groups, H, W, 1, 1, 1, 0, _p(gw), _stream()))
         return gx, gw, None
 
 
@@ -300,8 +346,11 @@ def _conv_backward(x, w, cfg, sink, gy, need_gx, need_gw):
             check(lib.mspl_conv_bwd_data(_p(gy), _p(w), N, Cin, Cout, groups, H, W, k, stride, 1, 0, _p(gx), _stream()))
     if need_gw:
         gw = torch.empty_like(w) if sink is None else None
-        check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0 if sink is None else 1,
-                                       _p(gw if sink is None else sink), _stream()))
+        if sink is not None and k == 1 and stride == 1:
+            _wgrad_1x1_into_sink(gy, x, N, Cin, Cout, groups, H, W, sink)
+        else:
+            check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, k, stride, 1, 0 if sink is None else 1,
+                                           _p(gw if sink is None else sink), _stream()))
     return gx, gw
 
 
@@ -561,8 +610,10 @@ class EESPFn(torch.autograd.Function):
             gx = ops.conv1x1(gc1, wt, groups, Epi(residual=gres) if gres is not None else None)
         s_wp = sk['wp']
         gwp = torch.empty_like(wp) if s_wp is None else None
-        check(lib.mspl_conv_bwd_weight(_p(gc1), _p(x), N, Cin, n, groups, H, W, 1, 1, 1, 0 if s_wp is None else 1,
-                                       _p(gwp if s_wp is None else s_wp), _stream()))
+        if s_wp is not None:
+            _wgrad_1x1_into_sink(gc1, x, N, Cin, n, groups, H, W, s_wp)
+        else:
+            check(lib.mspl_conv_bwd_weight(_p(gc1), _p(x), N, Cin, n, groups, H, W, 1, 1, 1, 0, _p(gwp), _stream()))
         ret = lambda sink, t: None if sink is not None else t          # noqa: E731
         gws = [ret(wsinks[k], tmp[k] if tmp is not None else None) for k in range(4)]
         return (gx, None, None, None, None, gwp, r_gp, r_bp, r_ap, *gws, ret(s_g2, d_g2), ret(s_b2, d_b2), ret(s_a2, d_a2),

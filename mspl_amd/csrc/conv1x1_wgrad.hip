@@ -6,6 +6,9 @@
 // eight pixels per iteration, every byte loaded is used.  Partial tiles are combined with float atomics (gw zeroed by the
 // launcher, or the parameter's gradient buffer when accumulating).
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "common.hpp"
 
@@ -29,12 +32,10 @@ struct WgG {
 // groups -- next group's requests before this group's MFMAs -- measured no faster: 24 us either way for the 512 -> 512 expansion
 // at 18x30, whose fp32 MFMA floor is 6.5 us.)  The four waves of a workgroup hold four slices of the same tile: they are summed
 // through LDS and leave with one atomic per tile element.
-__global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
-                                                                 float* __restrict__ gw) {
-    __shared__ float red[4][16][64];
+__device__ __forceinline__ void wgrad_tile_body(const float* __restrict__ gy, const float* __restrict__ x, const WgG& g,
+                                                float* __restrict__ gw, const int64_t bid, float (&red)[4][16][64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int bslots = g.nslots >> 2;                                   // workgroups per tile
-    const int64_t bid = blockIdx.x;
     const int64_t tile = bid / bslots;
     const int slot = (int)(bid - tile * bslots) * 4 + wave;
     const int grp = (int)(tile / (g.tm * g.tk));
@@ -85,6 +86,78 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __
         const int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), col = l & 31;
         if (m0 + row < g.M && k0 + col < g.K) atomicAdd(gw + ((size_t)grp * g.M + m0 + row) * g.K + k0 + col, v);
     }
+}
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
+                                                                 float* __restrict__ gw) {
+    __shared__ float red[4][16][64];
+    wgrad_tile_body(gy, x, g, gw, (int64_t)blockIdx.x, red);
+}
+
+// Several weight-gradient problems in ONE launch (mspl_conv1x1_wgrad_batch): the grouped 1x1 convolutions of a training step are
+// ~33 launches of 8-25 us for <= 7 us of matrix work each, and nothing downstream waits for any of them -- the autograd nodes queue
+// them (autograd.WgradQueue) and the queue goes out as a few launches whose grids are the problems' grids back to back.
+constexpr int WG_MAXP = 16;
+struct WgProb {
+    const float* gy;
+    const float* x;
+    float* gw;
+    WgG g;
+    unsigned first;              // first workgroup of this problem
+};
+struct WgBatch {
+    WgProb p[WG_MAXP];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_batch_kernel(WgBatch b) {
+    __shared__ float red[4][16][64];
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.n; ++i)
+        if (blockIdx.x >= b.p[i].first) k = i;                          // uniform
+    const WgProb& q = b.p[k];
+    wgrad_tile_body(q.gy, q.x, q.g, q.gw, (int64_t)(blockIdx.x - q.first), red);
+}
+
+static bool wgrad_geom(int N, int G, int M, int K, int P, WgG& g, int64_t& blocks, int share) {
+    if (M < 8 || K < 8 || (P & 3) != 0) return false;
+    g.N = N; g.G = G; g.M = M; g.K = K; g.P = P;
+    g.tm = ceil_div(M, 32); g.tk = ceil_div(K, 32);
+    const int64_t tiles = (int64_t)G * g.tm * g.tk;
+    g.gpi = ceil_div(P, 64);
+    if ((int64_t)N * g.gpi >= (1ll << 30)) return false;
+    g.ngroups = N * g.gpi;
+    // (in a batch the chip is shared: `share` problems aim at 3072 waves together, each at least at a quarter of that)
+    const int target = std::max(768, 3072 / std::max(1, share));
+    int64_t ns = (target + tiles - 1) / tiles;
+    if (ns < 4) ns = 4;
+    if (ns > g.ngroups) ns = g.ngroups;
+    g.nslots = (int)((ns + 3) & ~3ll);
+    blocks = tiles * (g.nslots >> 2);
+    return blocks < (1ll << 30);
+}
+
+// Returns the number of problems launched from the front of the list (0: the first problem is not eligible for this kernel).
+int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const int* N, const int* G, const int* M,
+                             const int* K, const int* P, int nprob, hipStream_t s) {
+    WgBatch b;
+    memset(&b, 0, sizeof(b));
+    int64_t total = 0;
+    int n = 0;
+    const int share = std::min(nprob, 4);
+    for (; n < nprob && n < WG_MAXP; ++n) {
+        int64_t blocks;
+        if (!wgrad_geom(N[n], G[n], M[n], K[n], P[n], b.p[n].g, blocks, share)) break;
+        if (total + blocks >= (1ll << 31)) break;
+        b.p[n].gy = gy[n]; b.p[n].x = x[n]; b.p[n].gw = gw[n];
+        b.p[n].first = (unsigned)total;
+        total += blocks;
+    }
+    if (n == 0) return 0;
+    b.n = n;
+    hipLaunchKernelGGL(conv1x1_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, b);
+    return n;
 }
 
 // Called by mspl_conv_bwd_weight for K == 1 (gw already zeroed unless accumulating).  Returns 1 when the shape is left to the

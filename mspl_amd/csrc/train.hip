@@ -14,6 +14,8 @@
 namespace mspl {
 
 int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M, int K, int P, float* gw, hipStream_t s);
+int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const int* N, const int* G, const int* M,
+                             const int* K, const int* P, int nprob, hipStream_t s);
 
 struct ConvGeom {
     int N, Cin, Cout, G, cin_g, cout_g, H, W, Ho, Wo, K, stride, dil, pad;
@@ -1151,6 +1153,43 @@ extern "C" int mspl_conv_bwd_data(const float* gy, const float* w, int32_t N, in
     hipLaunchKernelGGL(conv_bwd_data_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, w, g,
                        accumulate, gx, total);
     MSPL_CHECK_LAUNCH("conv_bwd_data");
+    return MSPL_OK;
+}
+
+// Weight gradients of several grouped 1x1 convolutions, ACCUMULATED into gw[i] (parameter gradient buffers), in as few launches as
+// the problems allow: runs of problems that fit the matrix-core kernel share one launch (csrc/conv1x1_wgrad.hip), the others go
+// through mspl_conv_bwd_weight one by one.
+extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin, int32_t Cout, int32_t groups,
+                                    int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
+                                    float* gw, void* stream);
+
+extern "C" int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const int32_t* N,
+                                        const int32_t* Cin, const int32_t* Cout, const int32_t* groups, const int32_t* HW,
+                                        int32_t nprob, void* stream) {
+    MSPL_REQUIRE(gy && x && gw && N && Cin && Cout && groups && HW, MSPL_ERR_NULL_POINTER, "conv1x1_wgrad_batch: null pointer");
+    MSPL_REQUIRE(nprob >= 0 && nprob <= 4096, MSPL_ERR_BAD_SHAPE, "conv1x1_wgrad_batch: %d problems", nprob);
+    hipStream_t s = (hipStream_t)stream;
+    int G[16], M[16], K[16], P[16], NN[16];
+    int at = 0;
+    while (at < nprob) {
+        int cnt = 0;
+        for (; cnt < 16 && at + cnt < nprob; ++cnt) {
+            const int i = at + cnt;
+            MSPL_REQUIRE(gy[i] && x[i] && gw[i], MSPL_ERR_NULL_POINTER, "conv1x1_wgrad_batch: problem %d has a null pointer", i);
+            MSPL_REQUIRE(N[i] > 0 && Cin[i] > 0 && Cout[i] > 0 && groups[i] > 0 && HW[i] > 0 && Cin[i] % groups[i] == 0 &&
+                         Cout[i] % groups[i] == 0, MSPL_ERR_BAD_SHAPE, "conv1x1_wgrad_batch: problem %d: N=%d Cin=%d Cout=%d groups=%d HW=%d",
+                         i, N[i], Cin[i], Cout[i], groups[i], HW[i]);
+            NN[cnt] = N[i]; G[cnt] = groups[i]; M[cnt] = Cout[i] / groups[i]; K[cnt] = Cin[i] / groups[i]; P[cnt] = HW[i];
+        }
+        const int done = conv1x1_wgrad_mfma_batch(gy + at, x + at, gw + at, NN, G, M, K, P, cnt, s);
+        if (done > 0) {
+            MSPL_CHECK_LAUNCH("conv1x1_wgrad_batch");
+            at += done;
+        } else {                 // the first problem of the run is not for the matrix-core kernel
+            if (int rc = mspl_conv_bwd_weight(gy[at], x[at], N[at], Cin[at], Cout[at], groups[at], 1, HW[at], 1, 1, 1, 1, gw[at], stream)) return rc;
+            ++at;
+        }
+    }
     return MSPL_OK;
 }
 

@@ -699,3 +699,43 @@ def test_pyramid_low_resolution_branches_one_launch_each_way(cfg):
     for i in range(2):
         close(gx[i], grads[i][0], atol=2e-6, rtol=1e-5)
         close(gw[i] - 0.5, grads[i][1], atol=2e-4 * float(grads[i][1].abs().max() + 1), rtol=1e-4)
+
+
+def test_conv1x1_weight_gradients_batched_in_one_launch():
+    """mspl_conv1x1_wgrad_batch: the weight gradients of several grouped 1x1 convolutions accumulated into their buffers by one
+    launch per run of matrix-core problems (a problem with fewer than 8 channels per group in between goes through the generic kernel),
+    against torch; and autograd.WgradQueue: inside grad_sinks() the nodes queue them, the exit of the context sends them out."""
+    import ctypes
+    from mspl_amd import autograd as ag
+    from mspl_amd._native import check, lib
+    probs = [(2, 128, 512, 4, 16, 30), (3, 512, 128, 4, 16, 30), (1, 12, 24, 4, 8, 12), (2, 64, 48, 1, 36, 60), (1, 256, 256, 4, 5, 8),
+             (2, 32, 16, 1, 20, 36)]                     # (N, Cin, Cout, groups, H, W); the third one has 3 input channels per group
+    gys, xs, gws, refs = [], [], [], []
+    for i, (N, Cin, Cout, G, H, W) in enumerate(probs):
+        x = rnd(N, Cin, H, W, seed=40 + i)
+        gy = rnd(N, Cout, H, W, seed=60 + i)
+        w = torch.zeros(Cout, Cin // G, 1, 1, requires_grad=True)
+        refs.append(torch.autograd.grad(F.conv2d(x, w, None, 1, 0, 1, G), w, gy)[0])
+        gys.append(gy.to(DEV)); xs.append(x.to(DEV)); gws.append(torch.full((Cout, Cin // G, 1, 1), 0.25, device=DEV))
+    n = len(probs)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    col = lambda k: (ctypes.c_int32 * n)(*[p[k] for p in probs])
+    hw = (ctypes.c_int32 * n)(*[p[4] * p[5] for p in probs])
+    check(lib.mspl_conv1x1_wgrad_batch(arr(gys), arr(xs), arr(gws), col(0), col(1), col(2), col(3), hw, n,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for g, r in zip(gws, refs):
+        assert float((g.cpu() - 0.25 - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-5
+    # the queue: two convolutions' weight gradients are still pending inside the context, in their buffers after it
+    w1 = rnd(48, 64, 1, 1, seed=80, scale=0.1).to(DEV).requires_grad_(True)
+    w2 = rnd(512, 128, 1, 1, seed=81, scale=0.1).to(DEV).requires_grad_(True)
+    x1, x2 = rnd(2, 64, 36, 60, seed=82).to(DEV).requires_grad_(True), rnd(2, 512, 16, 30, seed=83).to(DEV).requires_grad_(True)
+    ref = torch.autograd.grad((ag.conv(x1, w1, 1, 1).sum() + ag.conv(x2, w2, 1, 4).square().sum()), [w1, w2])
+    w1.grad, w2.grad = torch.zeros_like(w1), torch.zeros_like(w2)
+    with torch.enable_grad(), ag.grad_sinks():
+        (ag.conv(x1, w1, 1, 1).sum() + ag.conv(x2, w2, 1, 4).square().sum()).backward()
+        pending = len(ag.WGRADS.items)
+        torch.cuda.synchronize()
+        assert float(w1.grad.abs().max()) == 0.0 and float(w2.grad.abs().max()) == 0.0
+    assert pending == 2 and len(ag.WGRADS.items) == 0
+    for g, r in zip((w1.grad, w2.grad), ref):
+        assert float((g - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-5
