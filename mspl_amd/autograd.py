@@ -657,7 +657,7 @@ def _pyr_down_backward(gt, x_shape, sizes, stage_ws, pooled, down, g_stage):
         check(lib.mspl_bilinear_bwd(_p(gt[i]), N, P, hs_, ws_, h, w, _p(g_e), _stream()))
         g_es.append(g_e)
     adds = []
-    if _PYR_DOWN_FUSED and 1 <= len(down) <= 2 and all((sizes[i][0] + 2) * (sizes[i][1] + 2) * 4 + h * 16 <= 64 * 1024 for i in down):
+    if _PYR_DOWN_FUSED and 1 <= len(down) <= 2 and all(((sizes[i][0] + 2) * (sizes[i][1] + 2) + sizes[i][0] * sizes[i][1]) * 4 + h * 16 <= 128 * 1024 for i in down):
         nbd = len(down)
         adds = [torch.empty((N, P, h, w), device=dev, dtype=torch.float32) for _ in down]
         arr = lambda ts: (ctypes.c_void_p * nbd)(*[t.data_ptr() for t in ts])         # noqa: E731

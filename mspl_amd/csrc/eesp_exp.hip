@@ -149,7 +149,21 @@ __global__ __launch_bounds__(512, 4) void eesp_dw_exp_kernel(const float* __rest
     stamp();
 
     int lid = xe_xcd_remap(blockIdx.x, nwg);
-    const int gs = lid % NPW;  lid /= NPW;
+    int gs;
+    if (NPW == 2 && (nwg & 15) == 0) {
+        // Two workgroups per band: the one with groups 2-3 computes all four depthwise branches, the one with groups 0-1 only two (the
+        // hierarchical sum needs every branch below a group's own): ~1.3x the time.  When the grid is more than one round of
+        // workgroups (288 on 256 CUs at 18 x 30, batch 16) the leftover ones should be the SHORT ones: inside every XCD's chunk of
+        // the grid (workgroups are dealt to the XCDs round-robin, a chunk starts in order) the long workgroups of the chunk's
+        // bands come first, the short ones after them.  Same (band, group set) pairs, another launch order (measured alone, level 4:
+        // 35.3 -> 34.8 us at batch 16, 58.0 -> 54.4 us at batch 32, the size the label lanes launch).
+        const int q = nwg >> 3, half = q >> 1;
+        const int xcd = lid / q, l = lid - xcd * q;
+        gs = l < half ? 1 : 0;
+        lid = xcd * half + (l < half ? l : l - half);
+    } else {
+        gs = lid % NPW;  lid /= NPW;
+    }
     const int band = lid % bands;
     const int img = lid / bands;
     const int y0 = SPLIT ? band >> 1 : band * TH;

@@ -10,9 +10,11 @@
 // Rounds 3-4 ran this as three launches per branch (conv3x3 with flipped weights, the generic 3x3 weight gradient, the adaptive
 // pool's gather backward) on maps of 5x5 .. 72x120 values: six launches of pure latency per pyramid and step, thirty per train
 // step.  Here a workgroup owns (plane, branch, band of full-resolution rows): g_e of the plane sits zero-haloed in LDS (<= 36 KB),
-// g_p is evaluated where the gather needs it (never stored), the band's share of the low-resolution pixels feeds the nine tap sums
+// g_p of the rows a band touches is evaluated once into LDS, the band's share of the low-resolution pixels feeds the nine tap sums
 // (wave + LDS reduction, nine atomics per workgroup into the parameter's gradient buffer).
 #include <stdlib.h>
+
+#include <mutex>
 
 #include "common.hpp"
 
@@ -82,21 +84,28 @@ __global__ __launch_bounds__(256) void pyr_down_mid_bwd_kernel(PdbGeom g) {
         __syncthreads();
         if (tid < 9 && cnt > 0) atomicAdd(g.gw[bi] + (size_t)c * 9 + tid, (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
     }
-    // ---- full-resolution gradient of this band's rows: gather over the pooling windows that contain the pixel; g_p evaluated in
-    // place from the zero-haloed g_e: g_p[i, j] = sum w[ky][kx] * g_e[i - ky + 1, j - kx + 1] = sum w[ky][kx] * GE[i + 2 - ky][j + 2 - kx]
-    auto gp_at = [&](int i, int j) {
-        const float* q = GE + i * WS2 + j;             // GE[i + dy][j + dx], dy, dx in 0..2
-        float v = w00 * q[2 * WS2 + 2];
-        v = fmaf(w01, q[2 * WS2 + 1], v);  v = fmaf(w02, q[2 * WS2], v);
-        v = fmaf(w10, q[WS2 + 2], v);      v = fmaf(w11, q[WS2 + 1], v);  v = fmaf(w12, q[WS2], v);
-        v = fmaf(w20, q[2], v);            v = fmaf(w21, q[1], v);        v = fmaf(w22, q[0], v);
-        return v;
-    };
+    // ---- g_p of the low-resolution rows this band's full-resolution rows can touch -> LDS (evaluated once per cell, not once per
+    // full-resolution pixel: a 2x2 window has four pixels, the 0.1-scale windows ~100):
+    // g_p[i, j] = sum w[ky][kx] * g_e[i - ky + 1, j - kx + 1] = sum w[ky][kx] * GE[i + 2 - ky][j + 2 - kx]
+    float* GP = smem + (size_t)(hs + 2) * WS2;         // [hs][ws]
+    const int y0 = band * h / g.bands, y1 = (band + 1) * h / g.bands;
+    {
+        const int ia = (int)(((unsigned)y0 * (unsigned)hs) / (unsigned)h);
+        const int ib = y1 > y0 ? min(hs - 1, (int)(((unsigned)(y1 - 1) * (unsigned)hs) / (unsigned)h) + 2) : ia - 1;
+        for (int t = tid; t < (ib - ia + 1) * ws; t += 256) {
+            const int i = ia + t / ws, j = t - (t / ws) * ws;
+            const float* q = GE + i * WS2 + j;         // GE[i + dy][j + dx], dy, dx in 0..2
+            float v = w00 * q[2 * WS2 + 2];
+            v = fmaf(w01, q[2 * WS2 + 1], v);  v = fmaf(w02, q[2 * WS2], v);
+            v = fmaf(w10, q[WS2 + 2], v);      v = fmaf(w11, q[WS2 + 1], v);  v = fmaf(w12, q[WS2], v);
+            v = fmaf(w20, q[2], v);            v = fmaf(w21, q[1], v);        v = fmaf(w22, q[0], v);
+            GP[i * ws + j] = v;
+        }
+    }
     // Which windows contain a row / a column: ATen's windows overlap when the sizes do not divide, so an index sits in up to two
     // (three allowed for) of them.  Rows: a small LDS table built once per workgroup (one thread per row: the divisions are not
     // repeated per pixel); columns: per-thread registers (a thread keeps its column while it walks the band's rows).
-    const int y0 = band * h / g.bands, y1 = (band + 1) * h / g.bands;
-    int* RT = reinterpret_cast<int*>(smem + (size_t)(hs + 2) * WS2);         // [y1 - y0][4]: first window, then up to three heights (0 = not inside)
+    int* RT = reinterpret_cast<int*>(GP + (size_t)hs * ws);         // [y1 - y0][4]: first window, then up to three heights (0 = not inside)
     for (int r = tid; r < y1 - y0; r += 256) {
         const int y = y0 + r;
         const int i0 = (int)(((unsigned)y * (unsigned)hs) / (unsigned)h);
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void pyr_down_mid_bwd_kernel(PdbGeom g) {
                 if (hh == 0) continue;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    if (jw[k]) acc += gp_at(i0 + a, j0 + k) / (float)(hh * jw[k]);
+                    if (jw[k]) acc += GP[(i0 + a) * ws + j0 + k] / (float)(hh * jw[k]);
             }
             gxp[(size_t)(y0 + r) * w + x] = acc;
         }
@@ -159,11 +168,14 @@ extern "C" int mspl_pyr_down_mid_bwd(const float* const* g_e, const float* const
         MSPL_REQUIRE((int64_t)(h + 1) * hs[i] < (1ll << 31) && (int64_t)(w + 1) * ws[i] < (1ll << 31), MSPL_ERR_BAD_SHAPE,
                      "pyr_down_mid_bwd: map too large for the 32-bit window arithmetic");
         g.hs[i] = hs[i]; g.ws[i] = ws[i]; g.ge[i] = g_e[i]; g.pooled[i] = pooled[i]; g.wts[i] = stage_w[i]; g.gw[i] = gw[i]; g.gx[i] = gx[i];
-        const size_t b = (size_t)(hs[i] + 2) * (ws[i] + 2) * sizeof(float);
+        const size_t b = ((size_t)(hs[i] + 2) * (ws[i] + 2) + (size_t)hs[i] * ws[i]) * sizeof(float);      // g_e (haloed) + g_p
         if (b > lds) lds = b;
     }
     lds += (size_t)h * 4 * sizeof(int);              // the row table of a band (<= h rows)
-    MSPL_REQUIRE(lds <= 64 * 1024, MSPL_ERR_UNSUPPORTED, "pyr_down_mid_bwd: a %zu-byte low-resolution map does not fit the workgroup's LDS", lds);
+    static std::once_flag once;
+    static bool attr_ok = false;
+    std::call_once(once, [] { attr_ok = hipFuncSetAttribute((const void*)pyr_down_mid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess; });
+    MSPL_REQUIRE(lds <= (attr_ok ? 128 : 64) * 1024, MSPL_ERR_UNSUPPORTED, "pyr_down_mid_bwd: a %zu-byte low-resolution map does not fit the workgroup's LDS", lds);
     // bands of full-resolution rows per plane: enough workgroups to fill the chip (a plane's g_e is re-read per band: <= 36 KB from L2)
     const int64_t planes = (int64_t)N * P;
     int bands = 1;
