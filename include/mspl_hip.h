@@ -616,6 +616,11 @@ int mspl_eesp_bwd_fused_bnstat(const float* z, const float* gy, const float* x, 
 /* out = srcs[0] + ... + srcs[n-1] (1 <= n <= 8 equally shaped fp32 tensors of `count` elements, count % 4 == 0, 16-byte aligned; srcs
  * is a HOST array of device pointers): the gradient of a tensor with several consumers in one launch (autograd.FanOutFn). */
 int mspl_sum_n(const float* const* srcs, int32_t n, int64_t count, float* out, void* stream);
+/* The same sum + a constant per (N*C) plane: out[plane, :] = sum_k srcs[k][plane, :] + mul * plane_const[plane] -- the gradient of a
+ *     global average pool (EfficientPWConv's gate, nn_layers/efficient_pt.py:25-29) joins the sum as N*C values instead of a
+ *     broadcast full-size tensor.  srcs: n tensors of planes * HW floats. */
+int mspl_sum_n_planes(const float* const* srcs, int32_t n, const float* plane_const, float mul, int32_t planes, int32_t HW, float* out,
+                      void* stream);
 
 /* Transposed copies of many convolution weights in one launch (the weights of the data-gradient convolutions of a training
  * step; replaces one ATen permute copy + flip per convolution, autograd.ConvFn.backward).  seg_table: device array of

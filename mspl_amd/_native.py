@@ -159,6 +159,7 @@ SIGNATURES = {
     'mspl_png_writer_destroy': [ctypes.c_void_p],
     'mspl_abi_version': [],
     'mspl_sum_n': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_f32p, ctypes.c_void_p],
+    'mspl_sum_n_planes': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_f32p, ctypes.c_float, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_transpose_weights': [ctypes.c_void_p, ctypes.c_void_p, c_i32, ctypes.c_void_p],
     'mspl_adam_step': [c_f32p, c_f32p, c_f32p, c_f32p, c_i64] + [ctypes.c_float] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_merge_labels_fwd': [ctypes.POINTER(ctypes.c_void_p), c_i32, c_i64, c_i32, c_i32, c_i32, ctypes.c_void_p,

@@ -489,6 +489,19 @@ class FanOutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        # a gradient that is constant over every plane (GapGateFn hands out an expanded (N,C,1,1) tensor: the global average pool's
+        # gradient) joins the sum as N * C values: nobody writes, and the sum does not read, a full-size broadcast of it
+        pconst = [g for g in gs if g is not None and g.dim() == 4 and g.stride(2) == 0 and g.stride(3) == 0 and g.shape[2] * g.shape[3] > 1]
+        full = [g for g in gs if g is not None and not any(g is p for p in pconst)]
+        if len(pconst) == 1 and full and full[0].dim() == 4 and (full[0].shape[2] * full[0].shape[3]) % 4 == 0:
+            live = [_c(g) for g in full]
+            if not any(t.data_ptr() % 16 for t in live):
+                N_, C_, H_, W_ = live[0].shape
+                pc = pconst[0][:, :, 0, 0].contiguous()
+                out = torch.empty_like(live[0])
+                ptrs = (ctypes.c_void_p * len(live))(*[t.data_ptr() for t in live])
+                check(lib.mspl_sum_n_planes(ptrs, len(live), _p(pc), 1.0, N_ * C_, H_ * W_, _p(out), _stream()))
+                return out, None
         live = [_c(g) for g in gs if g is not None]
         if not live:
             return None, None
@@ -1017,6 +1030,9 @@ class AdaptivePoolFn(torch.autograd.Function):
         return gx, None
 
 
+_GATE_EXPANDED = os.environ.get('MSPL_GATE_EXPANDED', '1') != '0'      # A/B aid
+
+
 class GapGateFn(torch.autograd.Function):
     """gate = sigmoid(W . mean_hw(x)) -> (N, Cout)."""
 
@@ -1047,8 +1063,15 @@ class GapGateFn(torch.autograd.Function):
             check(lib.mspl_gap_gate_bwd(_p(_c(ggate)), _p(gate), _p(mean), _p(w), N, Cin, Cout, _p(gw), _p(gmean), _stream()))
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(ctx.shape, device=w.device, dtype=torch.float32)
-            check(lib.mspl_plane_broadcast(_p(gmean), N * Cin, H * W, 1.0 / (H * W), 0, _p(gx), _stream()))
+            if _GATE_EXPANDED:
+                # d mean / d x is 1 / HW everywhere in the plane: hand out the (N,Cin,1,1) values expanded over the plane (strides 0).  A
+                # FanOutFn downstream folds them into its one summation launch; any other consumer materialises them (_c).
+                gsc = torch.empty_like(gmean)
+                check(lib.mspl_plane_broadcast(_p(gmean), N * Cin, 1, 1.0 / (H * W), 0, _p(gsc), _stream()))       # (N * Cin values)
+                gx = gsc.view(N, Cin, 1, 1).expand(N, Cin, H, W)
+            else:
+                gx = torch.empty(ctx.shape, device=w.device, dtype=torch.float32)
+                check(lib.mspl_plane_broadcast(_p(gmean), N * Cin, H * W, 1.0 / (H * W), 0, _p(gx), _stream()))
         return gx, gw
 
 

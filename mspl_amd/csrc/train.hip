@@ -1693,6 +1693,46 @@ extern "C" int mspl_sum_n(const float* const* srcs, int32_t n, int64_t count, fl
     return MSPL_OK;
 }
 
+namespace mspl {
+// sum of n tensors + a per-plane constant (mul * pc[plane]): the gradient of a global average pool is constant over its plane, so the
+// sum of an encoder output's gradients takes it as N * C values instead of a full-size tensor somebody wrote only to have it added
+__global__ __launch_bounds__(256) void sum_n_planes_kernel(SumSrcs srcs, int n, const float* __restrict__ pc, float mul, int HW4,
+                                                           float* __restrict__ out) {
+    const int plane = blockIdx.z * gridDim.y + blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= HW4) return;
+    const int64_t i = (int64_t)plane * HW4 + q;
+    const float c = mul * pc[plane];
+    float4 a = reinterpret_cast<const float4*>(srcs.p[0])[i];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        if (k >= n) break;
+        const float4 b = reinterpret_cast<const float4*>(srcs.p[k])[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x += c; a.y += c; a.z += c; a.w += c;
+    reinterpret_cast<float4*>(out)[i] = a;
+}
+}  // namespace mspl
+
+extern "C" int mspl_sum_n_planes(const float* const* srcs, int32_t n, const float* plane_const, float mul, int32_t planes, int32_t HW,
+                                 float* out, void* stream) {
+    MSPL_REQUIRE(srcs && out && plane_const, MSPL_ERR_NULL_POINTER, "sum_n_planes: null pointer");
+    MSPL_REQUIRE(n >= 1 && n <= 8 && planes > 0 && HW > 0 && (HW & 3) == 0, MSPL_ERR_BAD_SHAPE,
+                 "sum_n_planes: n=%d planes=%d HW=%d (1..8 tensors, HW %% 4 == 0)", n, planes, HW);
+    mspl::SumSrcs s;
+    for (int k = 0; k < 8; ++k) {
+        s.p[k] = k < n ? srcs[k] : srcs[0];
+        MSPL_REQUIRE(s.p[k] && (((uintptr_t)s.p[k]) & 15) == 0, MSPL_ERR_NULL_POINTER, "sum_n_planes: source %d is NULL or not 16-byte aligned", k);
+    }
+    MSPL_REQUIRE((((uintptr_t)out) & 15) == 0, MSPL_ERR_UNSUPPORTED, "sum_n_planes: unaligned destination");
+    const int gy = planes < 65535 ? planes : 65535;
+    hipLaunchKernelGGL(mspl::sum_n_planes_kernel, dim3((unsigned)ceil_div(HW / 4, 256), (unsigned)gy, (unsigned)ceil_div(planes, gy)), dim3(256), 0,
+                       (hipStream_t)stream, s, n, plane_const, mul, HW / 4, out);
+    MSPL_CHECK_LAUNCH("sum_n_planes");
+    return MSPL_OK;
+}
+
 extern "C" int mspl_hff_suffix_sum(const float* g, int32_t N, int32_t n, int32_t HW, float* out, void* stream) {
     MSPL_REQUIRE(g && out, MSPL_ERR_NULL_POINTER, "hff_suffix_sum: null pointer");
     MSPL_REQUIRE(N > 0 && n > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "hff_suffix_sum: bad shape");

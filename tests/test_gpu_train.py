@@ -739,3 +739,21 @@ def test_conv1x1_weight_gradients_batched_in_one_launch():
     assert pending == 2 and len(ag.WGRADS.items) == 0
     for g, r in zip((w1.grad, w2.grad), ref):
         assert float((g - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-5
+
+
+def test_fan_out_takes_the_gate_gradient_as_plane_constants():
+    """An encoder output feeds the EfficientPWConv gate (global average pool -> 1x1 -> sigmoid, nn_layers/efficient_pt.py:25-29) and
+    other consumers: the pool's gradient is constant over every plane; GapGateFn hands it out as an expanded (N,C,1,1) tensor and
+    FanOutFn adds it inside its one summation launch (mspl_sum_n_planes) -- against torch autograd on the CPU."""
+    from mspl_amd import autograd as ag
+    x, w = rnd(2, 8, 6, 10, seed=1), rnd(6, 8, 1, 1, seed=2)
+    y, m1, m2 = rnd(2, 6, 6, 10, seed=3), rnd(2, 8, 6, 10, seed=4), rnd(2, 8, 6, 10, seed=5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = (y * torch.sigmoid(F.conv2d(F.adaptive_avg_pool2d(xr, 1), wr))).sum() + (xr * m1).sum() + (xr * xr * m2).sum()
+    gx_ref, gw_ref = torch.autograd.grad(ref, [xr, wr])
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    a = ag.fan_out(xd, 3)
+    out = ag.channel_scale(y.to(DEV), ag.gap_gate(a[0], wd)).sum() + (a[1] * m1.to(DEV)).sum() + (a[2] * a[2] * m2.to(DEV)).sum()
+    gx, gw = torch.autograd.grad(out, [xd, wd])
+    close(gx, gx_ref, atol=1e-5, rtol=1e-5)
+    close(gw, gw_ref, atol=1e-5, rtol=1e-4)
