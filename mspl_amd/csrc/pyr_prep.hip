@@ -243,11 +243,25 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
     auto load_row = [&](int y) {
         return *reinterpret_cast<const vecw*>(xp + (size_t)y * w + cl * VW);
     };
+    // The pooled maps sit ZERO-HALOED in LDS (row stride ws + 2, a zero row above and below): the depthwise 3x3 below then reads its
+    // nine taps unconditionally (four compares + selects per tap before: 55 of the ~80 vector instructions per output).
+    for (int i = 0; i < g.nb; ++i) {
+        float* Pz = smem + g.off[i];
+        const int hs = g.hs[i], WP = g.ws[i] + 2;
+        for (int t = tid; t < 2 * WP + 2 * hs; t += nthr) {
+            int at;
+            if (t < WP) at = t;                                             // top row
+            else if (t < 2 * WP) at = (hs + 1) * WP + (t - WP);             // bottom row
+            else { const int r = (t - 2 * WP) >> 1; at = (r + 1) * WP + ((t & 1) ? WP - 1 : 0); }      // left / right column
+            Pz[at] = 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < PP_MAXB; ++i) {
         if (i >= g.nb) break;
-        float* Pm = smem + g.off[i];
         const int hs = g.hs[i], ws = g.ws[i];
+        const int WP = ws + 2;
+        float* Pm = smem + g.off[i] + WP + 1;              // (0, 0) of the map inside its halo
         if (g.exact2[i]) {
             constexpr int U = 4;                           // pooled rows per group and trip: 8 row loads in flight per lane
             for (int o0 = 0; o0 < hs; o0 += ngroups * U) {
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
                         for (int j = 0; j < VW / 2; ++j) {
                             float s2 = 0.f;                  // (ATen's order inside the window: row-major)
                             s2 += r0[u][2 * j]; s2 += r0[u][2 * j + 1]; s2 += r1[u][2 * j]; s2 += r1[u][2 * j + 1];
-                            Pm[o * ws + cl * (VW / 2) + j] = s2 / 4.0f;
+                            Pm[o * WP + cl * (VW / 2) + j] = s2 / 4.0f;
                         }
                     }
                 }
@@ -308,18 +322,19 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
                     int xx = x0;
                     for (; xx + 1 < x1; xx += 2) { b0 += RB[xx]; b1 += RB[xx + 1]; }
                     if (xx < x1) b0 += RB[xx];
-                    if (ok) Pm[o * ws + ox] = (b0 + b1) / (float)((y1 - y0) * (x1 - x0));
+                    if (ok) Pm[o * WP + ox] = (b0 + b1) / (float)((y1 - y0) * (x1 - x0));
                 }
             }
         }
     }
     __syncthreads();
-    // depthwise 3x3 (zero padding) on the pooled maps
+    // depthwise 3x3 (zero padding = the halo) on the pooled maps
 #pragma unroll
     for (int i = 0; i < PP_MAXB; ++i) {
         if (i >= g.nb) break;
-        const float* Pm = smem + g.off[i];
         const int hs = g.hs[i], ws = g.ws[i];
+        const int WP = ws + 2;
+        const float* Pm = smem + g.off[i];                 // haloed: map element (y, x) at (y + 1) * WP + x + 1
         const float* w9 = g.wts[i] + (size_t)c * 9;
         const float w00 = w9[0], w01 = w9[1], w02 = w9[2], w10 = w9[3], w11 = w9[4], w12 = w9[5], w20 = w9[6], w21 = w9[7], w22 = w9[8];
         float* dst = g.out[i] + (size_t)plane * hs * ws;
@@ -327,13 +342,13 @@ __global__ __launch_bounds__(1024) void pyr_prep_stream_kernel(const float* __re
         int oy = tid / ws, ox = tid - oy * ws;             // one division; then the index advances by the block size per trip
         const int dy256 = nthr / ws, dx256 = nthr - dy256 * ws;
         for (int idx = tid; idx < total; idx += nthr) {
-            auto at = [&](int yy, int xx) { return (yy >= 0 && yy < hs && xx >= 0 && xx < ws) ? Pm[yy * ws + xx] : 0.f; };
-            float v = w00 * at(oy - 1, ox - 1);
-            v = fmaf(w01, at(oy - 1, ox), v);  v = fmaf(w02, at(oy - 1, ox + 1), v);
-            v = fmaf(w10, at(oy, ox - 1), v);  v = fmaf(w11, at(oy, ox), v);  v = fmaf(w12, at(oy, ox + 1), v);
-            v = fmaf(w20, at(oy + 1, ox - 1), v);  v = fmaf(w21, at(oy + 1, ox), v);  v = fmaf(w22, at(oy + 1, ox + 1), v);
+            const float* q = Pm + oy * WP + ox;            // q[dy * WP + dx] = map(oy - 1 + dy, ox - 1 + dx)
+            float v = w00 * q[0];
+            v = fmaf(w01, q[1], v);  v = fmaf(w02, q[2], v);
+            v = fmaf(w10, q[WP], v);  v = fmaf(w11, q[WP + 1], v);  v = fmaf(w12, q[WP + 2], v);
+            v = fmaf(w20, q[2 * WP], v);  v = fmaf(w21, q[2 * WP + 1], v);  v = fmaf(w22, q[2 * WP + 2], v);
             dst[idx] = v;
-            if (g.pool[i]) g.pool[i][(size_t)plane * total + idx] = Pm[idx];
+            if (g.pool[i]) g.pool[i][(size_t)plane * total + idx] = q[WP + 1];
             oy += dy256;  ox += dx256;
             if (ox >= ws) { ox -= ws; ++oy; }
         }
@@ -364,7 +379,7 @@ static int prep_stream_try(const float* x, int N, int P, int h, int w, int nb, c
             any_large = true;
         }
         g.off[i] = off_f;
-        off_f += (hs[i] * ws[i] + 3) & ~3;
+        off_f += ((hs[i] + 2) * (ws[i] + 2) + 3) & ~3;            // zero-haloed
     }
     g.rboff = off_f;
     g.RBS = (w + 3) & ~3;

@@ -132,6 +132,93 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
     }
 }
 
+// The DownSampler's pool (nn_layers/eesp.py:131-144: avg_pool(input) into channels [0, nin) of the block's output, + the image
+// reinforcement, module PReLU) in its own lean form.  The generic strip kernel above spent ~220 vector instructions per strip on
+// this launch (64-bit addressing of ~13 loads, a plane / C division per thread, the epilogue's optional operands behind uniform
+// branches): 13 M of a label pass's 262 M.  Here: grid = (strips, channel, image) -- no division; 32-bit offsets on uniform bases;
+// the epilogue is exactly scale / shift / three reinforcement planes / PReLU; the plane-sum partial goes through DPP adds.
+// Same arithmetic in the same order as avgpool3x3s2_kernel<true> with that epilogue (bit-identical outputs and plane sums).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    // total in lane 63 (row_shr 1, 2, 3 within rows of 16, then across bank groups and rows: the canonical 7-step DPP reduction)
+#define MSPL_DPP(x, ctrl, rm, bm) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rm, bm, true))
+    float t = v + MSPL_DPP(v, 0x111, 0xf, 0xf);
+    t += MSPL_DPP(v, 0x112, 0xf, 0xf);
+    t += MSPL_DPP(v, 0x113, 0xf, 0xf);
+    t += MSPL_DPP(t, 0x114, 0xf, 0xe);
+    t += MSPL_DPP(t, 0x118, 0xf, 0xc);
+    t += MSPL_DPP(t, 0x142, 0xa, 0xf);          // row_bcast:15
+    t += MSPL_DPP(t, 0x143, 0xc, 0xf);          // row_bcast:31
+#undef MSPL_DPP
+    return t;
+}
+
+struct DpGeom {
+    int C, Hi, Wi, Ho, Wo, XS;        // input channels (= pooled channels), sizes, strips per output row
+    unsigned mag_xs;
+    int ctot;                         // channels of the destination tensor
+};
+
+__global__ __launch_bounds__(256) void avgpool3x3s2_down_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ alpha,
+                                                                const float* __restrict__ reinf_r, const float* __restrict__ reinf_w,
+                                                                DpGeom g, float* __restrict__ out, float* __restrict__ psum) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const unsigned s = blockIdx.x * 256u + threadIdx.x;
+    const bool live = s < (unsigned)(g.Ho * g.XS);
+    float own = 0.f;
+    if (live) {
+        const int y = g.XS == 1 ? (int)s : (int)__umulhi(s, g.mag_xs);
+        const int x0 = ((int)s - y * g.XS) * 4;
+        const float* src = x + ((size_t)n * g.C + c) * (size_t)g.Hi * g.Wi;          // uniform
+        float4 a[3], b[3];
+        float l[3], m[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * y - 1 + ky;
+            m[ky] = (iy >= 0 && iy < g.Hi) ? 1.f : 0.f;
+            const unsigned o = (unsigned)(min(max(iy, 0), g.Hi - 1) * g.Wi + 2 * x0);
+            a[ky] = *reinterpret_cast<const float4*>(src + o);
+            b[ky] = *reinterpret_cast<const float4*>(src + o + 4);
+            l[ky] = src[x0 > 0 ? o - 1 : o];
+        }
+        const float lm = x0 > 0 ? 1.f : 0.f;
+        own = ((a[1].x + a[1].y) + (a[1].z + a[1].w)) + ((b[1].x + b[1].y) + (b[1].z + b[1].w));
+        own += m[2] * (((a[2].x + a[2].y) + (a[2].z + a[2].w)) + ((b[2].x + b[2].y) + (b[2].z + b[2].w)));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float w = m[ky];
+            acc[0] += w * ((lm * l[ky] + a[ky].x) + a[ky].y);
+            acc[1] += w * ((a[ky].y + a[ky].z) + a[ky].w);
+            acc[2] += w * ((a[ky].w + b[ky].x) + b[ky].y);
+            acc[3] += w * ((b[ky].y + b[ky].z) + b[ky].w);
+        }
+        const unsigned pix = (unsigned)(y * g.Wo + x0), hw = (unsigned)(g.Ho * g.Wo);
+        const float sc = scale[c], sh = shift[c], al = alpha[c];                     // uniform
+        const float rw0 = reinf_w[c * 3], rw1 = reinf_w[c * 3 + 1], rw2 = reinf_w[c * 3 + 2];
+        const float* r = reinf_r + (size_t)n * 3 * hw;                               // uniform
+        const float4 r0 = *reinterpret_cast<const float4*>(r + pix);
+        const float4 r1 = *reinterpret_cast<const float4*>(r + hw + pix);
+        const float4 r2 = *reinterpret_cast<const float4*>(r + 2 * hw + pix);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[j] * (1.0f / 9.0f), sc, sh);
+        v[0] += rw0 * r0.x + rw1 * r1.x + rw2 * r2.x;
+        v[1] += rw0 * r0.y + rw1 * r1.y + rw2 * r2.y;
+        v[2] += rw0 * r0.z + rw1 * r1.z + rw2 * r2.z;
+        v[3] += rw0 * r0.w + rw1 * r1.w + rw2 * r2.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : al * v[j];
+        store_out4(out + ((size_t)n * g.ctot + c) * (size_t)hw + pix, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    own = wave_sum_dpp(own);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = own;
+    __syncthreads();
+    // one slot per (plane, workgroup), planes in (n, c) order: the gate sums the slots in order
+    if (threadIdx.x == 0) psum[((size_t)n * g.C + c) * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // The column sources / weights depend on the output column only: a workgroup computes the table of the columns it
 // touches once into LDS (4 floats per column) instead of four bilinear_src evaluations per thread; source reads use
 // 32-bit offsets from the plane base.
@@ -402,6 +489,17 @@ extern "C" int mspl_avgpool3x3s2_psum_fwd(const float* x, int32_t N, int32_t C, 
     RsGeom g; Epi e; int64_t total;
     const int Ho = H > 0 ? (H - 1) / 2 + 1 : 0, Wo = W > 0 ? (W - 1) / 2 + 1 : 0;
     if (int rc = resample_common("avgpool3x3s2_psum", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
+    // the DownSampler's call (scale, shift, PReLU and the image reinforcement on an un-gated destination with whole 16-byte rows): lean form
+    if (e.scale && e.shift && e.alpha && e.reinf_r && e.reinf_w && !e.pre_add && !e.residual && !e.gate && !e.raw && e.coff == 0 &&
+        (W & 3) == 0 && (Wo & 3) == 0 && (H & 1) == 0 && C <= 65535 && N <= 65535 && (int64_t)H * W < (1ll << 30) &&
+        ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)e.reinf_r)) & 15) == 0) {
+        DpGeom d;
+        d.C = C; d.Hi = H; d.Wi = W; d.Ho = Ho; d.Wo = Wo; d.XS = g.XS; d.mag_xs = g.mag_xs; d.ctot = e.ctot;
+        hipLaunchKernelGGL(avgpool3x3s2_down_kernel, dim3((unsigned)ceil_div(Ho * g.XS, 256), (unsigned)C, (unsigned)N), dim3(256), 0,
+                           (hipStream_t)stream, x, e.scale, e.shift, e.alpha, e.reinf_r, e.reinf_w, d, out, psum);
+        MSPL_CHECK_LAUNCH("avgpool3x3s2_psum(DownSampler form)");
+        return MSPL_OK;
+    }
     hipLaunchKernelGGL(avgpool3x3s2_kernel<true>, strip_grid(g), dim3(256), 0, (hipStream_t)stream, x, g, e, out, psum);
     MSPL_CHECK_LAUNCH("avgpool3x3s2_psum");
     return MSPL_OK;
