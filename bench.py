@@ -310,6 +310,8 @@ def cityscapes_rate(dev, iters=12):
 
 
 SUPERVISED_BYTES_PER_IMAGE = 947.7e6     # tools/train_bytes.py 13 288 480: the same accounting for C=13 at 288x480
+SUPERVISED_BN_STAT_BYTES_PER_IMAGE = 316.7e6     # ... and what batch statistics need on top: per BatchNorm one read of its input (forward) and one
+                                                 # pass over (gradient, input) for the two channel sums (backward)
 EVAL_BYTES_PER_IMAGE = 306.7e6           # forward of the C=5 model at 256x480 (305.7 MB, tools/train_bytes.py) + the int64 labels (8 B / pixel)
 TRAIN_BYTES_PER_IMAGE = 820.5e6          # DESIGN.md section 7 / tools/train_bytes.py: forward (305.7 MB, = SURVEY 8(d)'s 306.9) + data-gradient + weight-gradient
                                          # passes per image in SURVEY 8(d)'s accounting (weighted layers 3x their forward bytes, weightless ones 2x), C=5, 256x480
@@ -464,13 +466,17 @@ def supervised_step_rate(dev, iters=6):
         loss, _ = step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    achieved = SUPERVISED_BYTES_PER_IMAGE * BATCH / dt / 1e9
+    total_bytes = SUPERVISED_BYTES_PER_IMAGE + SUPERVISED_BN_STAT_BYTES_PER_IMAGE
+    achieved = total_bytes * BATCH / dt / 1e9
     return {'value': round(BATCH / dt, 1), 'unit': 'images/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': iters,
-            'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_image': SUPERVISED_BYTES_PER_IMAGE, 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_image': total_bytes, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'accounting': 'tools/train_bytes.py 13 288 480 (the train step\'s accounting: forward + data gradient + weight '
-                                       'gradient of every weighted layer, BatchNorm / PReLU = 0 -- the batch-statistics pass over every '
-                                       'convolution result, which this mode needs on top, is NOT counted)'},
+                         'frac_without_statistics_passes': round(SUPERVISED_BYTES_PER_IMAGE * BATCH / dt / 1e9 / HBM_PEAK_GBS, 4),
+                         'accounting': 'tools/train_bytes.py 13 288 480: forward + data gradient + weight gradient of every weighted layer '
+                                       '(947.7 MB / image, the train step\'s accounting, BatchNorm / PReLU = 0) + the batch-statistics '
+                                       'passes this mode needs (316.7 MB / image: per BatchNorm one read of its input for the statistics and '
+                                       'one pass over (gradient, input) for the backward\'s channel sums); rounds 3-4 quoted the first term alone '
+                                       '(frac_without_statistics_passes)'},
             'workload': 'train_seg_ue iteration, ESPDNet-UE s=2.0 C=13 in train() (batch-statistics BN), bs=16 x 3 x 288 x 480 fp32, '
                         'CrossEntropy + flooding + SGD(2 lr groups), hipGraph replay + SGD kernels',
             'loss_finite': bool(torch.isfinite(loss))}
@@ -864,21 +870,21 @@ def main():
                 return n
         return None
     fam_traffic = {}
-    tname = newest(['r04_k2_hbm_traffic.json'])
+    tname = newest(['r05_k2_hbm_traffic.json', 'r04_k2_hbm_traffic.json'])
     if tname:
         tj = json.load(open(os.path.join(ROOT, 'profiles', tname)))
         fam_traffic = {'exp': tj.get('fused_avg_traffic_bytes_per_launch'), 'k2': tj.get('standalone_avg_traffic_bytes_per_launch'),
                        'source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % tname}
     # measured HBM bytes of one whole pass (every kernel; tools/pass_traffic.py, same PMC recipe)
     path_traffic, path_traffic_src = None, None
-    pname = newest(['r04_pass_hbm_traffic.json', 'r03_pass_hbm_traffic.json', 'r02_pass_hbm_traffic.json'])
+    pname = newest(['r05_pass_hbm_traffic.json', 'r04_pass_hbm_traffic.json', 'r03_pass_hbm_traffic.json', 'r02_pass_hbm_traffic.json'])
     if pname:
         path_traffic = int(json.load(open(os.path.join(ROOT, 'profiles', pname)))['total_MB_per_image'] * 1e6)
         path_traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over one pass)' % pname
     # the same kernels' average duration in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --profile-pass
     # --in-flight 1` (label passes only): the figure the live in-pass measurement has to agree with
     rocprof_us, rocprof_src = {}, None
-    cname = newest(['r04_kernel_stats_inflight1.csv'])
+    cname = newest(['r05_kernel_stats_inflight1.csv', 'r04_kernel_stats_inflight1.csv'])
     if cname:
         import csv
         acc_ = {'exp': [0.0, 0], 'k2': [0.0, 0]}
@@ -977,7 +983,7 @@ def main():
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': round(PATH_BYTES_PER_IMAGE * BATCH * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        pk = os.path.join(ROOT, 'profiles', newest(['r04_per_kernel.json', 'r03_per_kernel.json']) or 'none')
+        pk = os.path.join(ROOT, 'profiles', newest(['r05_per_kernel.json', 'r04_per_kernel.json', 'r03_per_kernel.json']) or 'none')
         if os.path.exists(pk):
             # per-kernel table of one label pass (us, MB, fraction of the HBM roof), from a rocprofv3 --kernel-trace --stats run of
             # `bench.py --profile-pass --in-flight 1` (no K2 re-issues in it) + the PMC traffic passes; tools/per_kernel.py

@@ -7,6 +7,8 @@ ESPDNet-UE s=2.0, C classes, H x W input, per image, fp32.   usage: python tools
 import math, sys
 C, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (5, 256, 480)
 rows = {}
+BN = [0.0]        # bytes of the batch-statistics passes (the supervised loop, model.train()): per BatchNorm one read of its input for the
+                  # statistics (forward) and one pass over (gradient, input) for the two channel sums (backward): 3 x 4 * C * HW
 
 
 def add(kind, fwd_bytes, weighted=True):
@@ -19,9 +21,14 @@ def px(div):
     return (H // div) * (W // div)
 
 
+def bn(channels, pixels):
+    BN[0] += 3 * 4 * channels * pixels
+
+
 def eesp(kind, cin, cout, div_in, stride):
     n = cout // 4
     pi, po = px(div_in), px(div_in * stride)
+    bn(n, pi); bn(4 * n, po); bn(cout, po)            # proj_1x1.bn, br_after_cat, conv_1x1_exp.bn
     add(kind + ' proj_1x1 (grouped 1x1)', 4 * pi * (cin + n))
     add(kind + ' K2 (4 dilated depthwise 3x3 + HFF)', 4 * n * (pi + 4 * po))
     add(kind + ' conv_1x1_exp (grouped 1x1)', 4 * po * (cout + cout))
@@ -31,12 +38,16 @@ def down(kind, cin, cout, div_in):
     eesp(kind, cin, cout - cin, div_in, 2)
     add(kind + ' avg pool 3x3/s2', 4 * cin * (px(div_in) + px(div_in * 2)), weighted=False)
     add(kind + ' inp_reinf (3x3 on the pooled image + 1x1)', 4 * px(div_in * 2) * (3 + 3 + 3 + cout))
+    bn(3, px(div_in * 2)); bn(cout, px(div_in * 2))   # inp_reinf's two BatchNorms
 
 
 def pyr(kind, cin, cout, div):
     p = px(div)
     h, w = H // div, W // div
     add(kind + ' projection 1x1', 4 * p * (cin + 16))
+    bn(16, p); bn(80, p); bn(16, p)                   # projection_layer, merge_layer.0, merge_layer.2
+    if cout != C:
+        bn(cout, p)                                   # last_layer_br (not on the two classifier pyramids)
     for s in (2.0, 1.5, 1.0, 0.5, 0.1):
         hs, ws = max(math.ceil(h * s), 5), max(math.ceil(w * s), 5)
         # resample in, depthwise 3x3 at the branch resolution, resample out (node-per-op accounting of SURVEY 8d)
@@ -50,6 +61,7 @@ def pyr(kind, cin, cout, div):
 
 
 add('level1 CBR 3x3/s2', 4 * (3 * px(1) + 32 * px(2)))
+bn(32, px(2))
 down('level2_0', 32, 128, 2)
 down('level3_0', 128, 256, 4)
 for _ in range(3):
@@ -65,6 +77,7 @@ pyr('bu_dec_l4', 32, C, 2)
 for name, cin, cout, div in (('merge_enc_dec_l2', 256, 64, 8), ('merge_enc_dec_l3', 128, 48, 4), ('merge_enc_dec_l4', 32, 32, 2)):
     add('EfficientPWConv x3 (grouped 3x3 + gate)', 4 * px(div) * (cin + cout) + 4 * px(div) * cin)
     add('decoder up-merge x3 (bilinear x2 + add + BR)', 4 * cout * (px(div * 2) + 2 * px(div)), weighted=False)
+    bn(cout, px(div)); bn(cout, px(div)); bn(cout, px(div))          # EfficientPWConv's two BatchNorms, bu_br
 add('final bilinear of both heads + loss', 4 * C * (px(2) + px(4)) + 2 * 4 * C * px(1), weighted=False)
 tf = sum(r[0] for r in rows.values())
 tt = sum(r[1] for r in rows.values())
@@ -81,3 +94,5 @@ print('|---|---|---|')
 for g, (f, t) in groups.items():
     print('| %s | %.1f | %.1f |' % (g, f / 1e6, t / 1e6))
 print('| **total** | **%.1f** | **%.1f** |' % (tf / 1e6, tt / 1e6))
+print('batch-statistics passes of the BatchNorms in train() (statistics read + backward sums pass): %.1f MB / image -> %.1f MB / image with them'
+      % (BN[0] / 1e6, (tt + BN[0]) / 1e6))
