@@ -325,7 +325,7 @@ def eesp_dw_bn(x, ws, dil, bn, alpha, stride=1):
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
     return EespDwBNFn.apply(x, ws[0], ws[1], ws[2], ws[3], tuple(dil), int(stride), bn.weight, bn.bias, alpha, bn.running_mean, bn.running_var,
-                            float(bn.eps), float(bn.momentum), _bn_workspace(bn, x.device), bn.num_batches_tracked)
+                            float(bn.eps), float(bn.momentum), _bn_workspace(bn, x.device), _bn_nbt(bn))
 
 
 def _conv_backward(x, w, cfg, sink, gy, need_gx, need_gw):
@@ -929,7 +929,7 @@ def bn_train_params(bn, device):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
-    return (bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), _bn_workspace(bn, device), bn.num_batches_tracked)
+    return (bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), _bn_workspace(bn, device), _bn_nbt(bn))
 
 
 def pyr_body_fits(shape, sizes):
@@ -1340,12 +1340,24 @@ class BNTrainPReLUFn(torch.autograd.Function):
 _SMALL_BN = os.environ.get('MSPL_BN_SMALL', '1') != '0'       # small planes: one launch per BatchNorm node and direction
 
 
+def _bn_nbt(bn):
+    """bn.num_batches_tracked as the statistics kernels take it (they add 1 through the raw pointer): an int64 tensor ON THE DEVICE --
+    a CPU or mistyped buffer would become a device-side write through a host pointer."""
+    nbt = bn.num_batches_tracked
+    if nbt is None or not (nbt.is_cuda and nbt.dtype == torch.int64):
+        raise RuntimeError('mspl_amd: num_batches_tracked must be an int64 tensor on the device')
+    return nbt
+
+
 def _bn_workspace(bn, device):
     """The BatchNorm's persistent, zeroed workspace of the two fused kernels (they hand it back zeroed)."""
-    ws = bn.__dict__.get('_mspl_bn_ws')
-    if ws is None or ws.device != device:
-        ws = torch.zeros(int(lib.mspl_bn_fused_workspace_bytes(bn.num_features)) // 8 + 1, dtype=torch.float64, device=device)
-        bn.__dict__['_mspl_bn_ws'] = ws
+    # one workspace per (module, stream): the kernels' "handed back zeroed" contract holds per stream of launches; the same module on
+    # two streams at once (side streams of the layers, two lanes) must not share partial sums
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    tab = bn.__dict__.setdefault('_mspl_bn_ws', {})
+    ws = tab.get(key)
+    if ws is None:
+        ws = tab[key] = torch.zeros(int(lib.mspl_bn_fused_workspace_bytes(bn.num_features)) // 8 + 1, dtype=torch.float64, device=device)
     return ws
 
 
@@ -1354,9 +1366,7 @@ def bn_train_prelu(z, bn, alpha=None, residual=None):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise RuntimeError('mspl_amd: BatchNorm2d variants without momentum / running statistics / affine parameters are '
                            'not on the path (the reference uses the defaults everywhere)')
-    nbt = bn.num_batches_tracked          # incremented by the statistics kernel (an int64 CUDA scalar; nn.BatchNorm2d adds 1 per forward)
-    if not (nbt.is_cuda and nbt.dtype == torch.int64):
-        raise RuntimeError('mspl_amd: num_batches_tracked must be an int64 tensor on the device')
+    nbt = _bn_nbt(bn)                     # incremented by the statistics kernel (an int64 CUDA scalar; nn.BatchNorm2d adds 1 per forward)
     return BNTrainPReLUFn.apply(z, bn.weight, bn.bias, alpha, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                                 _bn_workspace(bn, z.device), nbt)
 

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void eesp_bwd_fused_kernel(const float* __rest
         float gk[4], run = 0.f;
 #pragma unroll
         for (int k = 3; k >= 0; --k) {
-            const float u = zv[k] * sc[k] + sh[k];
+            const float u = fmaf(zv[k], sc[k], sh[k]);          // K2's own epilogue expression: same PReLU branch
             const bool pos = !act || u > 0.f;
             const float gz = pos ? gv[k] : al[k] * gv[k];
             if (own) {

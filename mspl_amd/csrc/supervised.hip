@@ -361,11 +361,11 @@ __global__ __launch_bounds__(1024) void bn_train_small_bwd_kernel(const float* _
     const float al = act ? alpha[c] : 1.f;
     float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
     auto direct = [&](float zv, float rv, float g) {           // gradient of the pre-activation, as affine_prelu_bwd_kernel
-        const float u = zv * sc + sh + rv;
+        const float u = fmaf(zv, sc, sh) + rv;          // the forward's expression (one fused multiply-add, then the residual): same PReLU branch
         return (!act || u > 0.f) ? g : al * g;
     };
     auto sums = [&](float zv, float rv, float g) {
-        const float u = zv * sc + sh + rv;
+        const float u = fmaf(zv, sc, sh) + rv;          // the forward's expression (one fused multiply-add, then the residual): same PReLU branch
         const float gzv = (!act || u > 0.f) ? g : al * g;
         if (act && u <= 0.f) s_alpha += g * u;
         s_scale += gzv * zv;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_train_bwd_apply_kernel(const float* __
     const bool act = alpha != nullptr;
     const float al = act ? alpha[c] : 1.f;
     auto one = [&](float zv, float g) {
-        const float u = zv * sc + sh;
+        const float u = fmaf(zv, sc, sh);               // the forward's expression
         const float gzv = (!act || u > 0.f) ? g : al * g;
         return fmaf(zv, pc, qc) + gzv * sc;
     };

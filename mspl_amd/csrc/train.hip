@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
     float s_scale = 0.f, s_shift = 0.f, s_alpha = 0.f;
     auto one = [&](float cv, float pv, float rv, float g, float& gz, float& gcv) {
         const float u = cv + pv;
-        const float z = u * sc + sh + rv;
+        const float z = fmaf(u, sc, sh) + rv;             // the forward epilogue's expression (epi_apply: fmaf, then + residual): same PReLU branch
         gz = (!act || z > 0.f) ? g : al * g;
         if (act && z <= 0.f) s_alpha += g * z;
         s_scale += gz * u;
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
     const size_t in0 = ((size_t)img * 4 * n + j) * (size_t)HW, kin = (size_t)n * HW;
     const size_t out0 = ((size_t)img * n + j) * (size_t)HW;
     auto one = [&](int k, float zv, float g) {
-        const float u = zv * sc[k] + sh[k];
+        const float u = fmaf(zv, sc[k], sh[k]);              // K2's own epilogue expression: same PReLU branch
         const bool pos = !act || u > 0.f;
         const float gz = pos ? g : al[k] * g;
         if (!pos) s_al[k] += g * u;
