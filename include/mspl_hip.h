@@ -345,8 +345,11 @@ int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, int32_t Cin
  *     parameter gradient buffers that were zeroed at the start of the step.  Problem i: gy[i] (N,Cout,HW), x[i] (N,Cin,HW),
  *     gw[i] (Cout, Cin/groups).  Nothing in a backward chain waits for a weight gradient, so the training steps queue them
  *     (mspl_amd.autograd.WgradQueue) and flush the queue here: ~33 launches of 8-25 us per uest step become a handful. */
-int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const int32_t* N, const int32_t* Cin,
-                             const int32_t* Cout, const int32_t* groups, const int32_t* HW, int32_t nprob, void* stream);
+int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const float* const* rowscale,
+                             const int32_t* N, const int32_t* Cin, const int32_t* Cout, const int32_t* groups, const int32_t* HW, int32_t nprob,
+                             void* stream);
+/* rowscale: NULL, or per problem NULL / a (Cout) vector s: gw[i][co, :] += s[co] * sum -- gy[i] is then the gradient BEFORE a
+ *     per-output-channel scale (a caller that keeps only the unscaled gradient in memory). */
 
 /* DownSampler tail (nn_layers/eesp.py:131-144) without materialising torch.cat: y = PReLU(cat[a, b] + reinf).  a (N,nin,HW): avg-pooled
  * input; b (N,C-nin,HW): the strided EESP branch; reinf (N,C,HW) or NULL; alpha (C).  Backward: ga / gb (shapes of a / b, contiguous),

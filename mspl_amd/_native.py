@@ -124,7 +124,7 @@ SIGNATURES = {
     'mspl_pyr_down_prep_train_fwd': [c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                      ctypes.c_void_p],
-    'mspl_conv1x1_wgrad_batch': [ctypes.POINTER(ctypes.c_void_p)] * 3 + [ctypes.POINTER(c_i32)] * 5 + [c_i32, ctypes.c_void_p],
+    'mspl_conv1x1_wgrad_batch': [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(c_i32)] * 5 + [c_i32, ctypes.c_void_p],
     'mspl_pyr_down_mid_bwd': [ctypes.POINTER(ctypes.c_void_p)] * 3 + [c_i32] * 5 + [ctypes.POINTER(c_i32)] * 2 +
                              [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.c_void_p],
     'mspl_dense_conv_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _EP, c_f32p,

@@ -54,8 +54,8 @@ class WgradQueue(object):
         self.items = []
         self.enabled = os.environ.get('MSPL_WGRAD_BATCH', '1') != '0'
 
-    def add(self, gy, x, N, Cin, Cout, groups, HW, sink):
-        self.items.append((gy, x, sink, int(N), int(Cin), int(Cout), int(groups), int(HW)))
+    def add(self, gy, x, N, Cin, Cout, groups, HW, sink, rowscale=None):
+        self.items.append((gy, x, sink, int(N), int(Cin), int(Cout), int(groups), int(HW), rowscale))
         if len(self.items) >= 64:
             self.flush()
 
@@ -69,16 +69,20 @@ class WgradQueue(object):
             return
         arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])      # noqa: E731
         ints = lambda k: (ctypes.c_int32 * n)(*[it[k] for it in items])                 # noqa: E731
-        check(lib.mspl_conv1x1_wgrad_batch(arr(0), arr(1), arr(2), ints(3), ints(4), ints(5), ints(6), ints(7), n, _stream()))
+        rs = (ctypes.c_void_p * n)(*[None if it[8] is None else it[8].data_ptr() for it in items])
+        check(lib.mspl_conv1x1_wgrad_batch(arr(0), arr(1), arr(2), rs, ints(3), ints(4), ints(5), ints(6), ints(7), n, _stream()))
 
 
 WGRADS = WgradQueue()
 
 
-def _wgrad_1x1_into_sink(gy, x, N, Cin, Cout, groups, H, W, sink):
-    """gw of a grouped 1x1 convolution, accumulated into `sink`: queued inside grad_sinks(), launched at once otherwise."""
-    if WGRADS.enabled and _SINKS[0]:
-        WGRADS.add(gy, x, N, Cin, Cout, groups, H * W, sink)
+def _wgrad_1x1_into_sink(gy, x, N, Cin, Cout, groups, H, W, sink, rowscale=None):
+    """gw of a grouped 1x1 convolution, accumulated into `sink`: queued inside grad_sinks(), launched at once otherwise.  rowscale: gy is
+    the gradient before a per-output-channel scale (applied at the store)."""
+    if (WGRADS.enabled and _SINKS[0]) or rowscale is not None:
+        WGRADS.add(gy, x, N, Cin, Cout, groups, H * W, sink, rowscale)
+        if not (WGRADS.enabled and _SINKS[0]):
+            WGRADS.flush()
     else:
         check(lib.mspl_conv_bwd_weight(_p(gy), _p(x), N, Cin, Cout, groups, H, W, 1, 1, 1, 1, _p(sink), _stream()))
 

@@ -32,8 +32,11 @@ struct WgG {
 // groups -- next group's requests before this group's MFMAs -- measured no faster: 24 us either way for the 512 -> 512 expansion
 // at 18x30, whose fp32 MFMA floor is 6.5 us.)  The four waves of a workgroup hold four slices of the same tile: they are summed
 // through LDS and leave with one atomic per tile element.
+// rowscale (or null): gw[m, k] += rowscale[m] * sum -- the caller's gy is then the gradient BEFORE a per-output-channel scale (the folded
+// BatchNorm scale of a convolution whose pointwise backward kept only the unscaled gradient in memory)
 __device__ __forceinline__ void wgrad_tile_body(const float* __restrict__ gy, const float* __restrict__ x, const WgG& g,
-                                                float* __restrict__ gw, const int64_t bid, float (&red)[4][16][64]) {
+                                                float* __restrict__ gw, const int64_t bid, float (&red)[4][16][64],
+                                                const float* __restrict__ rowscale = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int bslots = g.nslots >> 2;                                   // workgroups per tile
     const int64_t tile = bid / bslots;
@@ -84,7 +87,8 @@ __device__ __forceinline__ void wgrad_tile_body(const float* __restrict__ gy, co
         const int i = e >> 6, l = e & 63;
         const float v = (red[0][i][l] + red[1][i][l]) + (red[2][i][l] + red[3][i][l]);
         const int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), col = l & 31;
-        if (m0 + row < g.M && k0 + col < g.K) atomicAdd(gw + ((size_t)grp * g.M + m0 + row) * g.K + k0 + col, v);
+        if (m0 + row < g.M && k0 + col < g.K)
+            atomicAdd(gw + ((size_t)grp * g.M + m0 + row) * g.K + k0 + col, rowscale ? v * rowscale[grp * g.M + m0 + row] : v);
     }
 }
 
@@ -102,6 +106,7 @@ struct WgProb {
     const float* gy;
     const float* x;
     float* gw;
+    const float* rowscale;       // per output channel, or null
     WgG g;
     unsigned first;              // first workgroup of this problem
 };
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_batch_kernel(WgBatch b) {
     for (int i = 1; i < b.n; ++i)
         if (blockIdx.x >= b.p[i].first) k = i;                          // uniform
     const WgProb& q = b.p[k];
-    wgrad_tile_body(q.gy, q.x, q.g, q.gw, (int64_t)(blockIdx.x - q.first), red);
+    wgrad_tile_body(q.gy, q.x, q.g, q.gw, (int64_t)(blockIdx.x - q.first), red, q.rowscale);
 }
 
 static bool wgrad_geom(int N, int G, int M, int K, int P, WgG& g, int64_t& blocks, int share) {
@@ -139,8 +144,8 @@ static bool wgrad_geom(int N, int G, int M, int K, int P, WgG& g, int64_t& block
 }
 
 // Returns the number of problems launched from the front of the list (0: the first problem is not eligible for this kernel).
-int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const int* N, const int* G, const int* M,
-                             const int* K, const int* P, int nprob, hipStream_t s) {
+int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const float* const* rowscale, const int* N,
+                             const int* G, const int* M, const int* K, const int* P, int nprob, hipStream_t s) {
     WgBatch b;
     memset(&b, 0, sizeof(b));
     int64_t total = 0;
@@ -150,7 +155,7 @@ int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, floa
         int64_t blocks;
         if (!wgrad_geom(N[n], G[n], M[n], K[n], P[n], b.p[n].g, blocks, share)) break;
         if (total + blocks >= (1ll << 31)) break;
-        b.p[n].gy = gy[n]; b.p[n].x = x[n]; b.p[n].gw = gw[n];
+        b.p[n].gy = gy[n]; b.p[n].x = x[n]; b.p[n].gw = gw[n]; b.p[n].rowscale = rowscale ? rowscale[n] : nullptr;
         b.p[n].first = (unsigned)total;
         total += blocks;
     }

@@ -14,8 +14,8 @@
 namespace mspl {
 
 int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M, int K, int P, float* gw, hipStream_t s);
-int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const int* N, const int* G, const int* M,
-                             const int* K, const int* P, int nprob, hipStream_t s);
+int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, float* const* gw, const float* const* rowscale, const int* N,
+                             const int* G, const int* M, const int* K, const int* P, int nprob, hipStream_t s);
 
 struct ConvGeom {
     int N, Cin, Cout, G, cin_g, cout_g, H, W, Ho, Wo, K, stride, dil, pad;
@@ -1163,8 +1163,8 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
                                     int32_t H, int32_t W, int32_t K, int32_t stride, int32_t dilation, int32_t accumulate,
                                     float* gw, void* stream);
 
-extern "C" int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const int32_t* N,
-                                        const int32_t* Cin, const int32_t* Cout, const int32_t* groups, const int32_t* HW,
+extern "C" int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* const* x, float* const* gw, const float* const* rowscale,
+                                        const int32_t* N, const int32_t* Cin, const int32_t* Cout, const int32_t* groups, const int32_t* HW,
                                         int32_t nprob, void* stream) {
     MSPL_REQUIRE(gy && x && gw && N && Cin && Cout && groups && HW, MSPL_ERR_NULL_POINTER, "conv1x1_wgrad_batch: null pointer");
     MSPL_REQUIRE(nprob >= 0 && nprob <= 4096, MSPL_ERR_BAD_SHAPE, "conv1x1_wgrad_batch: %d problems", nprob);
@@ -1181,11 +1181,13 @@ extern "C" int mspl_conv1x1_wgrad_batch(const float* const* gy, const float* con
                          i, N[i], Cin[i], Cout[i], groups[i], HW[i]);
             NN[cnt] = N[i]; G[cnt] = groups[i]; M[cnt] = Cout[i] / groups[i]; K[cnt] = Cin[i] / groups[i]; P[cnt] = HW[i];
         }
-        const int done = conv1x1_wgrad_mfma_batch(gy + at, x + at, gw + at, NN, G, M, K, P, cnt, s);
+        const int done = conv1x1_wgrad_mfma_batch(gy + at, x + at, gw + at, rowscale ? rowscale + at : nullptr, NN, G, M, K, P, cnt, s);
         if (done > 0) {
             MSPL_CHECK_LAUNCH("conv1x1_wgrad_batch");
             at += done;
         } else {                 // the first problem of the run is not for the matrix-core kernel
+            MSPL_REQUIRE(!(rowscale && rowscale[at]), MSPL_ERR_UNSUPPORTED, "conv1x1_wgrad_batch: problem %d: rowscale needs the matrix-core kernel "
+                         "(>= 8 channels per group, HW %% 4 == 0)", at);
             if (int rc = mspl_conv_bwd_weight(gy[at], x[at], N[at], Cin[at], Cout[at], groups[at], 1, HW[at], 1, 1, 1, 1, gw[at], stream)) return rc;
             ++at;
         }

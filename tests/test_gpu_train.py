@@ -721,9 +721,14 @@ def test_conv1x1_weight_gradients_batched_in_one_launch():
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     col = lambda k: (ctypes.c_int32 * n)(*[p[k] for p in probs])
     hw = (ctypes.c_int32 * n)(*[p[4] * p[5] for p in probs])
-    check(lib.mspl_conv1x1_wgrad_batch(arr(gys), arr(xs), arr(gws), col(0), col(1), col(2), col(3), hw, n,
+    # rowscale on the first and fourth problem: gw[co, :] += s[co] * sum (the gradient operand is the one BEFORE a per-channel scale)
+    rsc = [rnd(probs[0][2], seed=90).abs().to(DEV) + 0.5, None, None, rnd(probs[3][2], seed=91).abs().to(DEV) + 0.5, None, None]
+    rs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in rsc])
+    check(lib.mspl_conv1x1_wgrad_batch(arr(gys), arr(xs), arr(gws), rs, col(0), col(1), col(2), col(3), hw, n,
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    for g, r in zip(gws, refs):
+    for g, r, sc in zip(gws, refs, rsc):
+        if sc is not None:
+            r = r * sc.cpu().view(-1, 1, 1, 1)
         assert float((g.cpu() - 0.25 - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-5
     # the queue: two convolutions' weight gradients are still pending inside the context, in their buffers after it
     w1 = rnd(48, 64, 1, 1, seed=80, scale=0.1).to(DEV).requires_grad_(True)
