@@ -942,6 +942,9 @@ def main():
             'roofline': dict(roof_exp(ip1 if 'exp' in ip1 else iso) or {}, **{
                 'kernel': 'eesp_dw_exp (K2 + K3 of a stride-1 EESP block, and the NEXT block\'s proj_1x1, in one launch: depthwise branches -> LDS '
                           '-> MFMA B operand -> second matrix stage on the accumulators; %d launches/forward, the dominant kernel of a pass)' % n_exp,
+                'covered_shapes': 'the fused launch exists for (n, columns) = (128, 30 | 32 | 64) and (64, 60 | 64 | 128): 480-, 512- and 1024-pixel-wide inputs, any height; '
+                                  'other widths take K1 / K2 / K3 as three launches with identical results (tests/test_gpu_parity.py::test_model_wide_inputs_fused_and_fallback); '
+                                  'this figure is the 480-wide case, the 1024-wide one is the cityscapes_512x1024 field',
                 'traffic': fam_traffic.get('exp'), 'traffic_source': fam_traffic.get('source'),
                 'accounting_note': family_note + '.  achieved = the matrix FLOPs (expansion 2 * 4n * n per pixel, + 2 * n * n where the next projection is fused in) / launch time; the depthwise '
                                    'vector work (36 FMAs per reduced channel and pixel) runs on the same SIMD issue and is not counted; '
