@@ -59,6 +59,12 @@ IMAGEIO_CASES = {
 
 TRAIN_CASE = dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 32, 48), sd_seed=21, in_seed=5,
                   lr=5e-4, weight_decay=5e-4, ignore_idx=4)
+# golden file -> case.  The second one (round 5) is large enough for the kernels the small one never reaches: the decoder's 48-column
+# maps take the streaming pyramid forward / backward kernels, the level-3 / 4 planes (8x12, 4x6 pixels: multiples of 4) the matrix-core
+# weight gradients and the fused EESP backward.
+TRAIN_CASES = {'train_step': TRAIN_CASE,
+               'train_step_64x96': dict(s=2.0, classes=5, dataset='greenhouse', shape=(2, 3, 64, 96), sd_seed=23, in_seed=7,
+                                        lr=5e-4, weight_decay=5e-4, ignore_idx=4)}
 
 
 # one supervised iteration (train_seg_ue + SGD with learning-rate groups, batch-statistics BatchNorm), SURVEY 8f-4

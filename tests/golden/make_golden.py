@@ -24,7 +24,7 @@ REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LABEL_LOOP_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE  # noqa: E402
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, IMAGEIO_CASES, LABEL_LOOP_CASES, LAYER_CASES, LR_CASES, NID_CASES, SUPERVISED_CASE, MODEL_CASES, RGBD_CASES, TRAIN_CASE, TRAIN_CASES  # noqa: E402
 from tests.synth import grad_sample_index, synth_adversarial_logits, synth_eval_batches, synth_image_u8, synth_input, synth_label_loop_images, synth_nid_inputs, synth_labels, synth_state_dict  # noqa: E402
 
 # reference imports (torch-only modules)
@@ -233,7 +233,11 @@ def gen_loss():
 
 
 def gen_train():
-    c = TRAIN_CASE
+    for gname, c in sorted(TRAIN_CASES.items()):
+        _gen_train_case(gname, c)
+
+
+def _gen_train_case(gname, c):
     m = build_model('espdnetue', c['s'], c['classes'], c['dataset']).eval()  # eval: uest default (Appendix B-3)
     m.load_state_dict(synth_state_dict(m.state_dict(), c['sd_seed']))
     x = synth_input(c['shape'], c['in_seed'])
@@ -266,7 +270,7 @@ def gen_train():
             idx = grad_sample_index(flat.numel())
             gs_val.append(flat[idx].numpy())
         gs_off.append(gs_off[-1] + (len(gs_val[-1]) if p_.grad is not None else 0))
-    save('train_step', loss=loss.detach(), names=np.array(names), gnorm=gnorm, gsum=gsum, delta=delta,
+    save(gname, loss=loss.detach(), names=np.array(names), gnorm=gnorm, gsum=gsum, delta=delta,
          gsample=np.concatenate(gs_val), gsample_off=np.array(gs_off, dtype=np.int64),
          keep=np.array(keep), **{'after_%d' % i: pd[k].detach() for i, k in enumerate(keep)})
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import labels as olab
-from tests.cases import TRAIN_CASE
+from tests.cases import TRAIN_CASE, TRAIN_CASES
 from tests.conftest import GOLDEN
 from tests.synth import synth_input, synth_labels, synth_state_dict
 
@@ -221,11 +221,13 @@ def test_uw_loss_vs_reference_golden(golden):
     torch.testing.assert_close(aux.grad.cpu(), torch.from_numpy(g['daux']), rtol=1e-3, atol=1e-8)
 
 
-def test_train_step_vs_reference_golden(golden):
-    """ESPDNet-UE C=5, frozen BN, one Adam step: loss, gradient norms, the 230 gradient-less tensors, updated weights."""
+@pytest.mark.parametrize('gname', sorted(TRAIN_CASES))
+def test_train_step_vs_reference_golden(gname, golden):
+    """ESPDNet-UE C=5, frozen BN, one Adam step: loss, gradient norms, the 230 gradient-less tensors, updated weights -- at 32x48 and
+    at 64x96 (the streaming pyramid kernels, the matrix-core weight gradients and the fused EESP backward are reached by the second)."""
     from mspl_amd import models, training
-    c = TRAIN_CASE
-    g = golden('train_step')
+    c = TRAIN_CASES[gname]
+    g = golden(gname)
     a = argparse.Namespace(s=c['s'], channels=3, num_classes=1000)
     m = models.ESPDNetwithUncertaintyEstimation(a, classes=c['classes'], dataset=c['dataset'], fix_pyr_plane_proj=True)
     m.load_state_dict(synth_state_dict(KEYS['espdnetue_s%s_c%d' % (c['s'], c['classes'])], c['sd_seed']))
@@ -347,13 +349,15 @@ def test_micro_batch_lanes_equal_one_graph(lanes):
     assert training.GraphedTrainStep(nets[1], x[:3], y[:3], cw, ignore_idx=4, lanes=2).lanes == 1
 
 
-def test_direct_gradient_sinks_equal_autograd_accumulation(monkeypatch):
+@pytest.mark.parametrize('hw', [(32, 48), (64, 96)])
+def test_direct_gradient_sinks_equal_autograd_accumulation(hw, monkeypatch):
     """Steps 2-3 with the parameter-gradient kernels writing straight into the flat gradient buffer (grad_sinks, the default
     of train_step) against the same steps with autograd's own AccumulateGrad (MSPL_GRAD_SINKS=0)."""
     from mspl_amd import models, training
     a = argparse.Namespace(s=2.0, channels=3, num_classes=1000)
-    x = synth_input((2, 3, 32, 48), 18).to(DEV)
-    y = synth_labels((2, 32, 48), 5, 18).to(DEV)
+    # (64x96: the queued 1x1 weight gradients take the matrix-core batch kernel, the pyramids their streaming kernels)
+    x = synth_input((2, 3) + hw, 18).to(DEV)
+    y = synth_labels((2,) + hw, 5, 18).to(DEV)
     cw = torch.ones(5)
     outs = []
     for flag in ('1', '0'):
@@ -361,14 +365,20 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(monkeypatch):
         m = models.ESPDNetwithUncertaintyEstimation(a, classes=5, dataset='greenhouse', fix_pyr_plane_proj=True)
         m.load_state_dict(synth_state_dict(KEYS['espdnetue_s2.0_c5'], 4))
         m = m.to(DEV).eval()
-        opt, losses = None, []
+        opt, losses, grads = None, [], []
         for _ in range(3):
             l, opt = training.train_step(m, x, y, cw, opt, ignore_idx=4)
             losses.append(float(l))
-        outs.append((losses, opt.flat_g.clone(), {k: v.clone() for k, v in m.state_dict().items()}))
+            grads.append(opt.flat_g.clone())
+        outs.append((losses, grads, {k: v.clone() for k, v in m.state_dict().items()}))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
-    g1, g0 = outs[0][1], outs[1][1]
-    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-7
+    # Step 2 is the first one through the sinks and starts from weights that differ by float atomics' order only: tight.
+    # By step 3 an ulp of difference in a weight can put one PReLU input of a 2x3 level-4 map on the other side of zero
+    # (measured: either 5e-7 or one block at 1e-2 of ITS OWN gradient, 6e-5 of the largest, run to run with the same
+    # settings on either side - tools/diag_sinks.py), so the third comparison is looser.
+    for step, tol in ((1, 1e-5), (2, 5e-4)):
+        g1, g0 = outs[0][1][step], outs[1][1][step]
+        assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max()) + 1e-7, step
     for k in outs[0][2]:
         np.testing.assert_allclose(outs[0][2][k].cpu().numpy(), outs[1][2][k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
 

@@ -12,7 +12,7 @@ import torch
 
 from oracle import labels as olab
 from oracle import net as onet
-from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, LABEL_LOOP_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE
+from tests.cases import ASPP_CASES, ESPDNET_CASES, EVAL_CASES, LABEL_LOOP_CASES, LAYER_CASES, MODEL_CASES, RGBD_CASES, TRAIN_CASE, TRAIN_CASES
 from tests.conftest import GOLDEN
 from tests.synth import synth_adversarial_logits, synth_eval_batches, synth_input, synth_label_loop_images, synth_labels, synth_state_dict
 
@@ -138,11 +138,12 @@ def test_uw_loss_value_and_grads(golden):
     torch.testing.assert_close(aux.grad, torch.from_numpy(g['daux']), rtol=1e-4, atol=1e-8)
 
 
-def test_train_step(golden):
+@pytest.mark.parametrize('gname', sorted(TRAIN_CASES))
+def test_train_step(gname, golden):
     """One uest self-training step (frozen BN, Adam + weight decay, unused params skipped)."""
     from oracle.train import train_step
-    c = TRAIN_CASE
-    g = golden('train_step')
+    c = TRAIN_CASES[gname]
+    g = golden(gname)
     sd = synth_state_dict(KEYS['espdnetue_s%s_c%d' % (c['s'], c['classes'])], c['sd_seed'])
     x = synth_input(c['shape'], c['in_seed'])
     labels = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed'])
