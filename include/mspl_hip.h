@@ -419,6 +419,17 @@ int mspl_uw_loss_fwd_bwd(const float* pred, const float* aux, const int64_t* tar
 int mspl_uw_loss_scaled_fwd_bwd(const float* pred, const float* aux, const int64_t* target, const float* class_weights,
                                 int32_t N, int32_t C, int32_t HW, float ce_scale, float out_scale, float* loss_acc,
                                 float* gpred, float* gaux, float* kld_out, void* stream);
+/* K11 at head resolution: the same loss taken from the decoder's two outputs BEFORE their bilinear up-sampling to the label map
+ * (model/segmentation/espdnet_ue.py:301-302, F.interpolate(..., mode='bilinear', align_corners=True) of main (N,C,Hm,Wm) and
+ * aux (N,C,Ha,Wa) to H x W; target (N,H,W) int64): the up-sampling happens inside the loss kernel, the two full-size logit tensors are
+ * never written.  gpred / gaux (N,C,H,W) = d loss / d (up-sampled logits), as mspl_uw_loss_scaled_fwd_bwd writes them: hand each to
+ * mspl_bilinear_bwd for the gradient of its low-resolution map.  loss_acc is ACCUMULATED into (caller zeroes).  Class counts
+ * mspl_uw_loss_heads_supported() says 1 for (1..8, 13, 20) and heads no larger than the label map; MSPL_ERR_UNSUPPORTED otherwise
+ * (callers then take the three-step form). */
+int mspl_uw_loss_heads_supported(int32_t C);
+int mspl_uw_loss_heads_fwd_bwd(const float* main_lo, const float* aux_lo, const int64_t* target, const float* class_weights,
+                               int32_t N, int32_t C, int32_t Hm, int32_t Wm, int32_t Ha, int32_t Wa, int32_t H, int32_t W,
+                               float ce_scale, float out_scale, float* loss_acc, float* gpred, float* gaux, void* stream);
 
 /* K13  dense (groups = 1) 1x1 / dilated 3x3 convolution on the fp32 matrix cores: the ASPP heads of nn_layers/aspp.py:7-99
  *      (Conv2d(Cin, Cout, k, padding = dilation, dilation) + BatchNorm + ReLU).  x: (N,Cin,H,W); w_packed: the conv weight

@@ -113,6 +113,8 @@ SIGNATURES = {
                             + [ctypes.c_void_p],
     'mspl_uw_loss_scaled_fwd_bwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float] + [c_f32p] * 4
                                    + [ctypes.c_void_p],
+    'mspl_uw_loss_heads_supported': [c_i32],
+    'mspl_uw_loss_heads_fwd_bwd': [c_f32p, c_f32p, ctypes.c_void_p, c_f32p] + [c_i32] * 8 + [ctypes.c_float] * 2 + [c_f32p] * 3 + [ctypes.c_void_p],
     'mspl_pixelwise_kld_fwd': [c_f32p, c_f32p, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],
     'mspl_pixelwise_kld_bwd': [c_f32p, c_f32p, c_f32p, c_i32, c_i32, c_i32, c_f32p, c_f32p, ctypes.c_void_p],
     'mspl_weighted_ce_fwd': [c_f32p, ctypes.c_void_p, c_f32p, c_f32p, c_i32, c_i32, c_i32, c_i32, c_f32p, ctypes.c_void_p],

@@ -1155,6 +1155,38 @@ class UWLossFn(torch.autograd.Function):
         return gpred * g, gaux * g, None, None, None, None, None
 
 
+class UWLossHeadsFn(torch.autograd.Function):
+    """UWLossFn on the decoder's two outputs BEFORE their up-sampling to the label map (espdnet_ue.py:301-302): value and gradients of
+    uw_loss(bilinear(main, size), bilinear(aux, size), ...) w.r.t. the low-resolution maps.  The up-sampling happens inside the loss
+    kernel (the two full-size logit tensors never exist); the two transposed interpolations of its gradients run right behind it, so
+    the node keeps two low-resolution tensors: three launches instead of five."""
+
+    @staticmethod
+    def forward(ctx, main, aux, target, class_weights, ce_scale, out_scale, root):
+        main, aux = _c(main), _c(aux)
+        N, C, Hm, Wm = main.shape
+        Ha, Wa = aux.shape[2:]
+        H, W = target.shape[-2:]
+        target = _c(target.to(torch.int64))
+        loss = torch.zeros(1, device=main.device, dtype=torch.float32)
+        gfull = torch.empty((2, N, C, H, W), device=main.device, dtype=torch.float32)
+        check(lib.mspl_uw_loss_heads_fwd_bwd(_p(main), _p(aux), _p(target), _p(_c(class_weights.float())), N, C, Hm, Wm, Ha, Wa, H, W,
+                                             float(ce_scale), float(out_scale), _p(loss), _p(gfull[0]), _p(gfull[1]), _stream()))
+        gmain, gaux = torch.empty_like(main), torch.empty_like(aux)
+        check(lib.mspl_bilinear_bwd(_p(gfull[0]), N, C, Hm, Wm, H, W, _p(gmain), _stream()))
+        check(lib.mspl_bilinear_bwd(_p(gfull[1]), N, C, Ha, Wa, H, W, _p(gaux), _stream()))
+        ctx.save_for_backward(gmain, gaux)
+        ctx.root = bool(root)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gmain, gaux = ctx.saved_tensors
+        if ctx.root:
+            return gmain, gaux, None, None, None, None, None
+        return gmain * g, gaux * g, None, None, None, None, None
+
+
 # functional spellings
 def conv(x, w, stride=1, groups=1):
     return ConvFn.apply(x, w, stride, groups)
@@ -1396,3 +1428,12 @@ channel_scale = ChannelScaleFn.apply
 
 def uw_loss(pred, aux, target, class_weights, ce_scale=20.0, out_scale=1.0, root=False):
     return UWLossFn.apply(pred, aux, target, class_weights, ce_scale, out_scale, root)
+
+
+def uw_loss_heads_supported(classes):
+    return bool(lib.mspl_uw_loss_heads_supported(int(classes)))
+
+
+def uw_loss_heads(main, aux, target, class_weights, ce_scale=20.0, out_scale=1.0, root=False):
+    """uw_loss(bilinear(main, target.shape[-2:]), bilinear(aux, ...), ...) from the low-resolution heads."""
+    return UWLossHeadsFn.apply(main, aux, target, class_weights, ce_scale, out_scale, root)

@@ -11,6 +11,7 @@ gradient exchange ONE all-reduce (mspl_amd.dist).  Parameters whose gradient sta
 module_act of strided EESPs: 230 of 570 tensors) are left out, exactly like torch.optim.Adam skips them.
 """
 import ctypes
+import os
 
 import torch
 
@@ -33,6 +34,26 @@ def uest_loss(pred, aux, labels, class_weights, ignore_idx=None, ce_scale=20.0):
     class_weights: tensor of num_classes weights; class_weights[ignore_idx] is treated as 0 (the reference zeroes it
     in place at construction, loss_fns/segmentation_loss.py:152-153)."""
     return ag.uw_loss(pred, aux, labels, _device_class_weights(class_weights, pred.device, ignore_idx), ce_scale)
+
+
+_LOSS_AT_HEADS = os.environ.get('MSPL_LOSS_HEADS', '1') != '0'      # A/B aid: 0 = up-sample both heads, then the loss
+
+
+def forward_loss(model, images, labels, cw, ce_scale=20.0, out_scale=1.0, root=False):
+    """model forward + uest loss (uest_seg_multi_os.py:1010-1023) on device class weights `cw`.  A model that exposes its decoder
+    outputs (`forward_lowres`: main at H/2, auxiliary at H/4) gets the loss taken at head resolution -- the up-sampling of
+    espdnet_ue.py:301-302 happens inside the loss kernel (ag.uw_loss_heads), same value and gradients; any other model is called as
+    the reference calls it and the loss takes its two full-size outputs."""
+    lowres = getattr(model, 'forward_lowres', None) if _LOSS_AT_HEADS else None
+    if lowres is not None:
+        main, aux = lowres(images)
+        if aux is not None and ag.uw_loss_heads_supported(main.shape[1]):
+            return ag.uw_loss_heads(main, aux, labels, cw, ce_scale, out_scale, root)
+        size = tuple(images.shape[2:])
+        pred, aux = ag.bilinear(main, size), ag.bilinear(aux, size)
+    else:
+        pred, aux = model(images)
+    return ag.uw_loss(pred, aux, labels, cw, ce_scale, out_scale, root)
 
 
 class FlatAdam:
@@ -99,8 +120,7 @@ def train_step(model, images, labels, class_weights, optimizer=None, ignore_idx=
     tr = getattr(optimizer, 'transposer', None)
     with torch.enable_grad(), ag.grad_sinks(), (tr.active() if tr is not None else ag.collect_conv_weights()) as got:
         layers.prefold_frozen_bn(model)
-        pred, aux = model(images)
-        loss = uest_loss(pred, aux, labels, class_weights, ignore_idx, ce_scale)
+        loss = forward_loss(model, images, labels, _device_class_weights(class_weights, images.device, ignore_idx), ce_scale)
         loss.backward()
     if optimizer is None:
         optimizer = FlatAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
@@ -163,8 +183,7 @@ class GraphedTrainStep:
                 self.optimizer.zero_grad()
                 with torch.enable_grad(), ag.grad_sinks(), tr.active():
                     layers.prefold_frozen_bn(model)
-                    pred, aux = model(self.images)
-                    self.loss = ag.uw_loss(pred, aux, self.labels, self.cw, ce_scale, root=True)
+                    self.loss = forward_loss(model, self.images, self.labels, self.cw, ce_scale, root=True)
                     self.loss.backward()
         else:
             # what every lane needs first: zeroed gradients, this step's transposed weights and folded BatchNorms (their tensors live
@@ -191,8 +210,8 @@ class GraphedTrainStep:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=st):
                         with torch.enable_grad(), ag.grad_sinks(), tr.active(refresh=False):
-                            pred, aux = model(self.images[i * b:(i + 1) * b])
-                            loss = ag.uw_loss(pred, aux, self.labels[i * b:(i + 1) * b], self.cw, ce_scale, out_scale=1.0 / self.lanes, root=True)
+                            loss = forward_loss(model, self.images[i * b:(i + 1) * b], self.labels[i * b:(i + 1) * b], self.cw, ce_scale,
+                                                out_scale=1.0 / self.lanes, root=True)
                             loss.backward()
                     self.lane_graphs.append(g)
                     self.lane_losses.append(loss)

@@ -221,8 +221,76 @@ def test_uw_loss_vs_reference_golden(golden):
     torch.testing.assert_close(aux.grad.cpu(), torch.from_numpy(g['daux']), rtol=1e-3, atol=1e-8)
 
 
+# (N, C, main size, aux size, label size, ignore class): the model's x2 / x4 heads, odd sizes with a ragged last band, more than one
+# 256-column tile, 13 and 20 classes (exponentials recomputed), a class count on the predicated kernel, labels outside 0..C-1
+HEADS_CASES = [(2, 5, (16, 24), (8, 12), (32, 48), 4), (1, 13, (9, 11), (5, 6), (18, 22), None), (1, 5, (20, 150), (10, 75), (40, 300), 0),
+               (2, 20, (7, 40), (4, 20), (14, 80), 19), (1, 3, (12, 136), (6, 68), (23, 271), None), (3, 5, (5, 5), (5, 5), (5, 5), 4)]
+
+
+@pytest.mark.parametrize('case', HEADS_CASES, ids=lambda c: 'n%dc%d_%dx%d' % (c[0], c[1], c[4][0], c[4][1]))
+def test_uw_loss_at_head_resolution(case):
+    """mspl_uw_loss_heads_fwd_bwd (loss + gradients w.r.t. the two low-resolution decoder outputs, one launch) against the oracle's
+    loss on F.interpolate(..., align_corners=True) of both heads with torch autograd on the CPU, and against the three-step HIP form."""
+    from mspl_amd import autograd as ag, training
+    from oracle import labels as olab
+    N, C, ms, as_, size, ign = case
+    main = synth_input((N, C) + ms, 300 + C) * 2
+    aux = synth_input((N, C) + as_, 301 + C) * 2
+    tgt = synth_labels((N,) + size, C, 302 + C)
+    wild = ign is None                        # these cases carry labels outside 0..C-1: weight 0, as in the three-step kernel (the
+    if wild:                                  # oracle's loss is not defined on them: they are compared with the three-step form only)
+        tgt[0, 0, :2] = 255
+        tgt[-1, -1, -1] = -1
+    cw = torch.linspace(0.5, 1.5, C)
+    assert ag.uw_loss_heads_supported(C)
+    cwd = training._device_class_weights(cw, torch.device(DEV), ign)
+    mg, agd = main.to(DEV).requires_grad_(True), aux.to(DEV).requires_grad_(True)
+    loss = ag.uw_loss_heads(mg, agd, tgt.to(DEV), cwd)
+    loss.backward()
+    m3, a3 = main.to(DEV).requires_grad_(True), aux.to(DEV).requires_grad_(True)
+    l3 = ag.uw_loss(ag.bilinear(m3, size), ag.bilinear(a3, size), tgt.to(DEV), cwd)
+    l3.backward()
+    torch.testing.assert_close(loss.detach(), l3.detach(), rtol=1e-5, atol=1e-6)       # (v_exp_f32 / v_log_f32 softmax terms here, expf / logf there)
+    sm, sa = float(m3.grad.abs().max()), float(a3.grad.abs().max())
+    torch.testing.assert_close(mg.grad, m3.grad, rtol=1e-4, atol=2e-6 * sm)
+    torch.testing.assert_close(agd.grad, a3.grad, rtol=1e-4, atol=2e-6 * sa)
+    if not wild:
+        mr, ar = main.clone().requires_grad_(True), aux.clone().requires_grad_(True)
+        up = lambda t: F.interpolate(t, size=size, mode='bilinear', align_corners=True)      # noqa: E731
+        ref = olab.uest_train_loss(up(mr), up(ar), tgt, cw, ignore_idx=ign)
+        ref.backward()
+        torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(mg.grad.cpu(), mr.grad, rtol=1e-3, atol=1e-5 * sm)
+        torch.testing.assert_close(agd.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-5 * sa)
+
+
+def test_uw_loss_at_head_resolution_scaled_and_not_root():
+    """out_scale (a micro-batch lane's 1 / lanes) and an incoming gradient other than one; unsupported class counts are refused."""
+    from mspl_amd import autograd as ag, training
+    from oracle import labels as olab
+    N, C, ms, as_, size, ign = 2, 5, (18, 30), (9, 15), (36, 60), 4
+    main, aux = synth_input((N, C) + ms, 310) * 2, synth_input((N, C) + as_, 311) * 2
+    tgt = synth_labels((N,) + size, C, 312)
+    cw = torch.linspace(0.5, 1.5, C)
+    mr, ar = main.clone().requires_grad_(True), aux.clone().requires_grad_(True)
+    up = lambda t: F.interpolate(t, size=size, mode='bilinear', align_corners=True)      # noqa: E731
+    ref = olab.uest_train_loss(up(mr), up(ar), tgt, cw, ignore_idx=ign)
+    ref.backward()
+    mg, agd = main.to(DEV).requires_grad_(True), aux.to(DEV).requires_grad_(True)
+    loss = ag.uw_loss_heads(mg, agd, tgt.to(DEV), training._device_class_weights(cw, torch.device(DEV), ign), out_scale=0.25)
+    (loss * 4).backward()                     # not the root: the backward multiplies by the incoming 4
+    torch.testing.assert_close(loss.detach().cpu() * 4, ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mg.grad.cpu(), mr.grad, rtol=1e-3, atol=1e-5 * float(mr.grad.abs().max()))
+    torch.testing.assert_close(agd.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-5 * float(ar.grad.abs().max()))
+    assert not ag.uw_loss_heads_supported(11) and not ag.uw_loss_heads_supported(21)
+    with pytest.raises(RuntimeError, match='uw_loss_heads'):
+        ag.uw_loss_heads(torch.zeros(1, 11, 4, 4, device=DEV), torch.zeros(1, 11, 2, 2, device=DEV),
+                         torch.zeros(1, 8, 8, dtype=torch.int64, device=DEV), torch.ones(11, device=DEV))
+
+
+@pytest.mark.parametrize('loss_form', ['heads', 'upsampled'])
 @pytest.mark.parametrize('gname', sorted(TRAIN_CASES))
-def test_train_step_vs_reference_golden(gname, golden):
+def test_train_step_vs_reference_golden(gname, loss_form, golden):
     """ESPDNet-UE C=5, frozen BN, one Adam step: loss, gradient norms, the 230 gradient-less tensors, updated weights -- at 32x48 and
     at 64x96 (the streaming pyramid kernels, the matrix-core weight gradients and the fused EESP backward are reached by the second)."""
     from mspl_amd import models, training
@@ -235,8 +303,13 @@ def test_train_step_vs_reference_golden(gname, golden):
     x = synth_input(c['shape'], c['in_seed']).to(DEV)
     labels = synth_labels((c['shape'][0],) + c['shape'][2:], c['classes'], c['in_seed']).to(DEV)
     with torch.enable_grad():
-        pred, aux = m(x)
-        loss = training.uest_loss(pred, aux, labels, torch.ones(c['classes']), ignore_idx=c['ignore_idx'])
+        if loss_form == 'heads':              # what train_step does: the loss at head resolution, up-sampling inside the kernel
+            cwd = training._device_class_weights(torch.ones(c['classes']), torch.device(DEV), c['ignore_idx'])
+            loss = training.forward_loss(m, x, labels, cwd)
+            assert type(loss.grad_fn).__name__.startswith('UWLossHeadsFn')
+        else:                                 # the reference's own call sequence: model(x), then the loss on the full-size logits
+            pred, aux = m(x)
+            loss = training.uest_loss(pred, aux, labels, torch.ones(c['classes']), ignore_idx=c['ignore_idx'])
         loss.backward()
     torch.testing.assert_close(loss.detach().cpu(), torch.from_numpy(g['loss']), rtol=2e-5, atol=1e-5)
     params = dict(m.named_parameters())
@@ -379,8 +452,9 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(hw, monkeypatch):
     for step, tol in ((1, 1e-5), (2, 5e-4)):
         g1, g0 = outs[0][1][step], outs[1][1][step]
         assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max()) + 1e-7, step
+    # (weights after three Adam steps at lr 5e-4: an element whose gradient is noise around zero moves by up to lr per step either way)
     for k in outs[0][2]:
-        np.testing.assert_allclose(outs[0][2][k].cpu().numpy(), outs[1][2][k].cpu().numpy(), rtol=0, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(outs[0][2][k].cpu().numpy(), outs[1][2][k].cpu().numpy(), rtol=0, atol=1e-4, err_msg=k)
 
 
 def _ref_losses():
