@@ -92,6 +92,104 @@ __device__ __forceinline__ void wgrad_tile_body(const float* __restrict__ gy, co
     }
 }
 
+// ---- the same tile through LDS in full 128-byte lines (round 5).  The body above loads its MFMA fragments straight from memory: lane
+// (r, h) takes 16 bytes of row r, so ONE load instruction touches 32 rows x 32 bytes -- a quarter of every 128-byte line it opens, and
+// four instructions later the line has to be found again.  With loads only (no MFMA, no atomics) the 512 -> 512 expansion in 4 groups at
+// 16 x 18x30 (31.5 MB of operands) took 26 us, 1.2 TB/s.  Here a wave fills a private LDS stage with LDS-DMA pieces of 8 rows x 128 bytes
+// (global_load_lds_dwordx4: lane l of a piece reads 16 bytes of row l >> 3; destination = piece base + 16 l, so the XOR swizzle that
+// keeps the fragment reads conflict-free is applied to the SOURCE chunk: chunk (l & 7) ^ (l >> 3)), two stages of 32 pixels in flight,
+// and reads its fragments with ds_read_b128 at the swizzled slot.  Wave-private stages: no barrier in the loop, the wave waits on its
+// own vmcnt.  The four waves still hold four pixel slots of one tile and meet in LDS at the end.  (Seating the four waves on the 2x2
+// neighbouring tiles of one pixel slot instead -- shared operand rows through L1 -- was neutral on the fragment-load body: 6.17 vs 6.20 ms.)
+// Level-4 run of 16 problems (413 MB): 223 -> 158 us; graphed train step 6.12 -> 6.04 ms, same box.
+constexpr int WGL_STAGE = 2048;                  // floats per stage and wave: 32 rows x 32 pixels of each operand (2 x 4 pieces of 1 KiB)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void wgrad_tile_body_lds(const float* __restrict__ gy, const float* __restrict__ x, const WgG& g,
+                                                    float* __restrict__ gw, const int64_t bid, float* smem,
+                                                    const float* __restrict__ rowscale) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    const int bslots = g.nslots >> 2;
+    const int64_t tile = bid / bslots;
+    const int slot = (int)(bid - tile * bslots) * 4 + wave;
+    const int grp = (int)(tile / (g.tm * g.tk));
+    const int tt = (int)(tile - (int64_t)grp * g.tm * g.tk);
+    const int m0 = (tt / g.tk) * 32, k0 = (tt % g.tk) * 32;
+    float* wbuf = smem + wave * 2 * WGL_STAGE;
+    // fill side: piece j of an operand = rows 8 j .. 8 j + 7; this lane's row inside a piece and its (swizzled) 16-byte chunk
+    const int lr = lane >> 3, ck = (lane & 7) ^ lr;
+    const float* arow[4];
+    const float* brow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                // rows outside the tile read its first row; their products are never stored
+        const int ra = m0 + 8 * j + lr, rb = k0 + 8 * j + lr;
+        arow[j] = gy + ((size_t)grp * g.M + (ra < g.M ? ra : m0)) * (size_t)g.P;
+        brow[j] = x + ((size_t)grp * g.K + (rb < g.K ? rb : k0)) * (size_t)g.P;
+    }
+    const size_t aimg = (size_t)g.G * g.M * g.P, bimg = (size_t)g.G * g.K * g.P;
+    // read side: chunk c = 2 i + h of row r sits at slot (r & 7) * 8 + (c ^ (r & 7)) of piece r >> 3
+    const int rbase = (r >> 3) * 256 + (r & 7) * 32, rx = r & 7;
+    const int nq = (g.ngroups - slot + g.nslots - 1) / g.nslots;        // 64-pixel groups of this wave (slot < nslots <= ngroups)
+    const int S = 2 * nq;                                               // stages of 32 pixels
+    auto issue = [&](int s) {
+        const int q = slot + (s >> 1) * g.nslots;
+        const int n = q / g.gpi, p0 = (q - n * g.gpi) * 64 + 32 * (s & 1);
+        const int pc = min(p0 + 4 * ck, g.P - 4);                       // clamped: a chunk is entirely inside or outside the plane
+        float* dst = wbuf + (s & 1) * WGL_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds(arow[j] + (size_t)n * aimg + pc, (lds_ptr_t)(dst + j * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(brow[j] + (size_t)n * bimg + pc, (lds_ptr_t)(dst + 1024 + j * 256), 16, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S > 0) issue(0);                         // (a slot past the last pixel group has nothing to load: nslots is rounded up to 4)
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) {
+            issue(s + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // stage s has landed; the 8 pieces of stage s + 1 stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const int q = slot + (s >> 1) * g.nslots;
+        const int p0 = (q % g.gpi) * 64 + 32 * (s & 1);
+        const float* src = wbuf + (s & 1) * WGL_STAGE + rbase;
+        float4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 2 * i + h;
+            a[i] = *reinterpret_cast<const float4*>(src + ((c ^ rx) << 2));
+            b[i] = *reinterpret_cast<const float4*>(src + 1024 + ((c ^ rx) << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (p0 + 8 * i + 4 * h >= g.P) { a[i] = zero; b[i] = zero; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                             // every wave is done with its stages: the first 16 KiB become the reduction buffer
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(smem);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int i = e >> 6, l = e & 63;
+        const float v = (red[0][i][l] + red[1][i][l]) + (red[2][i][l] + red[3][i][l]);
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5), col = l & 31;
+        if (m0 + row < g.M && k0 + col < g.K)
+            atomicAdd(gw + ((size_t)grp * g.M + m0 + row) * g.K + k0 + col, rowscale ? v * rowscale[grp * g.M + m0 + row] : v);
+    }
+}
+
 __global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
                                                                  float* __restrict__ gw) {
     __shared__ float red[4][16][64];
@@ -114,6 +212,16 @@ struct WgBatch {
     WgProb p[WG_MAXP];
     int n;
 };
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_batch_lds_kernel(WgBatch b) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WGL_STAGE];          // 64 KiB: two workgroups per CU
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.n; ++i)
+        if (blockIdx.x >= b.p[i].first) k = i;                          // uniform
+    const WgProb& q = b.p[k];
+    wgrad_tile_body_lds(q.gy, q.x, q.g, q.gw, (int64_t)(blockIdx.x - q.first), smem, q.rowscale);
+}
 
 __global__ __launch_bounds__(256) void conv1x1_wgrad_batch_kernel(WgBatch b) {
     __shared__ float red[4][16][64];
@@ -161,7 +269,9 @@ int conv1x1_wgrad_mfma_batch(const float* const* gy, const float* const* x, floa
     }
     if (n == 0) return 0;
     b.n = n;
-    hipLaunchKernelGGL(conv1x1_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, b);
+    static const int lds_on = MSPL_TUNE_INT("MSPL_WGRAD_GLDS", 1);
+    if (lds_on) hipLaunchKernelGGL(conv1x1_wgrad_batch_lds_kernel, dim3((unsigned)total), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(conv1x1_wgrad_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, b);
     return n;
 }
 

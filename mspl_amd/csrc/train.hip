@@ -1218,7 +1218,8 @@ extern "C" int mspl_conv_bwd_weight(const float* gy, const float* x, int32_t N, 
         const int tiles_m = ceil_div(g.cout_g, 16), tiles_k = ceil_div(g.cin_g, 16);
         int64_t base = (int64_t)groups * tiles_m * tiles_k;
         int chunks = 1;
-        while (base * chunks < 2048 && total / (chunks * 2) >= 1024) chunks *= 2;
+        static const int minpx = MSPL_TUNE_INT("MSPL_WGRAD16_MINPX", 256);
+        while (base * chunks < 2048 && total / (chunks * 2) >= minpx) chunks *= 2;
         const int64_t blocks = base * chunks;
         MSPL_REQUIRE(blocks < (1ll << 31), MSPL_ERR_BAD_SHAPE, "conv_bwd_weight: grid too large");
         hipLaunchKernelGGL(conv1x1_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, chunks, tiles_m, tiles_k, gw);

@@ -443,7 +443,7 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(hw, monkeypatch):
             l, opt = training.train_step(m, x, y, cw, opt, ignore_idx=4)
             losses.append(float(l))
             grads.append(opt.flat_g.clone())
-        outs.append((losses, grads, {k: v.clone() for k, v in m.state_dict().items()}))
+        outs.append((losses, grads, opt.flat_p.clone()))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
     # Step 2 is the first one through the sinks and starts from weights that differ by float atomics' order only: tight.
     # By step 3 an ulp of difference in a weight can put one PReLU input of a 2x3 level-4 map on the other side of zero
@@ -452,9 +452,15 @@ def test_direct_gradient_sinks_equal_autograd_accumulation(hw, monkeypatch):
     for step, tol in ((1, 1e-5), (2, 5e-4)):
         g1, g0 = outs[0][1][step], outs[1][1][step]
         assert float((g1 - g0).abs().max()) <= tol * float(g0.abs().max()) + 1e-7, step
-    # (weights after three Adam steps at lr 5e-4: an element whose gradient is noise around zero moves by up to lr per step either way)
-    for k in outs[0][2]:
-        np.testing.assert_allclose(outs[0][2][k].cpu().numpy(), outs[1][2][k].cpu().numpy(), rtol=0, atol=1e-4, err_msg=k)
+    # Weights after the three Adam steps.  Adam divides by sqrt(v): an element whose gradient is rounding noise around zero (a dilated tap
+    # that only ever sees padding on a 2x3 map) moves by ~lr per step in the direction of that noise, so such elements differ by up to
+    # 2 * 3 * lr between ANY two runs; the elements with a gradient above the noise floor in all three steps must agree closely.
+    p1, p0 = outs[0][2], outs[1][2]
+    floor = 1e-2 * float(outs[1][1][0].abs().median())
+    solid = torch.stack([g.abs() for g in outs[1][1]]).min(0).values > floor
+    assert float(solid.float().mean()) > 0.5
+    assert float((p1 - p0)[solid].abs().max()) <= 2e-5
+    assert float((p1 - p0).abs().max()) <= 2 * 3 * 5e-4 + 1e-6
 
 
 def _ref_losses():
@@ -793,7 +799,9 @@ def test_conv1x1_weight_gradients_batched_in_one_launch():
     from mspl_amd import autograd as ag
     from mspl_amd._native import check, lib
     probs = [(2, 128, 512, 4, 16, 30), (3, 512, 128, 4, 16, 30), (1, 12, 24, 4, 8, 12), (2, 64, 48, 1, 36, 60), (1, 256, 256, 4, 5, 8),
-             (2, 32, 16, 1, 20, 36)]                     # (N, Cin, Cout, groups, H, W); the third one has 3 input channels per group
+             (2, 32, 16, 1, 20, 36), (2, 512, 512, 4, 9, 12), (1, 96, 80, 1, 10, 14)]
+    # (N, Cin, Cout, groups, H, W); the third one has 3 input channels per group; 2x2 or more 32x32 tiles per group (the fourth, fifth
+    # and the last two: 4x4 tiles, and 3x3 with a ragged last tile) sit four tiles to a workgroup
     gys, xs, gws, refs = [], [], [], []
     for i, (N, Cin, Cout, G, H, W) in enumerate(probs):
         x = rnd(N, Cin, H, W, seed=40 + i)
@@ -806,7 +814,8 @@ def test_conv1x1_weight_gradients_batched_in_one_launch():
     col = lambda k: (ctypes.c_int32 * n)(*[p[k] for p in probs])
     hw = (ctypes.c_int32 * n)(*[p[4] * p[5] for p in probs])
     # rowscale on the first and fourth problem: gw[co, :] += s[co] * sum (the gradient operand is the one BEFORE a per-channel scale)
-    rsc = [rnd(probs[0][2], seed=90).abs().to(DEV) + 0.5, None, None, rnd(probs[3][2], seed=91).abs().to(DEV) + 0.5, None, None]
+    rsc = [rnd(probs[0][2], seed=90).abs().to(DEV) + 0.5, None, None, rnd(probs[3][2], seed=91).abs().to(DEV) + 0.5, None, None, None,
+           rnd(probs[7][2], seed=92).abs().to(DEV) + 0.5]
     rs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in rsc])
     check(lib.mspl_conv1x1_wgrad_batch(arr(gys), arr(xs), arr(gws), rs, col(0), col(1), col(2), col(3), hw, n,
                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
