@@ -411,6 +411,8 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict
     float s = 0.f;
     if ((HW & 3) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
+        // (unrolled: four 16-byte loads in flight per thread, same order of additions)
+#pragma unroll 4
         for (int i = threadIdx.x; i < (HW >> 2); i += 256) { const float4 v = s4[i]; s += (v.x + v.y) + (v.z + v.w); }
     } else {
         for (int i = threadIdx.x; i < HW; i += 256) s += src[i];

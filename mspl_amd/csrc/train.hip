@@ -893,6 +893,19 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
                                                         float* __restrict__ out) {
     const size_t base = (size_t)blockIdx.x * HW;
     float s = 0.f;
+    if ((HW & 3) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0) {          // 16-byte operands, four quads per operand in flight
+        const float4* a4 = reinterpret_cast<const float4*>(a + base);
+        const float4* b4 = b ? reinterpret_cast<const float4*>(b + base) : nullptr;
+        const int L = HW >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < L; i += 256) {
+            const float4 x = a4[i], y = b4 ? b4[i] : one;
+            s0 = fmaf(x.x, y.x, s0); s1 = fmaf(x.y, y.y, s1); s2 = fmaf(x.z, y.z, s2); s3 = fmaf(x.w, y.w, s3);
+        }
+        s = (s0 + s1) + (s2 + s3);
+    } else
     for (int i = threadIdx.x; i < HW; i += 256) s = fmaf(a[base + i], b ? b[base + i] : 1.f, s);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
@@ -912,6 +925,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     if (idx < Cout * Cin) {
         const int co = idx / Cin, ci = idx - co * Cin;
         float s = 0.f;
+        // (unrolled: the loads of eight iterations leave together; one iteration at a time the two loops were 16 + Cout dependent L2
+        // round trips: 20-31 us per launch for ~1 MB)
+#pragma unroll 8
         for (int n = 0; n < N; ++n) {
             const float gt = gate[n * Cout + co];
             s = fmaf(ggate[n * Cout + co] * gt * (1.f - gt), mean[n * Cin + ci], s);
@@ -921,6 +937,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     if (idx < N * Cin) {
         const int n = idx / Cin, ci = idx - n * Cin;
         float s = 0.f;
+#pragma unroll 8
         for (int co = 0; co < Cout; ++co) {
             const float gt = gate[n * Cout + co];
             s = fmaf(ggate[n * Cout + co] * gt * (1.f - gt), w[co * Cin + ci], s);
