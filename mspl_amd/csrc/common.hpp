@@ -251,6 +251,21 @@ __device__ __forceinline__ void bilinear_src_hp(float scale, int dst, int in_siz
     w0 = 1.0f - lam;
 }
 
+// Sum over the 64 lanes of a wave, total in lane 63: seven DPP adds (a __shfl_down ladder is six ds_bpermute round trips).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    // total in lane 63 (row_shr 1, 2, 3 within rows of 16, then across bank groups and rows: the canonical 7-step DPP reduction)
+#define MSPL_DPP(x, ctrl, rm, bm) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rm, bm, true))
+    float t = v + MSPL_DPP(v, 0x111, 0xf, 0xf);
+    t += MSPL_DPP(v, 0x112, 0xf, 0xf);
+    t += MSPL_DPP(v, 0x113, 0xf, 0xf);
+    t += MSPL_DPP(t, 0x114, 0xf, 0xe);
+    t += MSPL_DPP(t, 0x118, 0xf, 0xc);
+    t += MSPL_DPP(t, 0x142, 0xa, 0xf);          // row_bcast:15
+    t += MSPL_DPP(t, 0x143, 0xc, 0xf);          // row_bcast:31
+#undef MSPL_DPP
+    return t;
+}
+
 static inline float bilinear_scale(int in_size, int out_size) {
     return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
 }

@@ -77,9 +77,8 @@ __global__ __launch_bounds__(256) void pyr_down_mid_bwd_kernel(PdbGeom g) {
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_down(s[k], o, 64);
-            if ((tid & 63) == 0) red[k][tid >> 6] = s[k];
+            s[k] = wave_sum_dpp(s[k]);                        // total in lane 63
+            if ((tid & 63) == 63) red[k][tid >> 6] = s[k];
         }
         __syncthreads();
         if (tid < 9 && cnt > 0) atomicAdd(g.gw[bi] + (size_t)c * 9 + tid, (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));

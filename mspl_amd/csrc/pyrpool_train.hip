@@ -468,9 +468,8 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             float t = dwacc[i][k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-            if ((tid & 63) == 0) red[tid >> 6][k] = t;
+            t = wave_sum_dpp(t);                              // total in lane 63
+            if ((tid & 63) == 63) red[tid >> 6][k] = t;
         }
         __syncthreads();
         if (tid < 9) atomicAdd(&g.b[i].gw[(size_t)c * 9 + tid], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));

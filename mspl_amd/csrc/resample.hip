@@ -138,20 +138,6 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_kernel(const float* __restri
 // branches): 13 M of a label pass's 262 M.  Here: grid = (strips, channel, image) -- no division; 32-bit offsets on uniform bases;
 // the epilogue is exactly scale / shift / three reinforcement planes / PReLU; the plane-sum partial goes through DPP adds.
 // Same arithmetic in the same order as avgpool3x3s2_kernel<true> with that epilogue (bit-identical outputs and plane sums).
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    // total in lane 63 (row_shr 1, 2, 3 within rows of 16, then across bank groups and rows: the canonical 7-step DPP reduction)
-#define MSPL_DPP(x, ctrl, rm, bm) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rm, bm, true))
-    float t = v + MSPL_DPP(v, 0x111, 0xf, 0xf);
-    t += MSPL_DPP(v, 0x112, 0xf, 0xf);
-    t += MSPL_DPP(v, 0x113, 0xf, 0xf);
-    t += MSPL_DPP(t, 0x114, 0xf, 0xe);
-    t += MSPL_DPP(t, 0x118, 0xf, 0xc);
-    t += MSPL_DPP(t, 0x142, 0xa, 0xf);          // row_bcast:15
-    t += MSPL_DPP(t, 0x143, 0xc, 0xf);          // row_bcast:31
-#undef MSPL_DPP
-    return t;
-}
-
 struct DpGeom {
     int C, Hi, Wi, Ho, Wo, XS;        // input channels (= pooled channels), sizes, strips per output row
     unsigned mag_xs;

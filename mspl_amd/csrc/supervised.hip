@@ -399,9 +399,8 @@ __global__ __launch_bounds__(1024) void bn_train_small_bwd_kernel(const float* _
     float v[3] = {s_scale, s_shift, s_alpha};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o, 64);
-        if ((tid & 63) == 0) part[i][tid >> 6] = v[i];
+        v[i] = wave_sum_dpp(v[i]);                            // total in lane 63
+        if ((tid & 63) == 63) part[i][tid >> 6] = v[i];
     }
     __syncthreads();
     if (tid == 0) {

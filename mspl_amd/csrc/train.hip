@@ -138,10 +138,8 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_kernel(const float* __res
     __shared__ float part[4][CG * 9];
 #pragma unroll
     for (int t = 0; t < CG * 9; ++t) {
-        float v = acc[t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][t] = v;
+        const float v = wave_sum_dpp(acc[t]);                  // total in lane 63
+        if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6][t] = v;
     }
     __syncthreads();
     if (threadIdx.x < CG * 9)
@@ -216,10 +214,8 @@ __global__ __launch_bounds__(256) void g3x3_bwd_weight_strip_kernel(const float*
     __shared__ float part[4][CG * 9];
 #pragma unroll
     for (int t = 0; t < CG * 9; ++t) {
-        float v = acc[t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][t] = v;
+        const float v = wave_sum_dpp(acc[t]);                  // total in lane 63
+        if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6][t] = v;
     }
     __syncthreads();
     if (threadIdx.x < CG * 9)
@@ -287,10 +283,8 @@ __global__ __launch_bounds__(256, 3) void g3x3_bwd_weight_cob_kernel(const float
     for (int c = 0; c < COB; ++c)
 #pragma unroll
         for (int t = 0; t < CG * 9; ++t) {
-            float v = acc[c][t];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c * CG * 9 + t] = v;
+            const float v = wave_sum_dpp(acc[c][t]);           // total in lane 63
+            if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6][c * CG * 9 + t] = v;
         }
     __syncthreads();
     if (threadIdx.x < COB * CG * 9)
@@ -367,10 +361,8 @@ __global__ __launch_bounds__(256, 3) void g3x3_bwd_weight_s2_strip_kernel(const 
     for (int c = 0; c < COB; ++c)
 #pragma unroll
         for (int t = 0; t < CG * 9; ++t) {
-            float v = acc[c][t];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c * CG * 9 + t] = v;
+            const float v = wave_sum_dpp(acc[c][t]);           // total in lane 63
+            if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6][c * CG * 9 + t] = v;
         }
     __syncthreads();
     if (threadIdx.x < COB * CG * 9)
@@ -524,9 +516,8 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_kernel(const float* __re
     __shared__ float part[3][4];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
-        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v[k];
+        v[k] = wave_sum_dpp(v[k]);                            // total in lane 63
+        if ((threadIdx.x & 63) == 63) part[k][threadIdx.x >> 6] = v[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1127,9 +1118,8 @@ __global__ __launch_bounds__(256) void hff_bn_prelu_suffix_kernel(const float* _
         float v[3] = {s_sc[k], s_sh[k], s_al[k]};
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v[t] += __shfl_down(v[t], o, 64);
-            if ((threadIdx.x & 63) == 0) part[k * 3 + t][threadIdx.x >> 6] = v[t];
+            v[t] = wave_sum_dpp(v[t]);                        // total in lane 63
+            if ((threadIdx.x & 63) == 63) part[k * 3 + t][threadIdx.x >> 6] = v[t];
         }
     }
     __syncthreads();
