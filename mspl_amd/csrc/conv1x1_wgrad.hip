@@ -196,6 +196,12 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_kernel(const float* __
     wgrad_tile_body(gy, x, g, gw, (int64_t)blockIdx.x, red);
 }
 
+__global__ __launch_bounds__(256) void conv1x1_wgrad_mfma_lds_kernel(const float* __restrict__ gy, const float* __restrict__ x, WgG g,
+                                                                     float* __restrict__ gw) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * WGL_STAGE];
+    wgrad_tile_body_lds(gy, x, g, gw, (int64_t)blockIdx.x, smem, nullptr);
+}
+
 // Several weight-gradient problems in ONE launch (mspl_conv1x1_wgrad_batch): the grouped 1x1 convolutions of a training step are
 // ~33 launches of 8-25 us for <= 7 us of matrix work each, and nothing downstream waits for any of them -- the autograd nodes queue
 // them (autograd.WgradQueue) and the queue goes out as a few launches whose grids are the problems' grids back to back.
@@ -297,7 +303,9 @@ int conv1x1_wgrad_mfma_try(const float* gy, const float* x, int N, int G, int M,
     g.nslots = (int)((ns + 3) & ~3ll);
     const int64_t blocks = tiles * (g.nslots >> 2);
     if (blocks >= (1ll << 31)) return 1;
-    hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, gw);
+    static const int lds_on = MSPL_TUNE_INT("MSPL_WGRAD_GLDS", 1);
+    if (lds_on) hipLaunchKernelGGL(conv1x1_wgrad_mfma_lds_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, gw);
+    else hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, x, g, gw);
     return 0;
 }
 

@@ -201,10 +201,8 @@ __global__ __launch_bounds__(64 * NB) void pyr_merge_bwd_kernel(const float* __r
     for (int k = 0; k < 9; ++k) v[k] = dw[k];
     v[9] = a_sc;  v[10] = a_sh;  v[11] = a_al;  v[12] = q_sc;  v[13] = q_sh;  v[14] = q_al;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);       // every lane ends with the wave's total
-    }
+    for (int k = 0; k < 15; ++k)             // every lane ends with the wave's total (seven DPP adds + one readlane: the xor ladder was 90 ds_bpermute)
+        v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_dpp(v[k])), 63));
     if (lane < 9) {
         float t = v[0];
 #pragma unroll
@@ -682,10 +680,8 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream_kernel(const float*
     // ---- stage weight gradient: wave sum, one atomic per tap and wave
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        float t = dw[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-        if (lane == 0) atomicAdd(&gw[(size_t)c * 9 + k], t);
+        const float t = wave_sum_dpp(dw[k]);                      // total in lane 63
+        if (lane == 63) atomicAdd(&gw[(size_t)c * 9 + k], t);
     }
 }
 
@@ -924,10 +920,8 @@ __global__ __launch_bounds__(256) void pyr_branch_bwd_stream3_kernel(const float
     auto flush = [&](float (&dw)[9], float* gw) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            float t = dw[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
-            if (lane == 0) atomicAdd(&gw[(size_t)c * 9 + k], t);
+            const float t = wave_sum_dpp(dw[k]);                  // total in lane 63
+            if (lane == 63) atomicAdd(&gw[(size_t)c * 9 + k], t);
         }
     };
     flush(dwa, gw0);
