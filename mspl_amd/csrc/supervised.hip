@@ -588,7 +588,9 @@ extern "C" int mspl_bn_train_small_fwd(const float* z, const float* residual, co
     MSPL_REQUIRE(mspl_bn_train_small_fits(N, C, HW), MSPL_ERR_UNSUPPORTED, "bn_train_small_fwd: N=%d C=%d HW=%d is not a small-plane shape", N, C, HW);
     MSPL_REQUIRE((HW & 3) != 0 || ((((uintptr_t)z) | ((uintptr_t)residual) | ((uintptr_t)y)) & 15) == 0, MSPL_ERR_BAD_SHAPE,
                  "bn_train_small_fwd: operands must be 16-byte aligned");
-    const int nt_f = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= 2048 ? 1024 : 256;
+    // 1024 threads from MSPL_BN_SMALL_WIDE units (quads, or floats when HW % 4 != 0) per channel on, 256 below
+    static const int wide_f = MSPL_TUNE_INT("MSPL_BN_SMALL_WIDE", 2048);
+    const int nt_f = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= wide_f ? 1024 : 256;
     hipLaunchKernelGGL(bn_train_small_fwd_kernel, dim3((unsigned)C), dim3(nt_f), 0, (hipStream_t)stream, z, residual, gamma, beta, alpha, N, C,
                        HW, eps, momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), mean, invstd, scale,
                        shift, y);
@@ -606,7 +608,8 @@ extern "C" int mspl_bn_train_small_bwd(const float* z, const float* residual, co
     MSPL_REQUIRE(mspl_bn_train_small_fits(N, C, HW), MSPL_ERR_UNSUPPORTED, "bn_train_small_bwd: N=%d C=%d HW=%d is not a small-plane shape", N, C, HW);
     MSPL_REQUIRE((HW & 3) != 0 || ((((uintptr_t)z) | ((uintptr_t)residual) | ((uintptr_t)gy) | ((uintptr_t)gz) | ((uintptr_t)gres)) & 15) == 0,
                  MSPL_ERR_BAD_SHAPE, "bn_train_small_bwd: operands must be 16-byte aligned");
-    const int nt_b = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= 2048 ? 1024 : 256;
+    static const int wide_b = MSPL_TUNE_INT("MSPL_BN_SMALL_WIDE", 2048);
+    const int nt_b = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW) >= wide_b ? 1024 : 256;
     hipLaunchKernelGGL(bn_train_small_bwd_kernel, dim3((unsigned)C), dim3(nt_b), 0, (hipStream_t)stream, z, residual, gy, scale, shift, alpha,
                        gamma, mean, invstd, N, C, HW, (float)(1.0 / ((double)N * (double)HW)), accumulate, gz, gres, ggamma, gbeta, galpha);
     MSPL_CHECK_LAUNCH("bn_train_small_bwd");
