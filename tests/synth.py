@@ -163,3 +163,25 @@ def synth_adversarial_logits(C, seed, pixels=2048):
     shape = (n // 64, 8, 8, C)
     to = lambda t: torch.from_numpy(np.ascontiguousarray(t.reshape(shape).transpose(0, 3, 1, 2)))
     return to(pred), to(aux), a.reshape(shape[:3]), b.reshape(shape[:3]), k.reshape(shape[:3])
+
+
+def assert_weights_close_after_adam(got, want, lr, steps, tight=5e-5, frac=0.01):
+    """Weights of two runs of the same Adam steps whose gradients differ by rounding (float atomics land in a different order).
+    Adam divides by sqrt(v): an element whose gradient is rounding noise around zero moves by ~lr per step in the direction of
+    that noise, and an ulp of difference in a weight can put one PReLU input of a tiny map on the other side of zero, which moves
+    the gradients of that block by per cent (tools/diag_sinks.py).  So: every element within 2 * lr * steps, and all but `frac`
+    of them within `tight` -- a missing, doubled or misplaced gradient moves far more than one per cent of the elements.
+    got / want: dicts of tensors (state_dicts), tensors or arrays."""
+    import numpy as np
+    import torch
+
+    def flat(v):
+        if isinstance(v, dict):
+            return np.concatenate([t.detach().float().cpu().numpy().ravel() for t in v.values() if torch.is_floating_point(t)])
+        return (v.detach().float().cpu().numpy() if torch.is_tensor(v) else np.asarray(v, dtype=np.float32)).ravel()
+    a, b = flat(got), flat(want)
+    assert a.shape == b.shape
+    d = np.abs(a - b)
+    assert float(d.max()) <= 2.0 * lr * steps + tight, 'largest difference %.3g > 2 * lr * steps' % float(d.max())
+    loose = float((d > tight).mean())
+    assert loose <= frac, '%.4f of the elements differ by more than %g' % (loose, tight)

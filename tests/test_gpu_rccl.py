@@ -101,4 +101,5 @@ def test_train_step_with_rccl_all_reduce_between_graph_and_adam(nccl_world1):
         outs.append((losses, step.optimizer.flat_p.detach().cpu().numpy()))
     # float atomics order the gradient sums differently from run to run: same tolerances as test_micro_batch_lanes_equal_one_graph
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-4, atol=1e-6)
-    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=0, atol=5e-5)
+    from tests.synth import assert_weights_close_after_adam
+    assert_weights_close_after_adam(outs[1][1], outs[0][1], lr=5e-4, steps=3)
