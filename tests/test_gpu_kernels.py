@@ -256,7 +256,10 @@ def test_conv1x1_epilogues(cfg):
     # units per wave, a partly filled last wave, Shuffle-aware input channels; the other group shapes stay on the LDS-tiled kernel
     (2, 128, 48, 16, 24, 120, 1, 0), (1, 256, 64, 64, 12, 60, 1, 0), (2, 3, 3, 1, 18, 32, 1, 0), (1, 48, 128, 16, 10, 40, 1, 0),
     (1, 64, 256, 64, 9, 28, 1, 0), (1, 80, 30, 10, 16, 32, 1, 5), (3, 8, 3, 1, 29, 256, 1, 0), (1, 3, 3, 1, 50, 16, 1, 0),
-    (3, 64, 16, 16, 29, 256, 1, 0), (2, 80, 20, 20, 16, 32, 1, 5), (1, 32, 128, 32, 7, 20, 1, 0)])
+    (3, 64, 16, 16, 29, 256, 1, 0), (2, 80, 20, 20, 16, 32, 1, 5), (1, 32, 128, 32, 7, 20, 1, 0),
+    # the LDS-tiled kernel's lean staging (stride 1, one tile per row, W % 4 == 0, no Shuffle): narrowest row, a single row,
+    # a row count that leaves a short last tile, a last chunk shared by the spare threads
+    (1, 8, 3, 1, 3, 8, 1, 0), (2, 16, 6, 2, 1, 12, 1, 0), (2, 16, 6, 2, 41, 124, 1, 0), (1, 24, 9, 3, 19, 128, 1, 0)])
 def test_conv3x3(cfg):
     from mspl_amd import ops
     from mspl_amd.ops import Epi
