@@ -302,6 +302,27 @@ def test_bilinear_align_corners(cfg):
     close(got, F.prelu((ref + pre) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), alpha))
 
 
+@pytest.mark.parametrize('align', [True, False])
+@pytest.mark.parametrize('cfg', [((2, 3, 40, 64), (16, 32)), ((1, 5, 9, 16), (27, 16)), ((3, 2, 17, 20), (17, 40)), ((1, 2, 3, 8), (64, 8)),
+                                 ((2, 2, 72, 120), (144, 240))])
+def test_bilinear_streaming_walks(cfg, align):
+    """The register-streaming bilinear kernel keeps two horizontally interpolated source rows and walks down the output rows:
+    walks that jump more than one source row per output row (down-scaling), that repeat a row many
+    times (x21), unchanged heights, several planes per wave -- with pre_add AND residual operands -- against torch-CPU fp32."""
+    from mspl_amd import ops
+    from mspl_amd.ops import Epi
+    shape, size = cfg
+    x = rnd(*shape, seed=11)
+    ref = F.interpolate(x, size, mode='bilinear', align_corners=align)
+    C = shape[1]
+    pre, res = rnd(shape[0], C, *size, seed=12), rnd(shape[0], C, *size, seed=13)
+    scale, shift, alpha = rnd(C, seed=3).abs() + 0.5, rnd(C, seed=4) * 0.1, rnd(C, seed=5).abs() * 0.3
+    got = ops.bilinear(x.to(DEV), size, Epi(scale.to(DEV), shift.to(DEV), alpha.to(DEV), pre_add=pre.to(DEV), residual=res.to(DEV)),
+                       align_corners=align)
+    close(got, F.prelu((ref + pre) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res, alpha))
+    close(ops.bilinear(x.to(DEV), size, align_corners=align), ref, atol=1e-5)
+
+
 @pytest.mark.parametrize('cfg', [((2, 4, 32, 60), (16, 30)), ((1, 3, 24, 45), (16, 30)), ((1, 2, 16, 30), (5, 5)),
                                  ((1, 2, 6, 9), (5, 5)), ((1, 3, 128, 240), (13, 24)), ((1, 2, 5, 7), (5, 7)),
                                  ((1, 2, 192, 360), (128, 240))])
