@@ -26,7 +26,7 @@ struct C3Geom {
     int nvec;          // 16-byte chunks per staged row
     unsigned mag_nvec, mag_ih;   // ceil(2^32 / d): exact division of small counts by mul-hi
     unsigned xcd_per, total;     // XCD-contiguous tile order (common.hpp): neighbouring tiles share halo rows
-    int fast;                    // stride 1, one tile per row (TW == W), W % 4 == 0, no Shuffle, 16-byte-aligned x: lean staging
+    int fast;                    // W % 4 == 0, no Shuffle, 16-byte-aligned x: lean staging (2: stride 1 and one tile per row)
     unsigned mag_nv;             // ceil(2^32 / (W / 4))
 };
 
@@ -63,11 +63,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     // flat by all 256 threads with UL independent global loads in flight per thread before the first LDS write
     // (aligned 16-byte loads when W % 4 == 0, scalar LDS writes since ix0 = -1 mod 4, zero fill outside the image).
     const int per_plane = g.IH * g.IWS;
-    if (STRIDE == 1 && g.fast) {
-        // Lean staging (uniform choice): every staged row is a whole image row or a whole row of padding, a chunk is one aligned
-        // 16-byte load, LDS column j <-> input column j - 1.  The general walk below costs ~100 vector instructions per chunk
-        // (four guarded scalar loads and stores, Shuffle index division); on the 8 -> 3 grouped expansion at 72x120 that was
-        // two thirds of the kernel's instructions.  Here: two mul-hi divisions, one clamped load, one select, four LDS stores.
+    if (STRIDE == 1 && g.fast == 2) {
+        // Lean staging, whole-row tiles (stride 1, TW == W): LDS column j <-> input column j - 1, W / 4 chunks per row, four
+        // unguarded LDS stores per chunk, the four padding columns of a row written separately.  128 -> 48 in 16 groups at 16 x 72x120:
+        // 41.3 us (general walk) -> 40.6 (the guarded lean form below) -> 35.6 us (this form with 8-row tiles).
         constexpr int UL = 5;
         const int nv = g.W >> 2;
         const int rows = g.cin_g * g.IH;
@@ -99,6 +98,42 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         for (int i = tid; i < rows * 4; i += 256) {
             const int rr = i >> 2, q = i & 3;
             tile[rr * g.IWS + (q == 0 ? 0 : g.W + q)] = 0.f;
+        }
+    } else if (g.fast) {
+        // Lean staging (uniform choice; W % 4 == 0, no Shuffle, 16-byte-aligned planes): a staged row is a whole image row or padding,
+        // a 16-byte chunk lies wholly inside or outside the row (ix0 = -1 mod 4), so a chunk is one aligned load or zeros.  The
+        // general walk below costs ~100 vector instructions per chunk (four guarded scalar loads, 64-bit addresses, the Shuffle index
+        // division).  Stem 3 -> 32 stride 2 at 16 x 288x480: 35.8 -> 33.5 us.
+        constexpr int UL = 5;
+        const int c_lo = ix0 - 3;
+        const int total = g.cin_g * g.IH * g.nvec;
+        const float* xg = x + ((size_t)img * g.Cin + (size_t)grp * g.cin_g) * (size_t)g.H * g.W;
+        for (int base = 0; base < total; base += 256 * UL) {
+            float4 t4[UL];
+            int dst[UL], jcol[UL];
+            bool in[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int i = min(base + u * 256 + tid, total - 1);      // the last chunk is re-written by the spare threads
+                const int rr = (int)__umulhi((unsigned)i, g.mag_nvec), v = i - rr * g.nvec;
+                const int ci = (int)__umulhi((unsigned)rr, g.mag_ih), r = rr - ci * g.IH;
+                const int iy = iy0 + r, c0 = c_lo + 4 * v;
+                in[u] = iy >= 0 && iy < g.H && c0 >= 0 && c0 < g.W;
+                const int iyc = min(max(iy, 0), g.H - 1), c0c = min(max(c0, 0), g.W - 4);
+                t4[u] = *reinterpret_cast<const float4*>(xg + (unsigned)((ci * g.H + iyc) * g.W + c0c));   // < 2^29 (host check)
+                jcol[u] = 4 * v - 3;
+                dst[u] = rr * g.IWS + jcol[u];
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const float e0 = in[u] ? t4[u].x : 0.f, e1 = in[u] ? t4[u].y : 0.f, e2 = in[u] ? t4[u].z : 0.f, e3 = in[u] ? t4[u].w : 0.f;
+                float* d = tile + dst[u];
+                const int jq = jcol[u];                                   // LDS column of element 0: 4 v - 3
+                if (jq >= 0 && jq < g.IWS) d[0] = e0;
+                if (jq + 1 >= 0 && jq + 1 < g.IWS) d[1] = e1;
+                if (jq + 2 >= 0 && jq + 2 < g.IWS) d[2] = e2;
+                if (jq + 3 < g.IWS) d[3] = e3;
+            }
         }
     } else {
         constexpr int UL = 4;
@@ -498,13 +533,13 @@ static int launch3(const float* x, const float* w, C3Geom g, const Epi& e, float
     auto lds_of = [&](int th) {
         return ((size_t)g.cin_g * ((th - 1) * STRIDE + 3) * g.IWS + (size_t)g.cout_g * g.cin_g * 9 + (size_t)g.cout_g * 6) * sizeof(float);
     };
-    g.fast = STRIDE == 1 && g.tiles_x == 1 && g.TW == g.W && (g.W & 3) == 0 && g.sg == 0 && (((uintptr_t)x) & 15) == 0 &&
-             g.IWS >= g.W + 4 && g.W >= 8 && (int64_t)g.cin_g * g.H * g.W < (1ll << 29);
+    g.fast = (g.W & 3) == 0 && g.W >= 8 && g.sg == 0 && (((uintptr_t)x) & 15) == 0 && (int64_t)g.cin_g * g.H * g.W < (1ll << 29);
+    if (g.fast && STRIDE == 1 && g.tiles_x == 1 && g.TW == g.W && g.IWS >= g.W + 4) g.fast = 2;
     g.mag_nv = (unsigned)((0x100000000ull + (g.W >> 2) - 1) / std::max(g.W >> 2, 1));
     int th = g.Ho < 16 ? g.Ho : 16;
     // lean staging: a tile of 8 rows of the 8-plane groups (41.9 KB) keeps 240 of 256 threads on strips; at 4 rows it was 120
     static const int fast_cap_kb = MSPL_TUNE_INT("MSPL_C3_CAPKB", 48);
-    const size_t lds_cap = g.fast ? (size_t)fast_cap_kb * 1024 : 40 * 1024;
+    const size_t lds_cap = g.fast == 2 ? (size_t)fast_cap_kb * 1024 : 40 * 1024;
     while (th > 1 && lds_of(th) > lds_cap) th = (th + 1) / 2;
     // keep 256 threads busy: shrink the tile only while it still holds >= 256 strips
     while (th > 2 && (int64_t)g.coblks * (th / 2) * g.XS >= 512) th = th / 2;
