@@ -1300,9 +1300,11 @@ static int affine_prelu_bwd_launch(const float* c, const float* pre_add, const f
                                    const float* bn_mean, const float* bn_inv, void* stream, BnTail tl = BnTail()) {
     MSPL_REQUIRE(c && gy, MSPL_ERR_NULL_POINTER, "affine_prelu_bwd: null pointer");
     MSPL_REQUIRE(N > 0 && C > 0 && HW > 0, MSPL_ERR_BAD_SHAPE, "affine_prelu_bwd: bad shape N=%d C=%d HW=%d", N, C, HW);
-    // ~MSPL_AFF_BLOCKS workgroups (default 768: three per CU keep the memory system busy with two 16-byte loads per operand in
-    // flight per thread), at least ~2 units per thread, and as few same-address atomic chains per channel as that allows
-    static const int target = MSPL_TUNE_INT("MSPL_AFF_BLOCKS", 768);
+    // ~MSPL_AFF_BLOCKS workgroups, at least ~2 units per thread, and as few same-address atomic chains per channel as that allows.
+    // 384 (1.5 per CU; four 16-byte loads per operand in flight per thread): inside the training steps, where two micro-batch lanes
+    // run side by side, the leaner grid is the faster one (same box, alternating: 768 / 512 / 384 / 256 -> uest step 5.73 / 5.68 /
+    // 5.665 / 5.67 ms, supervised 8.73 / 8.68 / 8.65 / 8.68 ms; rounds 2-4 ran 768, tuned on the kernel alone)
+    static const int target = MSPL_TUNE_INT("MSPL_AFF_BLOCKS", 384);
     const int64_t units = (int64_t)N * ((HW & 3) == 0 ? HW / 4 : HW);
     int64_t parts = ceil_div64(target, C);
     if (parts > units / 512) parts = units / 512;
