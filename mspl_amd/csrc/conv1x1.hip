@@ -884,7 +884,8 @@ static int launch_pipe(const float* x, const float* w, PwGeom g, const Epi& e, c
     g.ptiles = (int)ceil_div64((int64_t)g.N * g.HW, 32 * nsub);
     // workgroups: at most one resident round (3 per CU), each walking TPW tiles per wave
     int tpw = 1;
-    while ((int64_t)g.G * g.mblocks * ceil_div(g.ptiles, wp * tpw) > 768) ++tpw;
+    static const int pipe_wgs = MSPL_TUNE_INT("MSPL_PW_PIPE_WGS", 768);
+    while ((int64_t)g.G * g.mblocks * ceil_div(g.ptiles, wp * tpw) > pipe_wgs) ++tpw;
     if (dbg_tpw) tpw = dbg_tpw;
     g.TPW = tpw;
     g.pgroups = ceil_div(g.ptiles, wp * tpw);

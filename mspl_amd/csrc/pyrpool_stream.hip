@@ -26,6 +26,13 @@
 namespace mspl {
 
 constexpr int P3_MAXB = 5;
+// Branch rows per trip of the row loop.  One row per trip pays ~60 of its ~312 vector instructions for moving the sliding windows at
+// the back edge (hipcc does not unroll the loop by itself: `#pragma unroll 2` is refused); with two steps in the loop body the windows
+// are renamed between them: rocprofv3 inside the label pass, alternating libraries, 43.4 -> 41.9 us per launch at 144x240 / 72x120,
+// 24.2 -> 22.9 us for the one-pixel form.  Three and five steps (222 / 256 registers, no spill) are SLOWER (47.6 / 49.0 us).
+#ifndef P3_STEPS
+#define P3_STEPS 2
+#endif
 constexpr int P3_SEGMAX = 19;       // (SEG + 2) * 3 table entries are computed by the 64 lanes in one step
 
 struct Pyr3Geom {
@@ -252,8 +259,9 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < PXL; ++j) acc[r][j] = 0.f;
 
-#pragma unroll 1
-    for (int br = ys - 1; br <= ye; ++br) {
+    // Two branch rows per trip of the loop: the sliding windows (x rows, low-resolution samples, merge accumulators) are renamed
+    // between the two steps instead of moved, the moves are paid once per trip at the back edge.
+    auto row_step = [&](const int br) __attribute__((always_inline)) {
         // ---- branch maps of row br
         float bv[5][PXL];
         const bool rowin = br >= 0 && br < h;
@@ -368,6 +376,14 @@ __global__ __launch_bounds__(256, 2) void pyrpool_stream_kernel(const float* __r
         }
 #pragma unroll
         for (int j = 0; j < PXL; ++j) { acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = 0.f; }
+    };
+    constexpr int STEPS = TRAIN ? 2 : P3_STEPS;            // (the training forward holds more per row: two steps fit its registers)
+#pragma unroll 1
+    for (int br = ys - 1; br <= ye; br += STEPS) {
+        row_step(br);
+#pragma unroll
+        for (int u = 1; u < STEPS; ++u)
+            if (br + u <= ye) row_step(br + u);
     }
 }
 
