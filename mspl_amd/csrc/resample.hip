@@ -144,6 +144,13 @@ struct DpGeom {
     int ctot;                         // channels of the destination tensor
 };
 
+// RAG: rows of Wo = 4k + 2 outputs (the level-4 DownSampler of a 480-wide input: 60 -> 30 columns).  The last strip of a row
+// owns two outputs and its second 16-byte piece lies past the row (taken as zeros, as the padding is); pixel offsets are
+// 8-byte aligned only, so the epilogue moves float2 halves.  That launch used to take the generic strip kernel above, where
+// the ragged strip sent every wave through both its load paths and the guarded element stores: 5.4 M of a label pass's vector
+// instructions for one launch.  Outputs are bit-identical to that kernel's; the plane-sum partials of a ragged strip are
+// added in the tree order of the other strips (the generic kernel's element path added them left to right).
+template <bool RAG>
 __global__ __launch_bounds__(256) void avgpool3x3s2_down_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ alpha,
                                                                 const float* __restrict__ reinf_r, const float* __restrict__ reinf_w,
@@ -164,7 +171,13 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_down_kernel(const float* __r
             m[ky] = (iy >= 0 && iy < g.Hi) ? 1.f : 0.f;
             const unsigned o = (unsigned)(min(max(iy, 0), g.Hi - 1) * g.Wi + 2 * x0);
             a[ky] = *reinterpret_cast<const float4*>(src + o);
-            b[ky] = *reinterpret_cast<const float4*>(src + o + 4);
+            if (!RAG) {
+                b[ky] = *reinterpret_cast<const float4*>(src + o + 4);
+            } else {
+                const bool bok = 2 * x0 + 4 < g.Wi;                                  // whole piece inside the row or whole piece outside
+                const float4 t = *reinterpret_cast<const float4*>(src + (bok ? o + 4 : o));
+                b[ky] = bok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             l[ky] = src[x0 > 0 ? o - 1 : o];
         }
         const float lm = x0 > 0 ? 1.f : 0.f;
@@ -183,9 +196,21 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_down_kernel(const float* __r
         const float sc = scale[c], sh = shift[c], al = alpha[c];                     // uniform
         const float rw0 = reinf_w[c * 3], rw1 = reinf_w[c * 3 + 1], rw2 = reinf_w[c * 3 + 2];
         const float* r = reinf_r + (size_t)n * 3 * hw;                               // uniform
-        const float4 r0 = *reinterpret_cast<const float4*>(r + pix);
-        const float4 r1 = *reinterpret_cast<const float4*>(r + hw + pix);
-        const float4 r2 = *reinterpret_cast<const float4*>(r + 2 * hw + pix);
+        float4 r0, r1, r2;
+        const bool hi = !RAG || x0 + 2 < g.Wo;                                       // RAG: outputs x0 + 2, x0 + 3 exist
+        if (!RAG) {
+            r0 = *reinterpret_cast<const float4*>(r + pix);
+            r1 = *reinterpret_cast<const float4*>(r + hw + pix);
+            r2 = *reinterpret_cast<const float4*>(r + 2 * hw + pix);
+        } else {
+            const unsigned p2 = hi ? pix + 2 : pix;
+            const float2 a0 = *reinterpret_cast<const float2*>(r + pix), b0 = *reinterpret_cast<const float2*>(r + p2);
+            const float2 a1 = *reinterpret_cast<const float2*>(r + hw + pix), b1 = *reinterpret_cast<const float2*>(r + hw + p2);
+            const float2 a2 = *reinterpret_cast<const float2*>(r + 2 * hw + pix), b2 = *reinterpret_cast<const float2*>(r + 2 * hw + p2);
+            r0 = make_float4(a0.x, a0.y, b0.x, b0.y);
+            r1 = make_float4(a1.x, a1.y, b1.x, b1.y);
+            r2 = make_float4(a2.x, a2.y, b2.x, b2.y);
+        }
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[j] * (1.0f / 9.0f), sc, sh);
@@ -195,7 +220,13 @@ __global__ __launch_bounds__(256) void avgpool3x3s2_down_kernel(const float* __r
         v[3] += rw0 * r0.w + rw1 * r1.w + rw2 * r2.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : al * v[j];
-        store_out4(out + ((size_t)n * g.ctot + c) * (size_t)hw + pix, make_float4(v[0], v[1], v[2], v[3]));
+        float* dst = out + ((size_t)n * g.ctot + c) * (size_t)hw + pix;
+        if (!RAG) {
+            store_out4(dst, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+            store_out2(dst, make_float2(v[0], v[1]));
+            if (hi) store_out2(dst + 2, make_float2(v[2], v[3]));
+        }
     }
     own = wave_sum_dpp(own);
     __shared__ float part[4];
@@ -479,11 +510,17 @@ extern "C" int mspl_avgpool3x3s2_psum_fwd(const float* x, int32_t N, int32_t C, 
     if (int rc = resample_common("avgpool3x3s2_psum", x, out, N, C, H, W, Ho, Wo, ep, g, e, total)) return rc;
     // the DownSampler's call (scale, shift, PReLU and the image reinforcement on an un-gated destination with whole 16-byte rows): lean form
     if (e.scale && e.shift && e.alpha && e.reinf_r && e.reinf_w && !e.pre_add && !e.residual && !e.gate && !e.raw && e.coff == 0 &&
-        (W & 3) == 0 && (Wo & 3) == 0 && (H & 1) == 0 && C <= 65535 && N <= 65535 && (int64_t)H * W < (1ll << 30) &&
+        (W & 3) == 0 && (H & 1) == 0 && C <= 65535 && N <= 65535 && (int64_t)H * W < (1ll << 30) &&
         ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)e.reinf_r)) & 15) == 0) {
+        // W = 4k: Wo = 2k is a whole number of 16-byte strips or (RAG) ends in one 8-byte half; plane sizes Ho * Wo are even
         DpGeom d;
         d.C = C; d.Hi = H; d.Wi = W; d.Ho = Ho; d.Wo = Wo; d.XS = g.XS; d.mag_xs = g.mag_xs; d.ctot = e.ctot;
-        hipLaunchKernelGGL(avgpool3x3s2_down_kernel, dim3((unsigned)ceil_div(Ho * g.XS, 256), (unsigned)C, (unsigned)N), dim3(256), 0,
+        const dim3 grid((unsigned)ceil_div(Ho * g.XS, 256), (unsigned)C, (unsigned)N);
+        if ((Wo & 3) == 0)
+            hipLaunchKernelGGL(avgpool3x3s2_down_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, e.scale, e.shift, e.alpha,
+                               e.reinf_r, e.reinf_w, d, out, psum);
+        else
+            hipLaunchKernelGGL(avgpool3x3s2_down_kernel<true>, grid, dim3(256), 0,
                            (hipStream_t)stream, x, e.scale, e.shift, e.alpha, e.reinf_r, e.reinf_w, d, out, psum);
         MSPL_CHECK_LAUNCH("avgpool3x3s2_psum(DownSampler form)");
         return MSPL_OK;

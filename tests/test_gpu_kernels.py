@@ -508,6 +508,38 @@ def test_avgpool_plane_sums_and_gate_from_sums(shape):
     assert torch.equal(sums2, sums) and torch.equal(ops.gate_from_sums(sums2, w.to(DEV), shape[2] * shape[3]), g1)
 
 
+@pytest.mark.parametrize('shape', [(2, 6, 36, 60), (1, 3, 4, 4), (2, 5, 6, 20), (2, 4, 8, 24), (1, 2, 2, 8), (16, 128, 36, 60)])
+def test_downsampler_pool_lean_forms_equal_the_strip_kernel(shape):
+    """The DownSampler's pool call (nn_layers/eesp.py:131-144: avg_pool into channels [0, nin) + BatchNorm fold + image
+    reinforcement + PReLU, with the input's plane sums) takes a lean kernel when W % 4 == 0: whole 16-byte strips (Wo % 4 == 0)
+    or rows that end in a two-output strip (Wo % 4 == 2: 60 -> 30 columns at level 4 of a 480-wide input).  The same call into a
+    destination slice at channel 1 takes the generic strip kernel: identical bits out, plane sums equal up to the order of the
+    additions; both against the definition in torch-CPU fp32."""
+    from mspl_amd import ops
+    N, C, H, W = shape
+    Ho, Wo, ctot = H // 2, W // 2, C + 2
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, C, H, W, generator=g)
+    sc, sh, al = torch.rand(ctot, generator=g) + 0.5, torch.randn(ctot, generator=g), torch.rand(ctot, generator=g) * 0.3
+    rw = torch.randn(ctot, 3, generator=g) * 0.5
+    r = torch.randn(N, 3, Ho, Wo, generator=g)
+    xd = x.to(DEV)
+    lean = torch.zeros(N, ctot, Ho, Wo, device=DEV)
+    _, s_lean = ops.avgpool3x3s2(xd, ops.Epi(sc.to(DEV), sh.to(DEV), al.to(DEV), reinf_r=r.to(DEV), reinf_w=rw.to(DEV)),
+                                 out=(lean, 0), plane_sums=True)
+    strip = torch.zeros(N, ctot, Ho, Wo, device=DEV)
+    roll = lambda v: torch.roll(v, 1, 0).contiguous().to(DEV)
+    _, s_strip = ops.avgpool3x3s2(xd, ops.Epi(roll(sc), roll(sh), roll(al), reinf_r=r.to(DEV), reinf_w=roll(rw)),
+                                  out=(strip, 1), plane_sums=True)
+    assert torch.equal(lean[:, :C], strip[:, 1:1 + C])
+    assert torch.count_nonzero(lean[:, C:]) == 0 and torch.count_nonzero(strip[:, 0]) == 0      # nothing outside the slice
+    torch.testing.assert_close(s_lean.sum(1), s_strip.sum(1), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(s_lean.sum(1).cpu().view(N, C), x.double().sum((2, 3)).float(), rtol=1e-5, atol=1e-3)
+    want = F.avg_pool2d(x, 3, 2, 1) * sc[:C].view(1, -1, 1, 1) + sh[:C].view(1, -1, 1, 1) + torch.einsum('ck,nkhw->nchw', rw[:C], r)
+    want = torch.where(want > 0, want, want * al[:C].view(1, -1, 1, 1))
+    close(lean[:, :C], want, atol=1e-5)
+
+
 def test_label_epilogue_hist_fits_and_fallback():
     """Shapes outside the LDS-staged form (heads at or near the output resolution: staged rows wider than 256 columns) are reported
     by label_epilogue_hist_fits; SelfLabelPass then takes label_epilogue + merge_labels(S=1), the two-launch form, instead of
